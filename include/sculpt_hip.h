@@ -1,0 +1,173 @@
+/*
+ * sculpt_hip.h -- C ABI of libsculpt_hip.so, the MI355X (gfx950) implementation of the
+ * TripoSR generation hot path of SculptMate.
+ *
+ * Every entry point replaces a piece of the reference's Python/torch hot path (file:line are
+ * relative to the reference repository root):
+ *
+ *   sculpt_triplane_query        TriplaneNeRFRenderer.query_triplane + NeRFMLP.forward
+ *                                  TripoSR/tsr/models/nerf_renderer.py:41-91
+ *                                  TripoSR/tsr/models/network_utils.py:116-124
+ *   sculpt_density_grid          TSR.extract_mesh's dense query over MarchingCubeHelper.grid_vertices
+ *                                  TripoSR/tsr/system.py:171-183, TripoSR/tsr/models/isosurface.py:25-39
+ *   sculpt_mc_*                  MarchingCubeHelper.forward -> skimage.measure.marching_cubes(vol, 0.0)
+ *                                  TripoSR/tsr/models/isosurface.py:41-54
+ *   sculpt_gemm_bf16 / sculpt_attention_bf16 / sculpt_layernorm / sculpt_groupnorm_tokens /
+ *   sculpt_vit_* / sculpt_upsample_scatter
+ *                                Transformer1D / BasicTransformerBlock / Attention / GEGLU,
+ *                                  HF ViTModel, TriplaneUpsampleNetwork
+ *                                  TripoSR/tsr/models/transformer/transformer_1d.py:179-219
+ *                                  TripoSR/tsr/models/transformer/basic_transformer_block.py:149-206,291-315
+ *                                  TripoSR/tsr/models/transformer/attention.py:569-653
+ *                                  TripoSR/tsr/models/tokenizers/image.py:41-60
+ *                                  TripoSR/tsr/models/network_utils.py:24-32
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.  All data pointers are DEVICE
+ *     pointers (HBM) unless the parameter name ends in _host.
+ *   - every function returns 0 on success, non-zero on error; the message is available from
+ *     sculpt_last_error() (thread local).  Nothing is retained past the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Launch functions are
+ *     asynchronous and graph-capturable unless stated otherwise.
+ *   - there is NO CPU fallback: without a usable HIP device the launch functions fail.
+ */
+#ifndef SCULPT_HIP_H
+#define SCULPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCULPT_ABI_VERSION 1
+
+typedef void *sculpt_stream_t;
+
+int sculpt_version(void);
+const char *sculpt_last_error(void);
+/* number of visible HIP devices (0 if none); never fails */
+int sculpt_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * NeRF decoder weights.  The reference MLP is Linear(3*C,64)+SiLU, NH x [Linear(64,64)+SiLU],
+ * Linear(64,4)  (network_utils.py:48-79; C=40, NH=8 in TripoSR/checkpoints/config.yaml:23-28).
+ * sculpt_mlp_pack re-orders the torch-layout weights (HOST pointers, W[l] is [out][in] row
+ * major) into the lane order the MFMA kernels read; the caller uploads the packed blob.
+ * ------------------------------------------------------------------------------------------ */
+size_t sculpt_mlp_packed_bytes(int in_channels, int n_hidden_64);
+int sculpt_mlp_pack(const float *const *W_host, const float *const *b_host, int n_layers,
+                    const int *dims_host, void *packed_host, size_t packed_bytes);
+
+/* query_triplane at arbitrary points.
+ *   planes      f32 [3][C][H][W]   (scene code of one image, TSR.forward output layout)
+ *   mlp_packed  blob from sculpt_mlp_pack (device copy); n_hidden_64 = the NH it was packed with
+ *   points      f32 [N][3] in (-radius, radius)
+ *   outputs (each may be NULL): density [N], features [N][3], density_act [N], color [N][3]
+ *   density_act = exp(density + density_bias), color = sigmoid(features)  (nerf_renderer.py:82-87) */
+int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *mlp_packed,
+                          int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,
+                          float *density, float *features, float *density_act, float *color,
+                          sculpt_stream_t stream);
+
+/* Dense density grid: density_act at lattice points (ix,iy,iz), ix in [x_begin,x_end), flat order
+ * ix*R*R + iy*R + iz (isosurface.py:34-37), positions taken from axis_coords[R] (the lattice is
+ * separable; axis_coords[i] is the coordinate in (-radius,radius) of index i, computed by the host
+ * exactly as the reference does: linspace(0,1,R) then scale_tensor, system.py:177-181).
+ *   workspace   sculpt_density_grid_workspace_bytes(R, x_end-x_begin) bytes of scratch
+ *   out         f32 [(x_end-x_begin)*R*R]
+ * The first MLP layer is applied per plane before the per-point sum (linear in the bilinear
+ * samples); see DESIGN.md "fused sample+MLP kernel". */
+size_t sculpt_density_grid_workspace_bytes(int R, int nx);
+int sculpt_density_grid(const float *planes, int C, int H, int W, const void *mlp_packed,
+                        int n_hidden_64, const float *axis_coords, int R, int x_begin, int x_end, float radius,
+                        float density_bias, void *workspace, float *out, sculpt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Marching cubes (Lewiner), output identical to skimage.measure.marching_cubes(vol, level)
+ * with default arguments, including vertex and face ORDER.
+ *   vol f32 [n0][n1][n2] C order.  Two phases: count (synchronises the stream, returns sizes),
+ *   then emit into caller-allocated buffers.
+ *   flags: SCULPT_MC_REFERENCE_ORDER  faces columns reordered [1,0,2] and stored as int64,
+ *          verts multiplied by vert_scale (isosurface.py:52-53) then mapped v*a + b
+ *          (scale_tensor, system.py:185-189) when SCULPT_MC_AFFINE is set.
+ * Errors: SCULPT_ERR_MC_LEVEL (level outside data range -> skimage ValueError),
+ *         SCULPT_ERR_MC_EMPTY (no surface -> skimage RuntimeError).
+ * ------------------------------------------------------------------------------------------ */
+#define SCULPT_MC_FACES_I64 1u
+#define SCULPT_MC_REFERENCE_ORDER 2u
+#define SCULPT_MC_USE_CLASSIC 4u
+#define SCULPT_ERR_MC_LEVEL 11
+#define SCULPT_ERR_MC_EMPTY 12
+
+size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2);
+int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsigned flags,
+                    void *workspace, int64_t *n_verts_host, int64_t *n_faces_host,
+                    sculpt_stream_t stream);
+int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsigned flags,
+                   void *workspace, float vert_div, float vert_mul, float vert_add,
+                   float *verts, void *faces, sculpt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Transformer primitives (bf16 storage, fp32 accumulate).  bf16 values are uint16_t bit patterns.
+ * ------------------------------------------------------------------------------------------ */
+#define SCULPT_EPI_NONE 0
+#define SCULPT_EPI_GELU 1   /* out = gelu_erf(acc + bias) */
+#define SCULPT_EPI_GEGLU 2  /* W holds [2*N][K]: out[:, n] = (acc_n + b_n) * gelu_erf(acc_{N+n} + b_{N+n}) */
+
+/* out[M][N] = epi(A[M][K] . W[N][K]^T + bias[N]) (+ residual[M][N], fp32)
+ *   A, W bf16 (K contiguous); bias fp32 or NULL; residual fp32 [M][ldr] or NULL;
+ *   outputs (any subset, at least one): out_f32 [M][ldo] fp32, out_bf16 [M][ldo] bf16,
+ *   out_bf16_t [N][ldt] bf16 = the transposed result (used to hand V^T to the attention kernel).
+ *   lda/ldw/ldo/ldt are row strides in elements.  K % 64 == 0; N % 128 == 0 (GEGLU: W has 2N rows,
+ *   N % 64 == 0); any M >= 1 (ragged last tile handled). */
+int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
+                     const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
+                     uint16_t *out_bf16_t, int ldt, int M, int N, int K, int epilogue,
+                     sculpt_stream_t stream);
+
+/* softmax(Q K^T * scale) V per head, no mask (attention.py:629-631; HF ViTSelfAttention).
+ *   Q [Tq][ldq], K [Tk][ldk] bf16 with head h at columns h*64 .. h*64+63;
+ *   Vt [heads*64][ldvt] bf16 = V transposed (row = h*64 + d, column = key); ldvt >= round_up(Tk, 64)
+ *   and the columns >= Tk must hold finite values (they are multiplied by exact zeros);
+ *   O [Tq][ldo] bf16.  Head dim is 64. */
+int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
+                          int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, float scale,
+                          sculpt_stream_t stream);
+
+/* y = LayerNorm(x) * gamma + beta over the last dim (rows x cols), x fp32 or bf16, y bf16 */
+int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const float *gamma,
+                     const float *beta, float eps, uint16_t *y, int ldy, float *y_f32, int rows, int cols,
+                     sculpt_stream_t stream);
+
+/* GroupNorm over x [C][T] fp32 (groups of C/G channels x T tokens, transformer_1d.py:183) written
+ * transposed as tokens y [T][C] bf16 */
+int sculpt_groupnorm_tokens(const float *x, int C, int T, int G, const float *gamma, const float *beta,
+                            float eps, uint16_t *y, float *stats_ws /* 2*G floats scratch */,
+                            sculpt_stream_t stream);
+
+/* out[c][t] = x[t][c] + residual[c][t]  (proj_out permute + residual, transformer_1d.py:211-217) */
+int sculpt_transpose_add(const float *x_tc, const float *residual_ct, float *out_ct, int T, int C,
+                         sculpt_stream_t stream);
+
+/* ViT front end (tokenizers/image.py:48 + HF ViTEmbeddings): normalise (x-mean)/std and cut
+ * [3][S][S] fp32 image into patch rows [S/P * S/P][3*P*P] bf16 (conv16/16 stride 16 as a GEMM) */
+int sculpt_vit_patchify(const float *image_hwc, int S, int P, const float *mean3_host, const float *std3_host,
+                        uint16_t *patches, sculpt_stream_t stream);
+/* tokens[0] = cls + pos[0]; tokens[1+i] = patch_out[i] + pos[1+i]  (fp32 residual stream) */
+int sculpt_vit_assemble(const float *patch_out, const float *cls, const float *pos, float *tokens,
+                        int n_patches, int hidden, sculpt_stream_t stream);
+
+/* ConvTranspose2d(k=2,s=2) epilogue: g [3*S*S][ldg] fp32 (GEMM output, column = co*4 + dy*2 + dx)
+ * + bias[Co] -> planes [3][Co][2S][2S]  (network_utils.py:20-32) */
+int sculpt_upsample_scatter(const float *g, int ldg, const float *bias, float *planes, int S, int Co,
+                            sculpt_stream_t stream);
+
+/* fp32 -> bf16 (round to nearest even), n elements */
+int sculpt_cast_bf16(const float *x, uint16_t *y, int64_t n, sculpt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCULPT_HIP_H */

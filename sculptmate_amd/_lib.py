@@ -1,0 +1,76 @@
+"""ctypes binding of libsculpt_hip.so -- the C ABI declared in include/sculpt_hip.h.
+
+There is no fallback: if the extension has not been built this module raises at import, and the
+launch functions fail when no HIP device is usable.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so first so both share ONE HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libsculpt_hip.so")
+
+
+class SculptError(RuntimeError):
+    def __init__(self, msg, code=1):
+        super().__init__(msg)
+        self.code = code
+
+
+if not os.path.exists(SO_PATH):
+    raise ImportError(
+        "sculptmate_amd: %s is missing -- build it with `python -m sculptmate_amd.build` "
+        "(or __graft_entry__.build()); there is no CPU fallback." % SO_PATH)
+
+lib = ctypes.CDLL(SO_PATH)
+
+_vp, _i, _i64, _f, _sz, _u = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                              ctypes.c_size_t, ctypes.c_uint)
+_pp = ctypes.POINTER(ctypes.c_void_p)
+_pi64 = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "sculpt_version": (_i, []),
+    "sculpt_last_error": (ctypes.c_char_p, []),
+    "sculpt_device_count": (_i, []),
+    "sculpt_mlp_packed_bytes": (_sz, [_i, _i]),
+    "sculpt_mlp_pack": (_i, [_pp, _pp, _i, _vp, _vp, _sz]),
+    "sculpt_triplane_query": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_density_grid_workspace_bytes": (_sz, [_i, _i]),
+    "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sculpt_mc_count": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _pi64, _pi64, _vp]),
+    "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp]),
+    "sculpt_groupnorm_tokens": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "sculpt_transpose_add": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sculpt_vit_patchify": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sculpt_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "sculpt_upsample_scatter": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    "sculpt_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+MC_FACES_I64 = 1
+MC_REFERENCE_ORDER = 2
+MC_USE_CLASSIC = 4
+ERR_MC_LEVEL = 11
+ERR_MC_EMPTY = 12
+EPI_NONE, EPI_GELU, EPI_GEGLU = 0, 1, 2
+
+
+def last_error():
+    return (lib.sculpt_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise SculptError(last_error() or ("sculpt error %d" % rc), rc)

@@ -1,0 +1,177 @@
+// Flash-style fused attention (no mask, head dim 64, bf16 in/out, fp32 softmax) for gfx950.
+//
+// Replaces F.scaled_dot_product_attention at
+//   TripoSR/tsr/models/transformer/attention.py:629-631   (self 3072x3072, cross 3072x1025; 16 heads)
+// and the eager softmax(QK^T/8)V of HF ViTSelfAttention (12 heads, 1025 tokens).
+//
+// One workgroup = 4 waves = 128 queries of one head; each wave owns 32 queries.  Per 64-key tile:
+//   S^T = K . Q^T   on v_mfma_f32_32x32x16_bf16 with the QUERY on the lane (column) -- so a lane
+//         holds 2x16 scores of ONE query: row max / row sum are in-register reductions plus one
+//         cross-half exchange, no LDS round trip.
+//   O^T += V^T . P^T: the S^T accumulator registers, converted pairwise to bf16, are directly the
+//         B operand of the second product (k order permuted to key = 16s + 8(j>>2) + 4h + (j&3));
+//         the A operand V^T is read from LDS in that same key order.  V arrives already transposed
+//         ([head*64+d][key], written by the QKV GEMM epilogue), so no transposing read is needed.
+// K and V^T tiles are register-prefetched one tile ahead into double-buffered LDS (one barrier per
+// tile); K rows use the (row>>1)&7 chunk swizzle so ds_read_b128 is conflict-free.
+#include "common.h"
+
+namespace sculpt {
+
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int a_lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restrict__ Q, int ldq,
+                                                        const uint16_t *__restrict__ K, int ldk,
+                                                        const uint16_t *__restrict__ Vt, int ldvt,
+                                                        uint16_t *__restrict__ O, int ldo, int Tq, int Tk,
+                                                        float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[2][64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[2][64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qc = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + qc;
+    const int qld = min(q, Tq - 1);
+
+    // Q fragments (B operand): Q[q][16*ks + 8h + j]
+    abf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const abf16x8 *>(Q + (long)qld * ldq + head * 64 + ks * 16 + h * 8);
+
+    // staging: K tile 64 keys x 8 chunks, V^T tile 64 d x 8 chunks; 2 chunks each per thread
+    const int nt = (Tk + 63) / 64;
+    uint4 kreg[2], vreg[2];
+    int sdst[2], srow[2], scol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i;
+        srow[i] = id >> 3; scol[i] = id & 7;
+        sdst[i] = a_lds_off(srow[i], scol[i]);
+    }
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(t * 64 + srow[i], Tk - 1);
+            kreg[i] = *reinterpret_cast<const uint4 *>(K + (long)key * ldk + head * 64 + scol[i] * 8);
+            vreg[i] = *reinterpret_cast<const uint4 *>(Vt + (long)(head * 64 + srow[i]) * ldvt + t * 64 + scol[i] * 8);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4 *>(&Ks[buf][sdst[i]]) = kreg[i];
+            *reinterpret_cast<uint4 *>(&Vs[buf][sdst[i]]) = vreg[i];
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) gload(t + 1);
+        // ---- S^T = K . Q^T
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const abf16x8 k0 = *reinterpret_cast<const abf16x8 *>(&Ks[buf][a_lds_off(qc, 2 * ks + h)]);
+            const abf16x8 k1 = *reinterpret_cast<const abf16x8 *>(&Ks[buf][a_lds_off(32 + qc, 2 * ks + h)]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+        }
+        // ---- online softmax over this lane's 32 keys (+ the other half's 32)
+        const int kbase = t * 64 + 4 * h;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key0 = kbase + (r & 3) + 8 * (r >> 2);
+            s0[r] = (key0 < Tk) ? s0[r] * scale_log2e : -INFINITY;
+            s1[r] = (key0 + 32 < Tk) ? s1[r] * scale_log2e : -INFINITY;
+            mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        // ---- O^T += V^T . P^T   (4 k-steps of 16 keys: (kt, s) = (0,0),(0,1),(1,0),(1,1))
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            abf16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = (kk < 2) ? s0[8 * (kk & 1) + j] : s1[8 * (kk & 1) + j];
+                pb[j] = (__bf16)pv;
+            }
+            // keys of element j: 16*kk + 8*(j>>2) + 4h + (j&3)  -> two 8-byte reads per d row
+            const int c0 = 2 * kk, c1 = 2 * kk + 1;
+            abf16x8 v0, v1;
+            {
+                const abf16x4 a = *reinterpret_cast<const abf16x4 *>(&Vs[buf][a_lds_off(qc, c0) + 8 * h]);
+                const abf16x4 b = *reinterpret_cast<const abf16x4 *>(&Vs[buf][a_lds_off(qc, c1) + 8 * h]);
+                v0 = abf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                const abf16x4 c = *reinterpret_cast<const abf16x4 *>(&Vs[buf][a_lds_off(32 + qc, c0) + 8 * h]);
+                const abf16x4 d = *reinterpret_cast<const abf16x4 *>(&Vs[buf][a_lds_off(32 + qc, c1) + 8 * h]);
+                v1 = abf16x8{c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+            }
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
+        }
+        if (t + 1 < nt) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < Tq) {
+        uint16_t *orow = O + (long)q * ldo + head * 64;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // registers 4*g4 .. 4*g4+3 are d = 8*g4 + 4h + {0..3}
+            abf16x4 a, b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = (__bf16)(o0[4 * g4 + r] * inv);
+                b[r] = (__bf16)(o1[4 * g4 + r] * inv);
+            }
+            *reinterpret_cast<abf16x4 *>(orow + 8 * g4 + 4 * h) = a;
+            *reinterpret_cast<abf16x4 *>(orow + 32 + 8 * g4 + 4 * h) = b;
+        }
+    }
+}
+
+}  // namespace sculpt
+
+using namespace sculpt;
+
+extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
+                                     int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, float scale,
+                                     sculpt_stream_t stream) {
+    SC_REQUIRE(Q && K && Vt && O, "attention: null argument");
+    SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
+    SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
+    SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
+    hipLaunchKernelGGL(attention_kernel, dim3(cdiv(Tq, 128), heads), dim3(256), 0, as_stream(stream), Q, ldq, K, ldk,
+                       Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

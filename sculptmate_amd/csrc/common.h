@@ -1,0 +1,54 @@
+// Shared helpers for the gfx950 kernels and their C-ABI launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/sculpt_hip.h"
+
+namespace sculpt {
+
+void set_error(const char *fmt, ...);
+
+#define SC_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            sculpt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),    \
+                              __FILE__, __LINE__);                                       \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+
+#define SC_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            sculpt::set_error(__VA_ARGS__);   \
+            return 2;                         \
+        }                                     \
+    } while (0)
+
+#define SC_LAUNCH_CHECK() SC_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(sculpt_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// number of CUs of the current device (cached)
+int num_cus();
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (plain cast path of the guide is not available for raw bits)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+}  // namespace sculpt

@@ -1,0 +1,722 @@
+// Marching cubes (Lewiner) on gfx950, output identical -- including vertex and face ORDER -- to
+// skimage.measure.marching_cubes(vol, level) with default arguments, which is what the reference
+// calls on the CPU at TripoSR/tsr/models/isosurface.py:46-48 (MarchingCubeHelper.forward :41-54).
+//
+// The sequential algorithm visits cells with the slowest array axis outermost and creates a
+// vertex the first time a cell touches a lattice edge.  The parallel restatement:
+//   * cell order            = C-order linear index of the cell grid (n0-1, n1-1, n2-1)
+//   * owner of an edge      = the first of the (up to 4) cells sharing it in that order; every
+//                             Lewiner tiling uses exactly the sign-changing edges of its cell
+//                             (checked over all tables in tests/test_mc_tables.py), so ownership is
+//                             purely geometric
+//   * vertex id             = exclusive scan over cells of "#vertices owned", plus the rank of the
+//                             edge among the owner's owned vertices in first-appearance order of the
+//                             owner's triangle list (centre vertex 12 is always owned)
+//   * face offset           = exclusive scan over cells of "#triangles"
+// Passes (each one thread per cell, 256 cells per workgroup, wave-level prefix scans):
+//   count : classify, per-block (ntri, nown) sums, data min/max
+//   scan  : exclusive scan of the block sums (single workgroup), totals
+//   verts : re-classify, block scan, owners write vertex positions + lattice-edge -> id map
+//   faces : re-classify, block scan, every active cell writes its triangles through the map
+// HBM traffic: 3 reads of the volume (4 B/voxel each) + 12 B/vertex + 12|24 B/face + sparse map.
+#include <float.h>
+#include <string.h>
+
+#include "common.h"
+#include "mc_luts.h"
+
+// The CPU implementation rounds every double operation separately (x86-64, no FMA contraction);
+// keep the device arithmetic identical.
+#pragma clang fp contract(off)
+
+namespace sculpt {
+
+static constexpr double MC_EPS = 2.220446049250313e-16;  // skimage: np.spacing(1.0)
+static constexpr int MC_BLOCK = 256;
+
+// device copies of the tables
+__constant__ signed char d_tiling_flat[MC_TILING_FLAT_SIZE];
+__constant__ unsigned short d_tiling_base[MC_NUM_TILINGS];
+__constant__ unsigned char d_tiling_rowlen[MC_NUM_TILINGS];
+__constant__ unsigned char d_tiling_inner[MC_NUM_TILINGS];
+__constant__ signed char d_cases[512];
+__constant__ signed char d_cases_classic[256 * 16];
+__constant__ signed char d_test3[24], d_test4[8], d_test6[48 * 3], d_test7[16 * 5], d_test10[6 * 3],
+    d_test12[24 * 4], d_test13[2 * 7], d_subconfig13[64];
+
+static bool g_tables_uploaded[64] = {false};
+
+static int upload_tables() {
+    int dev = 0;
+    SC_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && g_tables_uploaded[dev]) return 0;
+#define UP(sym, src) SC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sym), src, sizeof(src)))
+    UP(d_tiling_flat, mc_tiling_flat);
+    UP(d_tiling_base, mc_tiling_base);
+    UP(d_tiling_rowlen, mc_tiling_rowlen);
+    UP(d_tiling_inner, mc_tiling_inner);
+    UP(d_cases, mc_cases);
+    UP(d_cases_classic, mc_cases_classic);
+    UP(d_test3, mc_test3);
+    UP(d_test4, mc_test4);
+    UP(d_test6, mc_test6);
+    UP(d_test7, mc_test7);
+    UP(d_test10, mc_test10);
+    UP(d_test12, mc_test12);
+    UP(d_test13, mc_test13);
+    UP(d_subconfig13, mc_subconfig13);
+#undef UP
+    if (dev >= 0 && dev < 64) g_tables_uploaded[dev] = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// classification (per cell); v[8] = corner values minus level (double), Lewiner corner order
+// ---------------------------------------------------------------------------------------------
+__device__ bool test_face(const double *v, int face) {
+    const int af = face < 0 ? -face : face;
+    double A, B, C, D;
+    switch (af) {
+        case 1: A = v[0]; B = v[4]; C = v[5]; D = v[1]; break;
+        case 2: A = v[1]; B = v[5]; C = v[6]; D = v[2]; break;
+        case 3: A = v[2]; B = v[6]; C = v[7]; D = v[3]; break;
+        case 4: A = v[3]; B = v[7]; C = v[4]; D = v[0]; break;
+        case 5: A = v[0]; B = v[3]; C = v[2]; D = v[1]; break;
+        default: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
+    }
+    // no contraction: A*C and B*D are rounded separately in the CPU implementation
+    const double ac = __dmul_rn(A, C), bd = __dmul_rn(B, D);
+    const double acbd = __dsub_rn(ac, bd);
+    if (acbd > -MC_EPS && acbd < MC_EPS) return face >= 0;
+    return __dmul_rn(__dmul_rn((double)face, A), acbd) >= 0;
+}
+
+__device__ bool test_internal(const double *v, int mc_case, int config, int subconfig, int s) {
+    double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
+    int test = 0;
+#define MUL(a, b) __dmul_rn((a), (b))
+#define ADD(a, b) __dadd_rn((a), (b))
+#define SUB(a, b) __dsub_rn((a), (b))
+    if (mc_case == 4 || mc_case == 10) {
+        const double a = SUB(MUL(SUB(v[4], v[0]), SUB(v[6], v[2])), MUL(SUB(v[7], v[3]), SUB(v[5], v[1])));
+        const double b = SUB(SUB(ADD(MUL(v[2], SUB(v[4], v[0])), MUL(v[0], SUB(v[6], v[2]))),
+                                 MUL(v[1], SUB(v[7], v[3]))),
+                             MUL(v[3], SUB(v[5], v[1])));
+        t = -b / ADD(MUL(2.0, a), MC_EPS);
+        if (t < 0 || t > 1) return s > 0;
+        At = ADD(v[0], MUL(SUB(v[4], v[0]), t));
+        Bt = ADD(v[3], MUL(SUB(v[7], v[3]), t));
+        Ct = ADD(v[2], MUL(SUB(v[6], v[2]), t));
+        Dt = ADD(v[1], MUL(SUB(v[5], v[1]), t));
+    } else {
+        int edge;
+        if (mc_case == 6) edge = d_test6[config * 3 + 2];
+        else if (mc_case == 7) edge = d_test7[config * 5 + 4];
+        else if (mc_case == 12) edge = d_test12[config * 4 + 3];
+        else edge = d_tiling_flat[d_tiling_base[MC_T_13_5_1] + (config * 4 + subconfig) * 18];
+        // reference edge e from corner a to corner b; the three "parallel" edges (p0,p1),(q0,q1),(r0,r1)
+        int ea, eb, p0, p1, q0, q1, r0, r1;
+        switch (edge) {
+            case 0: ea = 0; eb = 1; p0 = 3; p1 = 2; q0 = 7; q1 = 6; r0 = 4; r1 = 5; break;
+            case 1: ea = 1; eb = 2; p0 = 0; p1 = 3; q0 = 4; q1 = 7; r0 = 5; r1 = 6; break;
+            case 2: ea = 2; eb = 3; p0 = 1; p1 = 0; q0 = 5; q1 = 4; r0 = 6; r1 = 7; break;
+            case 3: ea = 3; eb = 0; p0 = 2; p1 = 1; q0 = 6; q1 = 5; r0 = 7; r1 = 4; break;
+            case 4: ea = 4; eb = 5; p0 = 7; p1 = 6; q0 = 3; q1 = 2; r0 = 0; r1 = 1; break;
+            case 5: ea = 5; eb = 6; p0 = 4; p1 = 7; q0 = 0; q1 = 3; r0 = 1; r1 = 2; break;
+            case 6: ea = 6; eb = 7; p0 = 5; p1 = 4; q0 = 1; q1 = 0; r0 = 2; r1 = 3; break;
+            case 7: ea = 7; eb = 4; p0 = 6; p1 = 5; q0 = 2; q1 = 1; r0 = 3; r1 = 0; break;
+            case 8: ea = 0; eb = 4; p0 = 3; p1 = 7; q0 = 2; q1 = 6; r0 = 1; r1 = 5; break;
+            case 9: ea = 1; eb = 5; p0 = 0; p1 = 4; q0 = 3; q1 = 7; r0 = 2; r1 = 6; break;
+            case 10: ea = 2; eb = 6; p0 = 1; p1 = 5; q0 = 0; q1 = 4; r0 = 3; r1 = 7; break;
+            default: ea = 3; eb = 7; p0 = 2; p1 = 6; q0 = 1; q1 = 5; r0 = 0; r1 = 4; break;  // 11
+        }
+        t = v[ea] / ADD(SUB(v[ea], v[eb]), MC_EPS);
+        At = 0;
+        Bt = ADD(v[p0], MUL(SUB(v[p1], v[p0]), t));
+        Ct = ADD(v[q0], MUL(SUB(v[q1], v[q0]), t));
+        Dt = ADD(v[r0], MUL(SUB(v[r1], v[r0]), t));
+    }
+    if (At >= 0) test += 1;
+    if (Bt >= 0) test += 2;
+    if (Ct >= 0) test += 4;
+    if (Dt >= 0) test += 8;
+    const double det = SUB(MUL(At, Ct), MUL(Bt, Dt));
+#undef MUL
+#undef ADD
+#undef SUB
+    switch (test) {
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 12: return s > 0;
+        // scikit-image's Cython port falls off the end (returns 0) when the inner test fails
+        case 5: return (det < MC_EPS) ? (s > 0) : false;
+        case 10: return (det >= MC_EPS) ? (s > 0) : false;
+        default: return s < 0;
+    }
+}
+
+// returns tiling offset into d_tiling_flat and number of index entries (3*ntri); 0 if inactive
+struct Tiling {
+    int ofs;
+    int len;
+};
+
+__device__ Tiling classify(const double *v, bool classic) {
+    int index = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) index |= (v[k] > 0.0) ? (1 << k) : 0;
+    Tiling out;
+    out.ofs = 0;
+    out.len = 0;
+    if (index == 0 || index == 255) return out;
+    if (classic) {
+        // classic rows live in their own table; flag with negative offset
+        int n = 0;
+        while (n < 16 && d_cases_classic[16 * index + n] != -1) ++n;
+        out.ofs = -(16 * index) - 1;
+        out.len = n;
+        return out;
+    }
+    const int c = d_cases[2 * index], cfg = d_cases[2 * index + 1];
+    int table = -1, sub = 0, sc = 0;
+    switch (c) {
+        case 1: table = MC_T_1; break;
+        case 2: table = MC_T_2; break;
+        case 3: table = test_face(v, d_test3[cfg]) ? MC_T_3_2 : MC_T_3_1; break;
+        case 4: table = test_internal(v, c, cfg, 0, d_test4[cfg]) ? MC_T_4_1 : MC_T_4_2; break;
+        case 5: table = MC_T_5; break;
+        case 6:
+            if (test_face(v, d_test6[cfg * 3 + 0])) table = MC_T_6_2;
+            else table = test_internal(v, c, cfg, 0, d_test6[cfg * 3 + 1]) ? MC_T_6_1_1 : MC_T_6_1_2;
+            break;
+        case 7:
+            if (test_face(v, d_test7[cfg * 5 + 0])) sc += 1;
+            if (test_face(v, d_test7[cfg * 5 + 1])) sc += 2;
+            if (test_face(v, d_test7[cfg * 5 + 2])) sc += 4;
+            switch (sc) {
+                case 0: table = MC_T_7_1; break;
+                case 1: table = MC_T_7_2; sub = 0; break;
+                case 2: table = MC_T_7_2; sub = 1; break;
+                case 3: table = MC_T_7_3; sub = 0; break;
+                case 4: table = MC_T_7_2; sub = 2; break;
+                case 5: table = MC_T_7_3; sub = 1; break;
+                case 6: table = MC_T_7_3; sub = 2; break;
+                default: table = test_internal(v, c, cfg, sc, d_test7[cfg * 5 + 3]) ? MC_T_7_4_2 : MC_T_7_4_1; break;
+            }
+            break;
+        case 8: table = MC_T_8; break;
+        case 9: table = MC_T_9; break;
+        case 10:
+            if (test_face(v, d_test10[cfg * 3 + 0])) table = test_face(v, d_test10[cfg * 3 + 1]) ? MC_T_10_1_1_ : MC_T_10_2;
+            else if (test_face(v, d_test10[cfg * 3 + 1])) table = MC_T_10_2_;
+            else table = test_internal(v, c, cfg, 0, d_test10[cfg * 3 + 2]) ? MC_T_10_1_1 : MC_T_10_1_2;
+            break;
+        case 11: table = MC_T_11; break;
+        case 12:
+            if (test_face(v, d_test12[cfg * 4 + 0])) table = test_face(v, d_test12[cfg * 4 + 1]) ? MC_T_12_1_1_ : MC_T_12_2;
+            else if (test_face(v, d_test12[cfg * 4 + 1])) table = MC_T_12_2_;
+            else table = test_internal(v, c, cfg, 0, d_test12[cfg * 4 + 2]) ? MC_T_12_1_1 : MC_T_12_1_2;
+            break;
+        case 13:
+            for (int k = 0; k < 6; ++k)
+                if (test_face(v, d_test13[cfg * 7 + k])) sc += 1 << k;
+            sc = d_subconfig13[sc];
+            if (sc == 0) table = MC_T_13_1;
+            else if (sc <= 6) { table = MC_T_13_2; sub = sc - 1; }
+            else if (sc <= 18) { table = MC_T_13_3; sub = sc - 7; }
+            else if (sc <= 22) { table = MC_T_13_4; sub = sc - 19; }
+            else if (sc <= 26) {
+                sub = sc - 23;
+                table = test_internal(v, c, cfg, sub, d_test13[cfg * 7 + 6]) ? MC_T_13_5_1 : MC_T_13_5_2;
+            } else if (sc <= 38) { table = MC_T_13_3_; sub = sc - 27; }
+            else if (sc <= 44) { table = MC_T_13_2_; sub = sc - 39; }
+            else if (sc == 45) table = MC_T_13_1_;
+            break;
+        case 14: table = MC_T_14; break;
+        default: break;
+    }
+    if (table < 0) return out;
+    const int rowlen = d_tiling_rowlen[table];
+    out.ofs = d_tiling_base[table] + (cfg * d_tiling_inner[table] + sub) * rowlen;
+    out.len = rowlen;
+    return out;
+}
+
+__device__ __forceinline__ int tiling_entry(const Tiling &t, int i) {
+    return (t.ofs < 0) ? d_cases_classic[(-t.ofs - 1) + i] : d_tiling_flat[t.ofs + i];
+}
+
+// geometry of the cell grid
+struct Grid {
+    int n0, n1, n2;   // voxels
+    int c0, c1, c2;   // cells
+    long ncells;
+};
+
+__device__ __forceinline__ void load_cell(const float *__restrict__ vol, const Grid &g, int z, int y, int x,
+                                          double level, double *v) {
+    const long sy = g.n2, sz = (long)g.n1 * g.n2;
+    const float *p = vol + z * sz + y * sy + x;
+    v[0] = (double)p[0] - level;
+    v[1] = (double)p[1] - level;
+    v[2] = (double)p[sy + 1] - level;
+    v[3] = (double)p[sy] - level;
+    v[4] = (double)p[sz] - level;
+    v[5] = (double)p[sz + 1] - level;
+    v[6] = (double)p[sz + sy + 1] - level;
+    v[7] = (double)p[sz + sy] - level;
+}
+
+// does cell (x,y,z) own edge e (is it the first cell, in sweep order, that touches it)?
+__device__ __forceinline__ bool owns_edge(int e, int x, int y, int z) {
+    switch (e) {
+        case 0: return y == 0 && z == 0;
+        case 1: return z == 0;
+        case 2: return z == 0;
+        case 3: return x == 0 && z == 0;
+        case 4: return y == 0;
+        case 5: return true;
+        case 6: return true;
+        case 7: return x == 0;
+        case 8: return x == 0 && y == 0;
+        case 9: return y == 0;
+        case 10: return true;
+        case 11: return x == 0;
+        default: return true;  // 12: centre vertex
+    }
+}
+
+// lattice-edge slot of edge e of cell (x,y,z): axis plane (0 = along x, 1 = along y, 2 = along z)
+// and the lattice point the edge starts at
+__device__ __forceinline__ long edge_slot(int e, int x, int y, int z, const Grid &g) {
+    int axis, lx = x, ly = y, lz = z;
+    switch (e) {
+        case 0: axis = 0; break;
+        case 1: axis = 1; lx += 1; break;
+        case 2: axis = 0; ly += 1; break;
+        case 3: axis = 1; break;
+        case 4: axis = 0; lz += 1; break;
+        case 5: axis = 1; lx += 1; lz += 1; break;
+        case 6: axis = 0; ly += 1; lz += 1; break;
+        case 7: axis = 1; lz += 1; break;
+        case 8: axis = 2; break;
+        case 9: axis = 2; lx += 1; break;
+        case 10: axis = 2; lx += 1; ly += 1; break;
+        default: axis = 2; ly += 1; break;  // 11
+    }
+    const long nvox = (long)g.n0 * g.n1 * g.n2;
+    return axis * nvox + ((long)lz * g.n1 + ly) * g.n2 + lx;
+}
+
+// number of triangles / owned vertices of a classified cell, packed (ntri | nown << 16)
+__device__ int cell_counts(const Tiling &t, int x, int y, int z) {
+    if (t.len == 0) return 0;
+    unsigned seen = 0;
+    int nown = 0;
+    for (int i = 0; i < t.len; ++i) {
+        const int e = tiling_entry(t, i);
+        if (!(seen >> e & 1u)) {
+            seen |= 1u << e;
+            nown += owns_edge(e, x, y, z) ? 1 : 0;
+        }
+    }
+    return (t.len / 3) | (nown << 16);
+}
+
+// exclusive scan of `val` over the 256-thread block; returns exclusive prefix, total in *total
+__device__ int block_exclusive_scan(int val, int *total) {
+    __shared__ int wsum[MC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MC_BLOCK / 64; ++w) {
+        const int s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - val;
+}
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float ord2f(unsigned o) {
+    unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct McHeader {            // first 64 bytes of the workspace
+    unsigned long long total_tri;
+    unsigned long long total_vert;
+    unsigned min_ord, max_ord;
+    unsigned pad[10];
+};
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(const float *__restrict__ vol, Grid g, double level,
+                                                            int classic, int *__restrict__ block_counts,
+                                                            McHeader *__restrict__ hdr) {
+    const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
+    int packed = 0;
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    if (c < g.ncells) {
+        const int x = (int)(c % g.c2), y = (int)((c / g.c2) % g.c1), z = (int)(c / ((long)g.c2 * g.c1));
+        double v[8];
+        load_cell(vol, g, z, y, x, level, v);
+        {
+            const long sy = g.n2, sz = (long)g.n1 * g.n2;
+            const float *p = vol + z * sz + y * sy + x;
+            const float f[8] = {p[0], p[1], p[sy], p[sy + 1], p[sz], p[sz + 1], p[sz + sy], p[sz + sy + 1]};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                mn = fminf(mn, f[k]);
+                mx = fmaxf(mx, f[k]);
+            }
+        }
+        // wave early-out: most waves see no sign change at all
+        bool any = false;
+        {
+            int idx = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
+            any = idx != 0 && idx != 255;
+        }
+        if (any) {
+            Tiling t = classify(v, classic != 0);
+            packed = cell_counts(t, x, y, z);
+        }
+    }
+    // block reduce counts and min/max
+    __shared__ int s_cnt[MC_BLOCK / 64];
+    __shared__ float s_mn[MC_BLOCK / 64], s_mx[MC_BLOCK / 64];
+    int sum = packed;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d, 64);
+        mn = fminf(mn, __shfl_xor(mn, d, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[wave] = sum; s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < MC_BLOCK / 64; ++w) {
+            tot += s_cnt[w];
+            mn = fminf(mn, s_mn[w]);
+            mx = fmaxf(mx, s_mx[w]);
+        }
+        block_counts[blockIdx.x] = tot;
+        atomicMin(&hdr->min_ord, f2ord(mn));
+        atomicMax(&hdr->max_ord, f2ord(mx));
+    }
+}
+
+// single-workgroup exclusive scan of packed block counts -> separate tri/vert offsets
+__global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ block_counts, int nblocks,
+                                                       unsigned *__restrict__ tri_ofs, unsigned *__restrict__ vert_ofs,
+                                                       McHeader *__restrict__ hdr) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int pk = i < nblocks ? block_counts[i] : 0;
+        // 64-bit packed (tri low 32, vert high 32) so totals cannot overflow
+        const unsigned long long val = (unsigned long long)(pk & 0xffff) | ((unsigned long long)(pk >> 16) << 32);
+        unsigned long long inc = val;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long wbase = carry_s, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) wbase += wsum[w];
+            tot += wsum[w];
+        }
+        const unsigned long long ex = wbase + inc - val;
+        if (i < nblocks) {
+            tri_ofs[i] = (unsigned)(ex & 0xffffffffull);
+            vert_ofs[i] = (unsigned)(ex >> 32);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hdr->total_tri = carry_s & 0xffffffffull;
+        hdr->total_vert = carry_s >> 32;
+    }
+}
+
+// weights of the two end points of an edge -> parametric position along the edge (double)
+__device__ __forceinline__ double edge_frac(double v_near, double v_far) {
+    const double t_near = 1.0 / (MC_EPS + fabs(v_near));
+    const double t_far = 1.0 / (MC_EPS + fabs(v_far));
+    return t_far / (t_near + t_far);
+}
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restrict__ vol, Grid g, double level,
+                                                            int classic, const unsigned *__restrict__ vert_ofs,
+                                                            int *__restrict__ edge_map, float *__restrict__ verts,
+                                                            float vdiv, float vmul, float vadd, int affine) {
+    const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
+    int x = 0, y = 0, z = 0;
+    double v[8];
+    Tiling t;
+    t.ofs = 0; t.len = 0;
+    int nown = 0;
+    if (c < g.ncells) {
+        x = (int)(c % g.c2); y = (int)((c / g.c2) % g.c1); z = (int)(c / ((long)g.c2 * g.c1));
+        load_cell(vol, g, z, y, x, level, v);
+        int idx = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
+        if (idx != 0 && idx != 255) {
+            t = classify(v, classic != 0);
+            nown = cell_counts(t, x, y, z) >> 16;
+        }
+    }
+    int total;
+    const int pre = block_exclusive_scan(nown, &total);
+    if (nown == 0) return;
+    unsigned id = vert_ofs[blockIdx.x] + (unsigned)pre;
+    unsigned seen = 0;
+    for (int i = 0; i < t.len; ++i) {
+        const int e = tiling_entry(t, i);
+        if (seen >> e & 1u) continue;
+        seen |= 1u << e;
+        if (!owns_edge(e, x, y, z)) continue;
+        double px, py, pz;  // skimage's internal (x,y,z) = (axis2, axis1, axis0)
+        if (e == 12) {
+            // centre vertex: inverse-|value| weighted mean of the 8 corners, summed in corner order
+            double w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = 1.0 / (MC_EPS + fabs(v[k]));
+            double ff = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ff = __dadd_rn(ff, w[k]);
+            const double fx = __dadd_rn(__dadd_rn(__dadd_rn(w[1], w[2]), w[5]), w[6]);
+            const double fy = __dadd_rn(__dadd_rn(__dadd_rn(w[2], w[3]), w[6]), w[7]);
+            const double fz = __dadd_rn(__dadd_rn(__dadd_rn(w[4], w[5]), w[6]), w[7]);
+            px = __dadd_rn((double)x, fx / ff);
+            py = __dadd_rn((double)y, fy / ff);
+            pz = __dadd_rn((double)z, fz / ff);
+        } else {
+            // corner pairs (near = lower lattice coordinate along the edge axis, far = near+1)
+            int cn, cf, lx = x, ly = y, lz = z, axis;
+            switch (e) {
+                case 0: cn = 0; cf = 1; axis = 0; break;
+                case 1: cn = 1; cf = 2; axis = 1; lx += 1; break;
+                case 2: cn = 3; cf = 2; axis = 0; ly += 1; break;
+                case 3: cn = 0; cf = 3; axis = 1; break;
+                case 4: cn = 4; cf = 5; axis = 0; lz += 1; break;
+                case 5: cn = 5; cf = 6; axis = 1; lx += 1; lz += 1; break;
+                case 6: cn = 7; cf = 6; axis = 0; ly += 1; lz += 1; break;
+                case 7: cn = 4; cf = 7; axis = 1; lz += 1; break;
+                case 8: cn = 0; cf = 4; axis = 2; break;
+                case 9: cn = 1; cf = 5; axis = 2; lx += 1; break;
+                case 10: cn = 2; cf = 6; axis = 2; lx += 1; ly += 1; break;
+                default: cn = 3; cf = 7; axis = 2; ly += 1; break;
+            }
+            const double fr = edge_frac(v[cn], v[cf]);
+            // cell origin + (1.0 or fr): the off-axis offsets are exactly 0.0 or 1.0
+            px = (axis == 0) ? __dadd_rn((double)x, fr) : (double)lx;
+            py = (axis == 1) ? __dadd_rn((double)y, fr) : (double)ly;
+            pz = (axis == 2) ? __dadd_rn((double)z, fr) : (double)lz;
+            edge_map[edge_slot(e, x, y, z, g)] = (int)id;
+        }
+        // output columns (axis0, axis1, axis2) = (z, y, x): skimage's fliplr of its (x,y,z)
+        float o0 = (float)pz, o1 = (float)py, o2 = (float)px;
+        if (affine) {
+            o0 = o0 / vdiv; o1 = o1 / vdiv; o2 = o2 / vdiv;               // v_pos / (R - 1)  isosurface.py:53
+            o0 = __fadd_rn(__fmul_rn(o0, vmul), vadd);                     // scale_tensor    system.py:185-189
+            o1 = __fadd_rn(__fmul_rn(o1, vmul), vadd);
+            o2 = __fadd_rn(__fmul_rn(o2, vmul), vadd);
+        }
+        verts[3 * (size_t)id + 0] = o0;
+        verts[3 * (size_t)id + 1] = o1;
+        verts[3 * (size_t)id + 2] = o2;
+        ++id;
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restrict__ vol, Grid g, double level,
+                                                            int classic, const unsigned *__restrict__ tri_ofs,
+                                                            const unsigned *__restrict__ vert_ofs,
+                                                            const int *__restrict__ edge_map, IdxT *__restrict__ faces,
+                                                            int ref_order) {
+    const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
+    int x = 0, y = 0, z = 0;
+    Tiling t;
+    t.ofs = 0; t.len = 0;
+    int packed = 0;
+    if (c < g.ncells) {
+        x = (int)(c % g.c2); y = (int)((c / g.c2) % g.c1); z = (int)(c / ((long)g.c2 * g.c1));
+        double v[8];
+        load_cell(vol, g, z, y, x, level, v);
+        int idx = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
+        if (idx != 0 && idx != 255) {
+            t = classify(v, classic != 0);
+            packed = cell_counts(t, x, y, z);
+        }
+    }
+    int total;
+    const int pre = block_exclusive_scan(packed, &total);
+    if (t.len == 0) return;
+    const unsigned tri0 = tri_ofs[blockIdx.x] + (unsigned)(pre & 0xffff);
+    const unsigned vown0 = vert_ofs[blockIdx.x] + (unsigned)(pre >> 16);
+    // id of the centre vertex = own base + rank among owned vertices in first-appearance order
+    int centre_id = -1;
+    {
+        unsigned seen = 0;
+        int rank = 0;
+        for (int i = 0; i < t.len; ++i) {
+            const int e = tiling_entry(t, i);
+            if (seen >> e & 1u) continue;
+            seen |= 1u << e;
+            if (e == 12) { centre_id = (int)vown0 + rank; break; }
+            rank += owns_edge(e, x, y, z) ? 1 : 0;
+        }
+    }
+    const int ntri = t.len / 3;
+    for (int k = 0; k < ntri; ++k) {
+        int id[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tiling_entry(t, 3 * k + j);
+            id[j] = (e == 12) ? centre_id : edge_map[edge_slot(e, x, y, z, g)];
+        }
+        // internal (a,b,c); skimage 'descent' flips to (c,b,a); the reference then takes [1,0,2] -> (b,c,a)
+        IdxT *f = faces + 3 * (size_t)(tri0 + k);
+        if (ref_order) { f[0] = (IdxT)id[1]; f[1] = (IdxT)id[2]; f[2] = (IdxT)id[0]; }
+        else { f[0] = (IdxT)id[2]; f[1] = (IdxT)id[1]; f[2] = (IdxT)id[0]; }
+    }
+}
+
+static int make_grid(int n0, int n1, int n2, Grid *g) {
+    SC_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "marching_cubes: input array must be at least 2x2x2");
+    g->n0 = n0; g->n1 = n1; g->n2 = n2;
+    g->c0 = n0 - 1; g->c1 = n1 - 1; g->c2 = n2 - 1;
+    g->ncells = (long)g->c0 * g->c1 * g->c2;
+    SC_REQUIRE(g->ncells / MC_BLOCK < 0x7fffffffL, "marching_cubes: volume too large");
+    return 0;
+}
+
+struct WsLayout {
+    size_t off_counts, off_tri, off_vert, off_map, total;
+    int nblocks;
+};
+static WsLayout ws_layout(const Grid &g) {
+    WsLayout w;
+    w.nblocks = cdiv(g.ncells, MC_BLOCK);
+    size_t o = 64;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    w.off_counts = o; o = al(o + sizeof(int) * w.nblocks);
+    w.off_tri = o;    o = al(o + sizeof(unsigned) * w.nblocks);
+    w.off_vert = o;   o = al(o + sizeof(unsigned) * w.nblocks);
+    w.off_map = o;    o = al(o + sizeof(int) * 3 * (size_t)g.n0 * g.n1 * g.n2);
+    w.total = o;
+    return w;
+}
+
+}  // namespace sculpt
+
+using namespace sculpt;
+
+extern "C" {
+
+size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2) {
+    Grid g;
+    if (make_grid(n0, n1, n2, &g)) return 0;
+    return ws_layout(g).total;
+}
+
+int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsigned flags, void *workspace,
+                    int64_t *n_verts_host, int64_t *n_faces_host, sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    Grid g;
+    if (int rc = make_grid(n0, n1, n2, &g)) return rc;
+    SC_REQUIRE(vol && workspace && n_verts_host && n_faces_host, "mc_count: null argument");
+    if (int rc = upload_tables()) return rc;
+    const WsLayout w = ws_layout(g);
+    char *ws = reinterpret_cast<char *>(workspace);
+    McHeader *hdr = reinterpret_cast<McHeader *>(ws);
+    McHeader init;
+    memset(&init, 0, sizeof(init));
+    init.min_ord = 0xffffffffu;
+    init.max_ord = 0u;
+    SC_HIP(hipMemcpyAsync(hdr, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    const int classic = (flags & SCULPT_MC_USE_CLASSIC) ? 1 : 0;
+    hipLaunchKernelGGL(mc_count_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, classic,
+                       reinterpret_cast<int *>(ws + w.off_counts), hdr);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
+                       w.nblocks, reinterpret_cast<unsigned *>(ws + w.off_tri),
+                       reinterpret_cast<unsigned *>(ws + w.off_vert), hdr);
+    SC_LAUNCH_CHECK();
+    McHeader res;
+    SC_HIP(hipMemcpyAsync(&res, hdr, sizeof(res), hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    *n_verts_host = (int64_t)res.total_vert;
+    *n_faces_host = (int64_t)res.total_tri;
+    // skimage: "Surface level must be within volume data range." (ValueError)
+    const float mn = ord2f(res.min_ord), mx = ord2f(res.max_ord);
+    if ((double)level < (double)mn || (double)level > (double)mx) {
+        set_error("Surface level must be within volume data range.");
+        return SCULPT_ERR_MC_LEVEL;
+    }
+    if (res.total_vert == 0) {
+        set_error("No surface found at the given iso value.");
+        return SCULPT_ERR_MC_EMPTY;
+    }
+    SC_REQUIRE(res.total_vert < 0x7fffffffull && res.total_tri < 0x55555555ull, "marching_cubes: mesh too large for 32-bit ids");
+    return 0;
+}
+
+int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsigned flags, void *workspace,
+                   float vert_div, float vert_mul, float vert_add, float *verts, void *faces,
+                   sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    Grid g;
+    if (int rc = make_grid(n0, n1, n2, &g)) return rc;
+    SC_REQUIRE(vol && workspace && verts && faces, "mc_emit: null argument");
+    const WsLayout w = ws_layout(g);
+    char *ws = reinterpret_cast<char *>(workspace);
+    const int classic = (flags & SCULPT_MC_USE_CLASSIC) ? 1 : 0;
+    const int ref = (flags & SCULPT_MC_REFERENCE_ORDER) ? 1 : 0;
+    const unsigned *tri = reinterpret_cast<const unsigned *>(ws + w.off_tri);
+    const unsigned *vrt = reinterpret_cast<const unsigned *>(ws + w.off_vert);
+    int *emap = reinterpret_cast<int *>(ws + w.off_map);
+    hipLaunchKernelGGL(mc_verts_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, classic, vrt,
+                       emap, verts, vert_div, vert_mul, vert_add, ref);
+    SC_LAUNCH_CHECK();
+    if (flags & SCULPT_MC_FACES_I64)
+        hipLaunchKernelGGL(mc_faces_kernel<long long>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level,
+                           classic, tri, vrt, emap, reinterpret_cast<long long *>(faces), ref);
+    else
+        hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level,
+                           classic, tri, vrt, emap, reinterpret_cast<int *>(faces), ref);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,500 @@
+// Fused triplane sample + NeRF-MLP kernels for gfx950 (MI355X).
+//
+// Replaces (reference file:line):
+//   TriplaneNeRFRenderer.query_triplane / _query_chunk   TripoSR/tsr/models/nerf_renderer.py:41-91
+//   NeRFMLP.forward                                       TripoSR/tsr/models/network_utils.py:116-124
+//   dense query over MarchingCubeHelper.grid_vertices     TripoSR/tsr/system.py:171-183
+//
+// Design (see DESIGN.md "fused sample+MLP"):
+//   * one wave owns a tile of 32 points; the point index lives on the MFMA column (lane & 31).
+//   * hidden layers run on v_mfma_f32_32x32x2_f32 (exact fp32 == fmaf chain).  The 32x32
+//     accumulator of layer l has the point on the lane and 16 neurons in registers, which is
+//     exactly the B-operand shape of layer l+1 when the k order of layer l+1 is permuted to
+//     neuron(t,r,h) = 32t + 8(r>>2) + 4h + (r&3).  The weights are stored pre-permuted
+//     (sculpt_mlp_pack), so activations never leave registers: no LDS, no cross-lane traffic.
+//   * all hidden weights (NH*64*64 fp32 = 128 KiB) sit in LDS once per workgroup; A operands
+//     are fetched with conflict-free ds_read_b128 (4 k-steps per read).
+//   * dense grid: the lattice is separable, so layer 0 (linear in the bilinear samples) is
+//     evaluated once per lattice *pair* and plane (plane_features_kernel) and the per-point
+//     layer-0 pre-activation is the sum of three table rows.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace sculpt {
+
+static constexpr int HID = 64;          // hidden width (n_neurons)
+static constexpr uint32_t PACK_MAGIC = 0x53434d4cu;  // "SCML"
+
+struct MlpPackHeader {
+    uint32_t magic;
+    int32_t K0;        // in_channels (3*C)
+    int32_t NH;        // number of 64x64 hidden layers
+    int32_t total_floats;
+    int32_t off_w0raw; // [64][K0]
+    int32_t off_b0raw; // [64]
+    int32_t off_a0;    // [2][K0/2][64]
+    int32_t off_bacc;  // [NH+1][2 h][2 t][16 r]
+    int32_t off_hid;   // [NH][2 T][8 s4][64 lane][4]
+    int32_t off_wlast; // [4][2 h][2 t][16 r]
+    int32_t off_blast; // [4]
+    int32_t pad[5];
+};
+static_assert(sizeof(MlpPackHeader) == 64, "header is 16 words");
+
+__host__ __device__ __forceinline__ int nrow(int t, int r, int h) { return 32 * t + 8 * (r >> 2) + 4 * h + (r & 3); }
+
+static void pack_layout(int K0, int NH, MlpPackHeader *hd) {
+    memset(hd, 0, sizeof(*hd));
+    hd->magic = PACK_MAGIC;
+    hd->K0 = K0;
+    hd->NH = NH;
+    int o = 16;  // header words
+    hd->off_w0raw = o; o += HID * K0;
+    hd->off_b0raw = o; o += HID;
+    hd->off_a0 = o;    o += 2 * (K0 / 2) * 64;
+    hd->off_bacc = o;  o += (NH + 1) * 64;
+    hd->off_hid = o;   o += NH * 2 * 8 * 64 * 4;
+    hd->off_wlast = o; o += 4 * 64;
+    hd->off_blast = o; o += 4;
+    hd->total_floats = (o + 3) & ~3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) {
+    // x * sigmoid(x); exp via v_exp_f32 (exp2), reciprocal via v_rcp_f32 (1 ulp each)
+    float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ f32x16 silu16(f32x16 v) {
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = silu_f(v[i]);
+    return o;
+}
+
+// LDS image: [hid NH*4096*4 floats][bacc (NH+1)*64][wlast 256][blast 4]
+struct LdsView {
+    const float *hid, *bacc, *wlast, *blast;
+};
+
+__device__ __forceinline__ LdsView lds_view(float *smem, int NH) {
+    LdsView v;
+    v.hid = smem;
+    v.bacc = smem + NH * 16384;
+    v.wlast = v.bacc + (NH + 1) * 64;
+    v.blast = v.wlast + 256;
+    return v;
+}
+
+__device__ __forceinline__ void load_weights_to_lds(float *smem, const float *blob, const MlpPackHeader &hd) {
+    const int NH = hd.NH;
+    const int nh4 = NH * 16384 / 4;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_hid);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+    for (int i = threadIdx.x; i < nh4; i += blockDim.x) dst[i] = src[i];
+    float *bacc = smem + NH * 16384;
+    for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
+    float *wl = bacc + (NH + 1) * 64;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
+    if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
+    __syncthreads();
+}
+
+__device__ __forceinline__ f32x16 lds_bias16(const float *bacc, int l, int h, int t) {
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(bacc + ((l * 2 + h) * 2 + t) * 16);
+    f32x4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    o[8] = c[0]; o[9] = c[1]; o[10] = c[2]; o[11] = c[3];
+    o[12] = d[0]; o[13] = d[1]; o[14] = d[2]; o[15] = d[3];
+    return o;
+}
+
+// NH hidden layers: in/out = activations (post-SiLU) in accumulator layout.
+__device__ __forceinline__ void hidden_layers(const LdsView &L, int NH, int lane, int h, f32x16 &x0, f32x16 &x1) {
+    for (int l = 0; l < NH; ++l) {
+        f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+        f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
+        const f32x4 *A0 = reinterpret_cast<const f32x4 *>(L.hid) + ((l * 2 + 0) * 8) * 64 + lane;
+        const f32x4 *A1 = reinterpret_cast<const f32x4 *>(L.hid) + ((l * 2 + 1) * 8) * 64 + lane;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            f32x4 a0 = A0[s4 * 64];
+            f32x4 a1 = A1[s4 * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = s4 * 4 + j;
+                const float b = (s < 16) ? x0[s & 15] : x1[s & 15];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b, acc1, 0, 0, 0);
+            }
+        }
+        x0 = silu16(acc0);
+        x1 = silu16(acc1);
+    }
+}
+
+// last layer row o: partial dot over this lane's 32 neurons + other half
+__device__ __forceinline__ float last_dot(const LdsView &L, int o, int h, const f32x16 &x0, const f32x16 &x1) {
+    const float *w = L.wlast + (o * 2 + h) * 32;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(w[r], x0[r], s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(w[16 + r], x1[r], s);
+    s += __shfl_xor(s, 32, 64);
+    return s + L.blast[o];
+}
+
+__device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(1.44269504088896340736f * x); }
+
+// bilinear taps of torch grid_sample(align_corners=False, zeros padding) along one axis
+struct Tap1 {
+    int i0;       // floor index (may be -1 .. size-1)
+    float w1;     // weight of i0+1 (fraction), weight of i0 is 1-w1
+};
+__device__ __forceinline__ Tap1 tap_of(float g, int size) {
+    float f = ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+    float fl = floorf(f);
+    Tap1 t;
+    t.i0 = (int)fl;
+    t.w1 = f - fl;
+    return t;
+}
+// scale_tensor(p, (-r, r), (-1, 1))  (nerf_renderer.py:52-54); true fp32 division like torch CPU
+__device__ __forceinline__ float to_unit(float p, float radius, float span) {
+    float d = (p - (-radius)) / span;
+    return d * 2.0f + (-1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// General query at arbitrary points (C = 40 channels per plane).
+// lane (p = lane&31, h = lane>>5) samples features k = h*60 + s, s = 0..59, of point p.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512) void query_points_kernel(
+    const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
+    const float *__restrict__ pts, long N, float radius, float span, float density_bias,
+    float *__restrict__ density, float *__restrict__ features, float *__restrict__ density_act,
+    float *__restrict__ color) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K0 = 3 * C, S0 = K0 / 2;
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;
+    load_weights_to_lds(smem, blob, hd);
+    const LdsView L = lds_view(smem, NH);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const long ntiles = (N + 31) / 32;
+    const float *A0g = blob + hd.off_a0;
+    const long HW = (long)H * W;
+
+    for (long tile = (long)blockIdx.x * nwave + wave; tile < ntiles; tile += (long)gridDim.x * nwave) {
+        long n = tile * 32 + p;
+        const bool valid = n < N;
+        if (!valid) n = N - 1;
+        float q[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q[k] = to_unit(pts[3 * n + k], radius, span);
+        // plane pl: (gx, gy) = (q[ia], q[ib]); ia = {0,0,1}, ib = {1,2,2}  (nerf_renderer.py:57-60)
+        int off[3][4];
+        float wt[3][4];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const float gx = q[pl == 2 ? 1 : 0], gy = q[pl == 0 ? 1 : 2];
+            Tap1 tx = tap_of(gx, W), ty = tap_of(gy, H);
+            const float wx = tx.w1, ex = 1.0f - wx, wy = ty.w1, ey = 1.0f - wy;
+            const int x0 = tx.i0, x1 = x0 + 1, y0 = ty.i0, y1 = y0 + 1;
+            const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+            const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+            const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+            const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+            off[pl][0] = cy0 * W + cx0; wt[pl][0] = (vy0 && vx0) ? ey * ex : 0.f;
+            off[pl][1] = cy0 * W + cx1; wt[pl][1] = (vy0 && vx1) ? ey * wx : 0.f;
+            off[pl][2] = cy1 * W + cx0; wt[pl][2] = (vy1 && vx0) ? wy * ex : 0.f;
+            off[pl][3] = cy1 * W + cx1; wt[pl][3] = (vy1 && vx1) ? wy * wx : 0.f;
+        }
+        // layer 0 on MFMA: step s consumes feature k = h*S0 + s of point p
+        f32x16 acc0 = lds_bias16(L.bacc, 0, h, 0);
+        f32x16 acc1 = lds_bias16(L.bacc, 0, h, 1);
+#pragma unroll 4
+        for (int s = 0; s < S0; ++s) {
+            const int f = h * S0 + s;
+            const int pl = f / C, ch = f - pl * C;
+            const float *P = planes + ((long)pl * C + ch) * HW;
+            const int o0 = pl == 0 ? off[0][0] : (pl == 1 ? off[1][0] : off[2][0]);
+            const int o1 = pl == 0 ? off[0][1] : (pl == 1 ? off[1][1] : off[2][1]);
+            const int o2 = pl == 0 ? off[0][2] : (pl == 1 ? off[1][2] : off[2][2]);
+            const int o3 = pl == 0 ? off[0][3] : (pl == 1 ? off[1][3] : off[2][3]);
+            const float w0 = pl == 0 ? wt[0][0] : (pl == 1 ? wt[1][0] : wt[2][0]);
+            const float w1 = pl == 0 ? wt[0][1] : (pl == 1 ? wt[1][1] : wt[2][1]);
+            const float w2 = pl == 0 ? wt[0][2] : (pl == 1 ? wt[1][2] : wt[2][2]);
+            const float w3 = pl == 0 ? wt[0][3] : (pl == 1 ? wt[1][3] : wt[2][3]);
+            // same tap order as torch: nw + ne + sw + se
+            float v = P[o0] * w0;
+            v += P[o1] * w1;
+            v += P[o2] * w2;
+            v += P[o3] * w3;
+            const float a0 = A0g[(0 * S0 + s) * 64 + lane];
+            const float a1 = A0g[(1 * S0 + s) * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+        }
+        f32x16 x0 = silu16(acc0), x1 = silu16(acc1);
+        hidden_layers(L, NH, lane, h, x0, x1);
+        const float d = last_dot(L, 0, h, x0, x1);
+        const float f0 = last_dot(L, 1, h, x0, x1);
+        const float f1 = last_dot(L, 2, h, x0, x1);
+        const float f2 = last_dot(L, 3, h, x0, x1);
+        if (valid && h == 0) {
+            if (density) density[n] = d;
+            if (density_act) density_act[n] = exp_f(d + density_bias);
+            if (features) { features[3 * n] = f0; features[3 * n + 1] = f1; features[3 * n + 2] = f2; }
+            if (color) {
+                color[3 * n] = __builtin_amdgcn_rcpf(1.0f + exp_f(-f0));
+                color[3 * n + 1] = __builtin_amdgcn_rcpf(1.0f + exp_f(-f1));
+                color[3 * n + 2] = __builtin_amdgcn_rcpf(1.0f + exp_f(-f2));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Separable dense grid, step 1: per lattice pair (a -> W axis, b -> H axis) and plane k,
+//   F_k[a][b][j] = sum_c W0[n(j)][k*C + c] * bilinear(P_k; a, b)[c]   (+ b0 on plane 0)
+// stored in accumulator order j = h*32 + t*16 + r  <->  neuron nrow(t,r,h).
+// One 64-thread wave per pair; 4 pairs per 256-thread block.
+//   table 0 (FA): a = ix (local), b = iy     rows nx x R
+//   table 1 (FB): a = ix (local), b = iz     rows nx x R
+//   table 2 (FC): a = iy,         b = iz     rows R  x R
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void plane_features_kernel(
+    const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
+    const float *__restrict__ axis, int R, int x_begin, int nx, float radius, float span,
+    float *__restrict__ FA, float *__restrict__ FB, float *__restrict__ FC) {
+    __shared__ float smp[4][C];
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int K0 = hd.K0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long nA = (long)nx * R, nC = (long)R * R;
+    const long total = 2 * nA + nC;
+    long pair = (long)blockIdx.x * 4 + w;
+    const bool live = pair < total;
+    if (!live) pair = total - 1;
+    int k;
+    long rem;
+    float *dst;
+    if (pair < nA) { k = 0; rem = pair; dst = FA; }
+    else if (pair < 2 * nA) { k = 1; rem = pair - nA; dst = FB; }
+    else { k = 2; rem = pair - 2 * nA; dst = FC; }
+    const int a = (int)(rem / R), b = (int)(rem % R);
+    const int ia = (k == 2) ? a : a + x_begin;
+    const float gx = to_unit(axis[ia], radius, span), gy = to_unit(axis[b], radius, span);
+    Tap1 tx = tap_of(gx, W), ty = tap_of(gy, H);
+    const float wx = tx.w1, ex = 1.0f - wx, wy = ty.w1, ey = 1.0f - wy;
+    const int x0 = tx.i0, x1 = x0 + 1, y0 = ty.i0, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    const float wnw = (vy0 && vx0) ? ey * ex : 0.f, wne = (vy0 && vx1) ? ey * wx : 0.f;
+    const float wsw = (vy1 && vx0) ? wy * ex : 0.f, wse = (vy1 && vx1) ? wy * wx : 0.f;
+    if (lane < C) {
+        const float *P = planes + ((long)k * C + lane) * H * W;
+        float v = P[cy0 * W + cx0] * wnw;
+        v += P[cy0 * W + cx1] * wne;
+        v += P[cy1 * W + cx0] * wsw;
+        v += P[cy1 * W + cx1] * wse;
+        smp[w][lane] = v;
+    }
+    __syncthreads();
+    // lane j -> (h,t,r) -> neuron
+    const int hh = lane >> 5, tt = (lane >> 4) & 1, rr = lane & 15;
+    const int neuron = nrow(tt, rr, hh);
+    const float *w0 = blob + hd.off_w0raw + (long)neuron * K0 + k * C;
+    float s = (k == 0) ? blob[hd.off_b0raw + neuron] : 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) s = fmaf(w0[c], smp[w][c], s);
+    if (live) dst[rem * 64 + lane] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Separable dense grid, step 2: per tile of 32 consecutive iz at fixed (ix, iy):
+//   x = silu(FA[ix,iy] + FB[ix,iz] + FC[iy,iz]); NH hidden layers on MFMA; density row of the
+//   last layer on VALU; out = exp(d + density_bias).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_row32(const float *row, f32x16 &a, f32x16 &b) {
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(row);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 v = p[i];
+        a[4 * i] = v[0]; a[4 * i + 1] = v[1]; a[4 * i + 2] = v[2]; a[4 * i + 3] = v[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 v = p[4 + i];
+        b[4 * i] = v[0]; b[4 * i + 1] = v[1]; b[4 * i + 2] = v[2]; b[4 * i + 3] = v[3];
+    }
+}
+
+__global__ __launch_bounds__(512) void density_grid_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;
+    load_weights_to_lds(smem, blob, hd);
+    const LdsView L = lds_view(smem, NH);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int nzb = (R + 31) / 32;
+    const long ntiles = (long)nx * nzb * R;
+    // contiguous tile range per wave: consecutive tiles share (ix, zb) and walk iy
+    const long nw_total = (long)gridDim.x * nwave;
+    const long wid = (long)blockIdx.x * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+
+    for (long t = t_begin; t < t_end; ++t) {
+        const int iy = (int)(t % R);
+        const long u = t / R;
+        const int zb = (int)(u % nzb), ixl = (int)(u / nzb);
+        const int iz = zb * 32 + p;
+        const int izc = min(iz, R - 1);
+        f32x16 x0, x1, y0, y1;
+        load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
+        load_row32(FB + ((long)ixl * R + izc) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        x0 = silu16(x0); x1 = silu16(x1);
+        hidden_layers(L, NH, lane, h, x0, x1);
+        const float d = last_dot(L, 0, h, x0, x1);
+        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias);
+    }
+}
+
+}  // namespace sculpt
+
+using namespace sculpt;
+
+extern "C" {
+
+size_t sculpt_mlp_packed_bytes(int in_channels, int n_hidden_64) {
+    MlpPackHeader hd;
+    pack_layout(in_channels, n_hidden_64, &hd);
+    return (size_t)hd.total_floats * sizeof(float);
+}
+
+int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers, const int *dims,
+                    void *packed_host, size_t packed_bytes) {
+    SC_REQUIRE(n_layers >= 2, "mlp_pack: need at least 2 layers");
+    const int K0 = dims[0], NH = n_layers - 2;
+    SC_REQUIRE(K0 % 2 == 0 && K0 > 0, "mlp_pack: in_channels must be even");
+    for (int l = 1; l < n_layers; ++l) SC_REQUIRE(dims[l] == HID, "mlp_pack: hidden width must be 64 (got %d)", dims[l]);
+    SC_REQUIRE(dims[n_layers] == 4, "mlp_pack: last layer must have 4 outputs");
+    MlpPackHeader hd;
+    pack_layout(K0, NH, &hd);
+    SC_REQUIRE(packed_bytes >= (size_t)hd.total_floats * 4, "mlp_pack: buffer too small");
+    float *o = reinterpret_cast<float *>(packed_host);
+    memset(o, 0, (size_t)hd.total_floats * 4);
+    memcpy(o, &hd, sizeof(hd));
+    memcpy(o + hd.off_w0raw, Wh[0], sizeof(float) * HID * K0);
+    memcpy(o + hd.off_b0raw, bh[0], sizeof(float) * HID);
+    const int S0 = K0 / 2;
+    for (int T = 0; T < 2; ++T)
+        for (int s = 0; s < S0; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                o[hd.off_a0 + (T * S0 + s) * 64 + lane] = Wh[0][(size_t)(32 * T + (lane & 31)) * K0 + (lane >> 5) * S0 + s];
+    for (int l = 0; l <= NH; ++l)
+        for (int h = 0; h < 2; ++h)
+            for (int t = 0; t < 2; ++t)
+                for (int r = 0; r < 16; ++r) o[hd.off_bacc + ((l * 2 + h) * 2 + t) * 16 + r] = bh[l][nrow(t, r, h)];
+    for (int l = 0; l < NH; ++l) {
+        const float *Wl = Wh[l + 1];
+        for (int T = 0; T < 2; ++T)
+            for (int s = 0; s < 32; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = nrow(s >> 4, s & 15, lane >> 5);
+                    o[hd.off_hid + ((((l * 2 + T) * 8 + (s >> 2)) * 64 + lane) * 4) + (s & 3)] =
+                        Wl[(size_t)(32 * T + (lane & 31)) * HID + k];
+                }
+    }
+    const float *WL = Wh[n_layers - 1];
+    for (int oo = 0; oo < 4; ++oo)
+        for (int h = 0; h < 2; ++h)
+            for (int t = 0; t < 2; ++t)
+                for (int r = 0; r < 16; ++r) o[hd.off_wlast + ((oo * 2 + h) * 2 + t) * 16 + r] = WL[(size_t)oo * HID + nrow(t, r, h)];
+    for (int oo = 0; oo < 4; ++oo) o[hd.off_blast + oo] = bh[n_layers - 1][oo];
+    return 0;
+}
+
+static size_t lds_bytes_for(int NH) { return (size_t)(NH * 16384 + (NH + 1) * 64 + 256 + 4) * sizeof(float); }
+
+int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *mlp_packed,
+                          int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,
+                          float *density, float *features, float *density_act, float *color,
+                          sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    SC_REQUIRE(C == 40, "triplane_query: built for C=40 channels per plane (got %d)", C);
+    SC_REQUIRE(planes && mlp_packed, "triplane_query: null input");
+    if (N <= 0) return 0;
+    SC_REQUIRE(points, "triplane_query: null points");
+    SC_REQUIRE(n_hidden_64 >= 0, "triplane_query: bad n_hidden_64");
+    const size_t lds = lds_bytes_for(n_hidden_64);
+    SC_REQUIRE(lds <= 160 * 1024, "triplane_query: %d hidden layers do not fit LDS", n_hidden_64);
+    auto kern = query_points_kernel<40>;
+    SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long ntiles = (N + 31) / 32;
+    const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
+    const float span = (float)((double)radius - (double)(-radius));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, planes, H, W,
+                       reinterpret_cast<const float *>(mlp_packed), points, (long)N, radius, span,
+                       density_bias, density, features, density_act, color);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t sculpt_density_grid_workspace_bytes(int R, int nx) {
+    return ((size_t)2 * nx * R + (size_t)R * R) * 64 * sizeof(float);
+}
+
+int sculpt_density_grid(const float *planes, int C, int H, int W, const void *mlp_packed,
+                        int n_hidden_64, const float *axis_coords, int R, int x_begin, int x_end, float radius,
+                        float density_bias, void *workspace, float *out, sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    SC_REQUIRE(C == 40, "density_grid: built for C=40 channels per plane (got %d)", C);
+    SC_REQUIRE(planes && mlp_packed && axis_coords && workspace && out, "density_grid: null argument");
+    SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "density_grid: bad range [%d,%d) of %d", x_begin, x_end, R);
+    SC_REQUIRE(n_hidden_64 >= 0, "density_grid: bad n_hidden_64");
+    const size_t lds = lds_bytes_for(n_hidden_64);
+    SC_REQUIRE(lds <= 160 * 1024, "density_grid: %d hidden layers do not fit LDS", n_hidden_64);
+    const int nx = x_end - x_begin;
+    float *FA = reinterpret_cast<float *>(workspace);
+    float *FB = FA + (size_t)nx * R * 64;
+    float *FC = FB + (size_t)nx * R * 64;
+    const float span = (float)((double)radius - (double)(-radius));
+    const long pairs = 2L * nx * R + (long)R * R;
+    hipLaunchKernelGGL(plane_features_kernel<40>, dim3(cdiv(pairs, 4)), dim3(256), 0, st, planes, H, W,
+                       reinterpret_cast<const float *>(mlp_packed), axis_coords, R, x_begin, nx, radius,
+                       span, FA, FB, FC);
+    SC_LAUNCH_CHECK();
+    SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long ntiles = (long)nx * ((R + 31) / 32) * R;
+    const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
+    hipLaunchKernelGGL(density_grid_kernel, dim3(grid), dim3(512), lds, st,
+                       reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

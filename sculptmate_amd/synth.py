@@ -1,0 +1,181 @@
+"""Seeded synthetic inputs and weights (NumPy PCG64) for tests, smoke and bench.
+
+There is no network for checkpoints, so every run uses random-init weights of the reference
+architecture, drawn with the reference initialisers' *distributions* (SURVEY.md section 8d):
+  ViT-B/16            trunc-normal sigma=0.02                       (checkpoints/config.json:9)
+  nn.Linear           kaiming-uniform a=sqrt(5)  -> U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+  NeRFMLP weights     kaiming_uniform_(relu)     -> U(-sqrt(6/fan_in), sqrt(6/fan_in))
+                                                   (tsr/models/network_utils.py:94)
+  triplane tokens     randn / sqrt(1024)            (tsr/models/tokenizers/triplane.py:20-27)
+Key names follow the reference checkpoint layout (ViT under the
+HF-4.38 names `image_tokenizer.model.encoder.layer.N.attention.attention.query...`).
+Values are generated as float32 NumPy arrays so host and GPU box agree bit for bit.
+"""
+import math
+
+import numpy as np
+
+TSR_CFG = dict(
+    cond_image_size=512,
+    vit=dict(hidden=768, layers=12, heads=12, mlp=3072, patch=16, image_size=224, eps=1e-12),
+    plane_size=32, num_channels=1024,
+    backbone=dict(heads=16, head_dim=64, layers=16, cross_dim=768, groups=32),
+    upsample_out=40,
+    decoder=dict(in_channels=120, n_neurons=64, n_hidden_layers=9),
+    radius=0.87, density_bias=-1.0,
+)
+
+TINY_CFG = dict(
+    cond_image_size=64,
+    vit=dict(hidden=64, layers=2, heads=2, mlp=128, patch=16, image_size=224, eps=1e-12),
+    plane_size=4, num_channels=64,
+    backbone=dict(heads=2, head_dim=32, layers=2, cross_dim=64, groups=32),
+    upsample_out=40,
+    decoder=dict(in_channels=120, n_neurons=64, n_hidden_layers=9),
+    radius=0.87, density_bias=-1.0,
+)
+
+
+def _uniform(rng, shape, bound):
+    return ((rng.random(shape, dtype=np.float32) * 2.0 - 1.0) * np.float32(bound)).astype(np.float32)
+
+
+def _linear(rng, out_f, in_f, bias=True, prefix="", sd=None):
+    b = 1.0 / math.sqrt(in_f)
+    sd[prefix + ".weight"] = _uniform(rng, (out_f, in_f), b)
+    if bias:
+        sd[prefix + ".bias"] = _uniform(rng, (out_f,), b)
+
+
+def _trunc_normal(rng, shape, std=0.02):
+    x = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+    return np.clip(x, -2 * std, 2 * std).astype(np.float32)
+
+
+def decoder_state(seed=0, in_channels=120, n_neurons=64, n_hidden_layers=9, prefix="decoder."):
+    """NeRFMLP parameters: layers.{0,2,...,18}.{weight,bias} (network_utils.py:48-79)."""
+    rng = np.random.default_rng([seed, 11])
+    sd = {}
+    dims = [in_channels] + [n_neurons] * n_hidden_layers + [4]
+    for i in range(len(dims) - 1):
+        fan_in = dims[i]
+        sd["%slayers.%d.weight" % (prefix, 2 * i)] = _uniform(rng, (dims[i + 1], fan_in), math.sqrt(6.0 / fan_in))
+        sd["%slayers.%d.bias" % (prefix, 2 * i)] = _uniform(rng, (dims[i + 1],), 1.0 / math.sqrt(fan_in))
+    return sd
+
+
+def decoder_lists(sd, prefix="decoder."):
+    n = len([k for k in sd if k.startswith(prefix + "layers.") and k.endswith(".weight")])
+    Ws = [sd["%slayers.%d.weight" % (prefix, 2 * i)] for i in range(n)]
+    bs = [sd["%slayers.%d.bias" % (prefix, 2 * i)] for i in range(n)]
+    return Ws, bs
+
+
+def triplane(seed=0, channels=40, size=64, scale=1.0):
+    """A synthetic scene code [3, C, size, size] (stand-in for TSR.forward output)."""
+    rng = np.random.default_rng([seed, 12])
+    return (rng.standard_normal((3, channels, size, size), dtype=np.float32) * np.float32(scale)).astype(np.float32)
+
+
+def smooth_triplane(seed=0, channels=40, size=64, scale=1.0):
+    """Low-frequency scene code: random 8x8 control grid, bilinearly upsampled (object-like fields)."""
+    rng = np.random.default_rng([seed, 13])
+    c = rng.standard_normal((3, channels, 9, 9), dtype=np.float32)
+    t = np.linspace(0, 8, size, dtype=np.float32)
+    i0 = np.minimum(t.astype(np.int64), 7)
+    f = (t - i0).astype(np.float32)
+    rows = c[:, :, i0, :] * (1 - f)[None, None, :, None] + c[:, :, i0 + 1, :] * f[None, None, :, None]
+    out = rows[:, :, :, i0] * (1 - f) + rows[:, :, :, i0 + 1] * f
+    return (out * np.float32(scale)).astype(np.float32)
+
+
+def image_rgba(seed=0, size=512):
+    """uint8 RGBA: box-filtered noise with a disc alpha of radius 0.39*size."""
+    rng = np.random.default_rng([seed, 14])
+    raw = rng.integers(0, 256, (size, size, 4), dtype=np.uint8).astype(np.float32)
+    k = 9
+    pad = np.pad(raw, ((k // 2, k // 2), (k // 2, k // 2), (0, 0)), mode="edge")
+    cs = np.cumsum(np.cumsum(pad, axis=0), axis=1)
+    cs = np.pad(cs, ((1, 0), (1, 0), (0, 0)))
+    box = (cs[k:, k:] - cs[:-k, k:] - cs[k:, :-k] + cs[:-k, :-k]) / (k * k)
+    img = np.clip(np.rint(box), 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size]
+    r = np.hypot(xx - size / 2 + 0.5, yy - size / 2 + 0.5)
+    img[..., 3] = np.where(r <= 0.390625 * size, 255, 0).astype(np.uint8)
+    return img
+
+
+def composite_rgb(rgba):
+    """rgb*a + 0.5*(1-a) on float32 in [0,1]  (/root/reference/preprocessing.py:122)."""
+    x = rgba.astype(np.float32) / np.float32(255.0)
+    a = x[..., 3:4]
+    return (x[..., :3] * a + np.float32(0.5) * (1 - a)).astype(np.float32)
+
+
+def tsr_state(seed=0, cfg=None):
+    """Full TSR state dict (NumPy float32) with the reference checkpoint's key names."""
+    cfg = cfg or TSR_CFG
+    rng = np.random.default_rng([seed, 15])
+    sd = {}
+    v = cfg["vit"]
+    H = v["hidden"]
+    p = "image_tokenizer.model."
+    n_pos = (v["image_size"] // v["patch"]) ** 2 + 1
+    sd[p + "embeddings.cls_token"] = _trunc_normal(rng, (1, 1, H))
+    sd[p + "embeddings.position_embeddings"] = _trunc_normal(rng, (1, n_pos, H))
+    sd[p + "embeddings.patch_embeddings.projection.weight"] = _trunc_normal(rng, (H, 3, v["patch"], v["patch"]))
+    sd[p + "embeddings.patch_embeddings.projection.bias"] = np.zeros(H, np.float32)
+    for i in range(v["layers"]):
+        q = p + "encoder.layer.%d." % i
+        for nm in ("query", "key", "value"):
+            sd[q + "attention.attention.%s.weight" % nm] = _trunc_normal(rng, (H, H))
+            sd[q + "attention.attention.%s.bias" % nm] = _uniform(rng, (H,), 0.02)
+        sd[q + "attention.output.dense.weight"] = _trunc_normal(rng, (H, H))
+        sd[q + "attention.output.dense.bias"] = _uniform(rng, (H,), 0.02)
+        sd[q + "intermediate.dense.weight"] = _trunc_normal(rng, (v["mlp"], H))
+        sd[q + "intermediate.dense.bias"] = _uniform(rng, (v["mlp"],), 0.02)
+        sd[q + "output.dense.weight"] = _trunc_normal(rng, (H, v["mlp"]))
+        sd[q + "output.dense.bias"] = _uniform(rng, (H,), 0.02)
+        for ln in ("layernorm_before", "layernorm_after"):
+            sd[q + ln + ".weight"] = (1.0 + _uniform(rng, (H,), 0.1)).astype(np.float32)
+            sd[q + ln + ".bias"] = _uniform(rng, (H,), 0.05)
+    sd[p + "layernorm.weight"] = (1.0 + _uniform(rng, (H,), 0.1)).astype(np.float32)
+    sd[p + "layernorm.bias"] = _uniform(rng, (H,), 0.05)
+    sd[p + "pooler.dense.weight"] = _trunc_normal(rng, (H, H))
+    sd[p + "pooler.dense.bias"] = np.zeros(H, np.float32)
+
+    C, S = cfg["num_channels"], cfg["plane_size"]
+    sd["tokenizer.embeddings"] = (rng.standard_normal((3, C, S, S), dtype=np.float32)
+                                  / np.float32(math.sqrt(C))).astype(np.float32)
+    b = cfg["backbone"]
+    D = b["heads"] * b["head_dim"]
+    sd["backbone.norm.weight"] = (1.0 + _uniform(rng, (C,), 0.1)).astype(np.float32)
+    sd["backbone.norm.bias"] = _uniform(rng, (C,), 0.05)
+    _linear(rng, D, C, True, "backbone.proj_in", sd)
+    for i in range(b["layers"]):
+        q = "backbone.transformer_blocks.%d." % i
+        for ln in ("norm1", "norm2", "norm3"):
+            sd[q + ln + ".weight"] = (1.0 + _uniform(rng, (D,), 0.1)).astype(np.float32)
+            sd[q + ln + ".bias"] = _uniform(rng, (D,), 0.05)
+        for nm, kd in (("attn1", D), ("attn2", b["cross_dim"])):
+            _linear(rng, D, D, False, q + nm + ".to_q", sd)
+            _linear(rng, D, kd, False, q + nm + ".to_k", sd)
+            _linear(rng, D, kd, False, q + nm + ".to_v", sd)
+            _linear(rng, D, D, True, q + nm + ".to_out.0", sd)
+        _linear(rng, 8 * D, D, True, q + "ff.net.0.proj", sd)
+        _linear(rng, D, 4 * D, True, q + "ff.net.2", sd)
+    _linear(rng, C, D, True, "backbone.proj_out", sd)
+    co = cfg["upsample_out"]
+    bound = 1.0 / math.sqrt(co * 4)
+    sd["post_processor.upsample.weight"] = _uniform(rng, (C, co, 2, 2), bound)
+    sd["post_processor.upsample.bias"] = _uniform(rng, (co,), bound)
+    d = cfg["decoder"]
+    sd.update(decoder_state(seed, d["in_channels"], d["n_neurons"], d["n_hidden_layers"]))
+    return sd
+
+
+def calibrate_density_bias(pre_activation, inside_fraction=0.015, threshold=25.0, density_bias=-1.0):
+    """Bias shift b* for decoder.layers.18.bias[0] so that `inside_fraction` of the probe voxels
+    exceed the iso threshold: exp(d + b* + density_bias) = threshold at the (1-f) quantile."""
+    qv = np.quantile(np.asarray(pre_activation, np.float64), 1.0 - inside_fraction)
+    return float(math.log(threshold) - density_bias - qv)
