@@ -31,6 +31,18 @@
 
 namespace sculpt {
 
+// A product that must be rounded on its own (the CPU code has no FMA): the empty asm makes the value
+// opaque to the optimiser, so no later add can be fused with it.  (HIP's __dmul_rn/__dadd_rn are
+// plain operators parsed under the default contract=fast and DO get fused after inlining.)
+__device__ __forceinline__ double rounded(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 static constexpr double MC_EPS = 2.220446049250313e-16;  // skimage: np.spacing(1.0)
 static constexpr int MC_BLOCK = 256;
 
@@ -85,18 +97,18 @@ __device__ bool test_face(const double *v, int face) {
         default: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
     }
     // no contraction: A*C and B*D are rounded separately in the CPU implementation
-    const double ac = __dmul_rn(A, C), bd = __dmul_rn(B, D);
-    const double acbd = __dsub_rn(ac, bd);
+    const double ac = rounded(A * C), bd = rounded(B * D);
+    const double acbd = ac - bd;
     if (acbd > -MC_EPS && acbd < MC_EPS) return face >= 0;
-    return __dmul_rn(__dmul_rn((double)face, A), acbd) >= 0;
+    return rounded(rounded((double)face * A) * acbd) >= 0;
 }
 
 __device__ bool test_internal(const double *v, int mc_case, int config, int subconfig, int s) {
     double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
     int test = 0;
-#define MUL(a, b) __dmul_rn((a), (b))
-#define ADD(a, b) __dadd_rn((a), (b))
-#define SUB(a, b) __dsub_rn((a), (b))
+#define MUL(a, b) rounded((a) * (b))
+#define ADD(a, b) ((a) + (b))
+#define SUB(a, b) ((a) - (b))
     if (mc_case == 4 || mc_case == 10) {
         const double a = SUB(MUL(SUB(v[4], v[0]), SUB(v[6], v[2])), MUL(SUB(v[7], v[3]), SUB(v[5], v[1])));
         const double b = SUB(SUB(ADD(MUL(v[2], SUB(v[4], v[0])), MUL(v[0], SUB(v[6], v[2]))),
@@ -510,13 +522,13 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
             for (int k = 0; k < 8; ++k) w[k] = 1.0 / (MC_EPS + fabs(v[k]));
             double ff = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ff = __dadd_rn(ff, w[k]);
-            const double fx = __dadd_rn(__dadd_rn(__dadd_rn(w[1], w[2]), w[5]), w[6]);
-            const double fy = __dadd_rn(__dadd_rn(__dadd_rn(w[2], w[3]), w[6]), w[7]);
-            const double fz = __dadd_rn(__dadd_rn(__dadd_rn(w[4], w[5]), w[6]), w[7]);
-            px = __dadd_rn((double)x, fx / ff);
-            py = __dadd_rn((double)y, fy / ff);
-            pz = __dadd_rn((double)z, fz / ff);
+            for (int k = 0; k < 8; ++k) ff = ff + w[k];
+            const double fx = ((w[1] + w[2]) + w[5]) + w[6];
+            const double fy = ((w[2] + w[3]) + w[6]) + w[7];
+            const double fz = ((w[4] + w[5]) + w[6]) + w[7];
+            px = (double)x + fx / ff;
+            py = (double)y + fy / ff;
+            pz = (double)z + fz / ff;
         } else {
             // corner pairs (near = lower lattice coordinate along the edge axis, far = near+1)
             int cn, cf, lx = x, ly = y, lz = z, axis;
@@ -536,18 +548,18 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
             }
             const double fr = edge_frac(v[cn], v[cf]);
             // cell origin + (1.0 or fr): the off-axis offsets are exactly 0.0 or 1.0
-            px = (axis == 0) ? __dadd_rn((double)x, fr) : (double)lx;
-            py = (axis == 1) ? __dadd_rn((double)y, fr) : (double)ly;
-            pz = (axis == 2) ? __dadd_rn((double)z, fr) : (double)lz;
+            px = (axis == 0) ? (double)x + fr : (double)lx;
+            py = (axis == 1) ? (double)y + fr : (double)ly;
+            pz = (axis == 2) ? (double)z + fr : (double)lz;
             edge_map[edge_slot(e, x, y, z, g)] = (int)id;
         }
         // output columns (axis0, axis1, axis2) = (z, y, x): skimage's fliplr of its (x,y,z)
         float o0 = (float)pz, o1 = (float)py, o2 = (float)px;
         if (affine) {
             o0 = o0 / vdiv; o1 = o1 / vdiv; o2 = o2 / vdiv;               // v_pos / (R - 1)  isosurface.py:53
-            o0 = __fadd_rn(__fmul_rn(o0, vmul), vadd);                     // scale_tensor    system.py:185-189
-            o1 = __fadd_rn(__fmul_rn(o1, vmul), vadd);
-            o2 = __fadd_rn(__fmul_rn(o2, vmul), vadd);
+            o0 = rounded(o0 * vmul) + vadd;                                // scale_tensor    system.py:185-189
+            o1 = rounded(o1 * vmul) + vadd;
+            o2 = rounded(o2 * vmul) + vadd;
         }
         verts[3 * (size_t)id + 0] = o0;
         verts[3 * (size_t)id + 1] = o1;

@@ -86,7 +86,7 @@ struct LdsView {
 __device__ __forceinline__ LdsView lds_view(float *smem, int NH) {
     LdsView v;
     v.hid = smem;
-    v.bacc = smem + NH * 16384;
+    v.bacc = smem + NH * 4096;
     v.wlast = v.bacc + (NH + 1) * 64;
     v.blast = v.wlast + 256;
     return v;
@@ -94,11 +94,11 @@ __device__ __forceinline__ LdsView lds_view(float *smem, int NH) {
 
 __device__ __forceinline__ void load_weights_to_lds(float *smem, const float *blob, const MlpPackHeader &hd) {
     const int NH = hd.NH;
-    const int nh4 = NH * 16384 / 4;
+    const int nh4 = NH * 4096 / 4;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_hid);
     f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
     for (int i = threadIdx.x; i < nh4; i += blockDim.x) dst[i] = src[i];
-    float *bacc = smem + NH * 16384;
+    float *bacc = smem + NH * 4096;
     for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
     float *wl = bacc + (NH + 1) * 64;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
@@ -438,7 +438,7 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
     return 0;
 }
 
-static size_t lds_bytes_for(int NH) { return (size_t)(NH * 16384 + (NH + 1) * 64 + 256 + 4) * sizeof(float); }
+static size_t lds_bytes_for(int NH) { return (size_t)(NH * 4096 + (NH + 1) * 64 + 256 + 4) * sizeof(float); }
 
 int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *mlp_packed,
                           int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,

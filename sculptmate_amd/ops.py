@@ -68,7 +68,7 @@ def triplane_query(planes, mlp, points, radius=0.87, density_bias=-1.0,
                                     float(radius), float(density_bias), _ptr(out["density"]),
                                     _ptr(out["features"]), _ptr(out["density_act"]), _ptr(out["color"]),
                                     _stream()))
-    return {k: v.view(*shape, -1) for k, v in out.items() if v is not None}
+    return {k: v.view(*shape, v.shape[-1]) for k, v in out.items() if v is not None}
 
 
 def grid_axis_coords(resolution, radius):

@@ -86,7 +86,7 @@ def smooth_triplane(seed=0, channels=40, size=64, scale=1.0):
     f = (t - i0).astype(np.float32)
     rows = c[:, :, i0, :] * (1 - f)[None, None, :, None] + c[:, :, i0 + 1, :] * f[None, None, :, None]
     out = rows[:, :, :, i0] * (1 - f) + rows[:, :, :, i0 + 1] * f
-    return (out * np.float32(scale)).astype(np.float32)
+    return np.ascontiguousarray((out * np.float32(scale)).astype(np.float32))
 
 
 def image_rgba(seed=0, size=512):

@@ -1,0 +1,35 @@
+"""GPU timing of the hot kernels with HIP events (quick look; bench.py is the contract)."""
+import sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sculptmate_amd import ops, synth
+
+dev = torch.device("cuda:0")
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+Ws, bs = synth.decoder_lists(synth.decoder_state(seed=1))
+mlp = ops.PackedMLP(Ws, bs, dev)
+tri = torch.from_numpy(synth.smooth_triplane(seed=2, scale=3.0)).to(dev)
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+out = torch.empty(R ** 3, device=dev)
+t = timeit(lambda: ops.density_grid(tri, mlp, R, out=out))
+flops = 82.4e3 * R ** 3
+print("density_grid %d^3: %.3f ms  -> %.1f TFLOP/s algorithmic (%.1f%% of 157.3 f32 MFMA peak)" % (R, t, flops / t / 1e9, flops / t / 1e9 / 157.3 * 100))
+# calibrated field for MC
+g = torch.linspace(-0.87, 0.87, R, device=dev)
+x, y, z = torch.meshgrid(g, g, g, indexing="ij")
+vol = (25.0 * torch.exp(9.0 * (0.5 - torch.sqrt(x * x + 1.3 * y * y + 0.8 * z * z))) - 25.0).contiguous()
+v, f = ops.marching_cubes(vol, 0.0)
+t = timeit(lambda: ops.marching_cubes(vol, 0.0))
+print("marching_cubes %d^3: %.3f ms (%d verts %d faces) -> %.1f GB/s of 4B/voxel" % (R, t, len(v), len(f), 4 * R ** 3 / t / 1e6))
+pts = (torch.rand(300000, 3, device=dev) * 2 - 1) * 0.87
+t = timeit(lambda: ops.triplane_query(tri, mlp, pts, want=("color",)))
+print("triplane_query 300k pts: %.3f ms" % t)
