@@ -76,13 +76,14 @@ int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *
  * separable; axis_coords[i] is the coordinate in (-radius,radius) of index i, computed by the host
  * exactly as the reference does: linspace(0,1,R) then scale_tensor, system.py:177-181).
  *   workspace   sculpt_density_grid_workspace_bytes(R, x_end-x_begin) bytes of scratch
- *   out         f32 [(x_end-x_begin)*R*R]
+ *   out         f32 [(x_end-x_begin)*R*R] = density_act + out_add   (out_add = -threshold gives the
+ *               volume the reference hands to marching cubes, system.py:184 + isosurface.py:45)
  * The first MLP layer is applied per plane before the per-point sum (linear in the bilinear
  * samples); see DESIGN.md "fused sample+MLP kernel". */
 size_t sculpt_density_grid_workspace_bytes(int R, int nx);
 int sculpt_density_grid(const float *planes, int C, int H, int W, const void *mlp_packed,
                         int n_hidden_64, const float *axis_coords, int R, int x_begin, int x_end, float radius,
-                        float density_bias, void *workspace, float *out, sculpt_stream_t stream);
+                        float density_bias, float out_add, void *workspace, float *out, sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Marching cubes (Lewiner), output identical to skimage.measure.marching_cubes(vol, level)

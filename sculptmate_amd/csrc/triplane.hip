@@ -348,7 +348,7 @@ __device__ __forceinline__ void load_row32(const float *row, f32x16 &a, f32x16 &
 
 __global__ __launch_bounds__(512) void density_grid_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, int nx, float density_bias, float *__restrict__ out) {
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void density_grid_kernel(
         x0 = silu16(x0); x1 = silu16(x1);
         hidden_layers(L, NH, lane, h, x0, x1);
         const float d = last_dot(L, 0, h, x0, x1);
-        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias);
+        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
     }
 }
 
@@ -470,7 +470,7 @@ size_t sculpt_density_grid_workspace_bytes(int R, int nx) {
 
 int sculpt_density_grid(const float *planes, int C, int H, int W, const void *mlp_packed,
                         int n_hidden_64, const float *axis_coords, int R, int x_begin, int x_end, float radius,
-                        float density_bias, void *workspace, float *out, sculpt_stream_t stream) {
+                        float density_bias, float out_add, void *workspace, float *out, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     SC_REQUIRE(C == 40, "density_grid: built for C=40 channels per plane (got %d)", C);
     SC_REQUIRE(planes && mlp_packed && axis_coords && workspace && out, "density_grid: null argument");
@@ -492,7 +492,7 @@ int sculpt_density_grid(const float *planes, int C, int H, int W, const void *ml
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
     const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
     hipLaunchKernelGGL(density_grid_kernel, dim3(grid), dim3(512), lds, st,
-                       reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out);
+                       reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out);
     SC_LAUNCH_CHECK();
     return 0;
 }

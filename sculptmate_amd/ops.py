@@ -91,9 +91,10 @@ def _workspace(key, nbytes, device):
     return t
 
 
-def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None):
-    """density_act over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]
-    (TSR.extract_mesh's dense query, system.py:171-183)."""
+def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None,
+                 out_add=0.0):
+    """density_act (+ out_add) over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]
+    (TSR.extract_mesh's dense query, system.py:171-183; out_add=-threshold folds system.py:184)."""
     planes = _req(planes, torch.float32, "planes")
     R = int(resolution)
     x_end = R if x_end is None else int(x_end)
@@ -104,7 +105,7 @@ def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begi
     if out is None:
         out = torch.empty(nx * R * R, dtype=torch.float32, device=planes.device)
     check(lib.sculpt_density_grid(_ptr(planes), C, H, W, _ptr(mlp.blob), mlp.n_hidden, _ptr(axis), R,
-                                  int(x_begin), x_end, float(radius), float(density_bias), _ptr(ws),
+                                  int(x_begin), x_end, float(radius), float(density_bias), float(out_add), _ptr(ws),
                                   _ptr(out), _stream()))
     return out
 
@@ -143,3 +144,71 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     check(lib.sculpt_mc_emit(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), float(vert_div),
                              float(vert_mul), float(vert_add), _ptr(verts), _ptr(faces), _stream()))
     return verts, faces
+
+
+# ----------------------------------------------------------------------------------------------
+# transformer primitives (bf16 storage as torch.bfloat16 tensors; fp32 accumulate)
+# ----------------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0):
+    """out[m][n] = epi(A[m][:] . W[n][:] + bias[n]) (+ residual[m][n]); see sculpt_gemm_bf16.
+    A [>=M][K] bf16, W [N or 2N][K] bf16 (row stride = K).  Outputs are caller-allocated."""
+    K = A.shape[1]
+    N = W.shape[0] // 2 if epilogue == _lib.EPI_GEGLU else W.shape[0]
+    M = A.shape[0] if M is None else M
+    ldo = (out_f32 if out_f32 is not None else out_bf16).stride(0) if (out_f32 is not None or out_bf16 is not None) else 0
+    if out_f32 is not None and out_bf16 is not None:
+        assert out_f32.stride(0) == out_bf16.stride(0)
+    check(lib.sculpt_gemm_bf16(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                               residual.stride(0) if residual is not None else 0, _ptr(out_f32), _ptr(out_bf16),
+                               ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, M, N, K,
+                               epilogue, _stream()))
+
+
+def attention(Q, K, Vt, O, Tq, Tk, heads, scale):
+    """O = softmax(Q K^T scale) V per head (D=64); Vt is V transposed [heads*64][ld >= round_up(Tk,64)]."""
+    check(lib.sculpt_attention_bf16(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O),
+                                    O.stride(0), Tq, Tk, heads, float(scale), _stream()))
+
+
+def layernorm(x, gamma, beta, eps, y=None, y_f32=None, rows=None):
+    rows = x.shape[0] if rows is None else rows
+    xf = x if x.dtype == torch.float32 else None
+    xb = x if x.dtype == BF16 else None
+    ldy = (y if y is not None else y_f32).stride(0)
+    check(lib.sculpt_layernorm(_ptr(xf), _ptr(xb), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y), ldy,
+                               _ptr(y_f32), rows, x.shape[1], _stream()))
+
+
+def groupnorm_tokens(x_ct, groups, gamma, beta, eps, y_tc, stats_ws):
+    C, T = x_ct.shape
+    check(lib.sculpt_groupnorm_tokens(_ptr(x_ct), C, T, groups, _ptr(gamma), _ptr(beta), float(eps), _ptr(y_tc),
+                                      _ptr(stats_ws), _stream()))
+
+
+def transpose_add(x_tc, residual_ct, out_ct):
+    T, C = x_tc.shape
+    check(lib.sculpt_transpose_add(_ptr(x_tc), _ptr(residual_ct), _ptr(out_ct), T, C, _stream()))
+
+
+def vit_patchify(image_hwc, patch, mean, std, patches):
+    S = image_hwc.shape[0]
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(lib.sculpt_vit_patchify(_ptr(image_hwc), S, patch, ctypes.cast(m, ctypes.c_void_p),
+                                  ctypes.cast(s, ctypes.c_void_p), _ptr(patches), _stream()))
+
+
+def vit_assemble(patch_out, cls, pos, tokens):
+    n_patches, hidden = patch_out.shape[0], patch_out.shape[1]
+    check(lib.sculpt_vit_assemble(_ptr(patch_out), _ptr(cls), _ptr(pos), _ptr(tokens), n_patches, hidden, _stream()))
+
+
+def upsample_scatter(g, bias, planes, S, Co):
+    check(lib.sculpt_upsample_scatter(_ptr(g), g.stride(0), _ptr(bias), _ptr(planes), S, Co, _stream()))
+
+
+def cast_bf16(x, y):
+    check(lib.sculpt_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()))

@@ -15,27 +15,6 @@ import math
 
 import numpy as np
 
-TSR_CFG = dict(
-    cond_image_size=512,
-    vit=dict(hidden=768, layers=12, heads=12, mlp=3072, patch=16, image_size=224, eps=1e-12),
-    plane_size=32, num_channels=1024,
-    backbone=dict(heads=16, head_dim=64, layers=16, cross_dim=768, groups=32),
-    upsample_out=40,
-    decoder=dict(in_channels=120, n_neurons=64, n_hidden_layers=9),
-    radius=0.87, density_bias=-1.0,
-)
-
-TINY_CFG = dict(
-    cond_image_size=64,
-    vit=dict(hidden=64, layers=2, heads=2, mlp=128, patch=16, image_size=224, eps=1e-12),
-    plane_size=4, num_channels=64,
-    backbone=dict(heads=2, head_dim=32, layers=2, cross_dim=64, groups=32),
-    upsample_out=40,
-    decoder=dict(in_channels=120, n_neurons=64, n_hidden_layers=9),
-    radius=0.87, density_bias=-1.0,
-)
-
-
 def _uniform(rng, shape, bound):
     return ((rng.random(shape, dtype=np.float32) * 2.0 - 1.0) * np.float32(bound)).astype(np.float32)
 
@@ -113,62 +92,29 @@ def composite_rgb(rgba):
 
 
 def tsr_state(seed=0, cfg=None):
-    """Full TSR state dict (NumPy float32) with the reference checkpoint's key names."""
-    cfg = cfg or TSR_CFG
+    """Full TSR state dict (NumPy float32) with the reference checkpoint's key names and shapes
+    (sculptmate_amd.tsr.spec.param_spec), distributions as described in the module docstring."""
+    from .tsr.spec import DEFAULT_CFG, param_spec
+
+    cfg = cfg or DEFAULT_CFG
     rng = np.random.default_rng([seed, 15])
     sd = {}
-    v = cfg["vit"]
-    H = v["hidden"]
-    p = "image_tokenizer.model."
-    n_pos = (v["image_size"] // v["patch"]) ** 2 + 1
-    sd[p + "embeddings.cls_token"] = _trunc_normal(rng, (1, 1, H))
-    sd[p + "embeddings.position_embeddings"] = _trunc_normal(rng, (1, n_pos, H))
-    sd[p + "embeddings.patch_embeddings.projection.weight"] = _trunc_normal(rng, (H, 3, v["patch"], v["patch"]))
-    sd[p + "embeddings.patch_embeddings.projection.bias"] = np.zeros(H, np.float32)
-    for i in range(v["layers"]):
-        q = p + "encoder.layer.%d." % i
-        for nm in ("query", "key", "value"):
-            sd[q + "attention.attention.%s.weight" % nm] = _trunc_normal(rng, (H, H))
-            sd[q + "attention.attention.%s.bias" % nm] = _uniform(rng, (H,), 0.02)
-        sd[q + "attention.output.dense.weight"] = _trunc_normal(rng, (H, H))
-        sd[q + "attention.output.dense.bias"] = _uniform(rng, (H,), 0.02)
-        sd[q + "intermediate.dense.weight"] = _trunc_normal(rng, (v["mlp"], H))
-        sd[q + "intermediate.dense.bias"] = _uniform(rng, (v["mlp"],), 0.02)
-        sd[q + "output.dense.weight"] = _trunc_normal(rng, (H, v["mlp"]))
-        sd[q + "output.dense.bias"] = _uniform(rng, (H,), 0.02)
-        for ln in ("layernorm_before", "layernorm_after"):
-            sd[q + ln + ".weight"] = (1.0 + _uniform(rng, (H,), 0.1)).astype(np.float32)
-            sd[q + ln + ".bias"] = _uniform(rng, (H,), 0.05)
-    sd[p + "layernorm.weight"] = (1.0 + _uniform(rng, (H,), 0.1)).astype(np.float32)
-    sd[p + "layernorm.bias"] = _uniform(rng, (H,), 0.05)
-    sd[p + "pooler.dense.weight"] = _trunc_normal(rng, (H, H))
-    sd[p + "pooler.dense.bias"] = np.zeros(H, np.float32)
-
-    C, S = cfg["num_channels"], cfg["plane_size"]
-    sd["tokenizer.embeddings"] = (rng.standard_normal((3, C, S, S), dtype=np.float32)
-                                  / np.float32(math.sqrt(C))).astype(np.float32)
-    b = cfg["backbone"]
-    D = b["heads"] * b["head_dim"]
-    sd["backbone.norm.weight"] = (1.0 + _uniform(rng, (C,), 0.1)).astype(np.float32)
-    sd["backbone.norm.bias"] = _uniform(rng, (C,), 0.05)
-    _linear(rng, D, C, True, "backbone.proj_in", sd)
-    for i in range(b["layers"]):
-        q = "backbone.transformer_blocks.%d." % i
-        for ln in ("norm1", "norm2", "norm3"):
-            sd[q + ln + ".weight"] = (1.0 + _uniform(rng, (D,), 0.1)).astype(np.float32)
-            sd[q + ln + ".bias"] = _uniform(rng, (D,), 0.05)
-        for nm, kd in (("attn1", D), ("attn2", b["cross_dim"])):
-            _linear(rng, D, D, False, q + nm + ".to_q", sd)
-            _linear(rng, D, kd, False, q + nm + ".to_k", sd)
-            _linear(rng, D, kd, False, q + nm + ".to_v", sd)
-            _linear(rng, D, D, True, q + nm + ".to_out.0", sd)
-        _linear(rng, 8 * D, D, True, q + "ff.net.0.proj", sd)
-        _linear(rng, D, 4 * D, True, q + "ff.net.2", sd)
-    _linear(rng, C, D, True, "backbone.proj_out", sd)
-    co = cfg["upsample_out"]
-    bound = 1.0 / math.sqrt(co * 4)
-    sd["post_processor.upsample.weight"] = _uniform(rng, (C, co, 2, 2), bound)
-    sd["post_processor.upsample.bias"] = _uniform(rng, (co,), bound)
+    for name, shape in param_spec(cfg).items():
+        if name.startswith("decoder."):
+            continue
+        is_bias = name.endswith(".bias")
+        norm = any(t in name for t in ("layernorm", ".norm", "norm1", "norm2", "norm3"))
+        if norm:
+            sd[name] = _uniform(rng, shape, 0.05) if is_bias else (1.0 + _uniform(rng, shape, 0.1)).astype(np.float32)
+        elif name.startswith("image_tokenizer."):
+            sd[name] = _uniform(rng, shape, 0.02) if is_bias else _trunc_normal(rng, shape)
+        elif name == "tokenizer.embeddings":
+            sd[name] = (rng.standard_normal(shape, dtype=np.float32) / np.float32(math.sqrt(shape[1]))).astype(np.float32)
+        elif name.startswith("post_processor."):
+            sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(cfg["post_processor"]["out_channels"] * 4))
+        else:  # backbone linears: kaiming-uniform(a=sqrt(5)) on the weight, same bound on the bias
+            fan_in = shape[1] if len(shape) == 2 else int(sd[name[:-4] + "weight"].shape[1])
+            sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(fan_in))
     d = cfg["decoder"]
     sd.update(decoder_state(seed, d["in_channels"], d["n_neurons"], d["n_hidden_layers"]))
     return sd

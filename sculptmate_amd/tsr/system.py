@@ -1,0 +1,444 @@
+"""TSR -- the TripoSR system behind SculptMate's "lean" generator, MI355X-native.
+
+Mirrors the surface of /root/reference/TripoSR/tsr/system.py::TSR that the add-on uses
+(SURVEY.md section 8b): from_pretrained, renderer.set_chunk_size, to(device), __call__/forward,
+extract_mesh, plus a headless run() that returns meshes.  All arithmetic of the hot path runs in
+libsculpt_hip.so (hand-written HIP, gfx950); torch only owns HBM buffers and streams.
+
+Pipeline per image (reference file:line):
+  ImagePreprocessor (host)                          tsr/utils.py:62-112
+  DINOSingleImageTokenizer = ViT-B/16, 1025 tokens  tsr/models/tokenizers/image.py:41-60
+  Triplane1DTokenizer tokens [1024, 3072]           tsr/models/tokenizers/triplane.py:29-45
+  Transformer1D, 16 blocks                          tsr/models/transformer/transformer_1d.py:179-219
+  TriplaneUpsampleNetwork -> scene code [3,40,64,64] tsr/models/network_utils.py:24-32
+  extract_mesh: density grid -> marching cubes      tsr/system.py:171-200
+"""
+import math
+import os
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .posemb import interpolate_pos_embedding
+from .utils import ImagePreprocessor, scale_tensor
+
+BF16 = torch.bfloat16
+
+from .spec import DEFAULT_CFG, IMAGE_MEAN, IMAGE_STD, param_spec  # noqa: E402,F401
+
+
+class Mesh:
+    """What run() returns per image: trimesh-constructible arrays."""
+
+    def __init__(self, vertices, faces, vertex_colors=None):
+        self.vertices = vertices
+        self.faces = faces
+        self.vertex_colors = vertex_colors
+
+    def to_trimesh(self):  # pragma: no cover (trimesh is optional)
+        import trimesh
+
+        return trimesh.Trimesh(vertices=self.vertices, faces=self.faces, vertex_colors=self.vertex_colors)
+
+
+class MarchingCubeHelper:
+    """tsr/models/isosurface.py:17-54 on the GPU (sculpt_mc_*)."""
+
+    points_range = (0, 1)
+
+    def __init__(self, resolution: int):
+        self.resolution = resolution
+        self._grid_vertices = None
+
+    @property
+    def grid_vertices(self) -> torch.Tensor:
+        """[R^3, 3] lattice in [0,1] (isosurface.py:25-39).  Only built if somebody asks for it: the
+        dense query generates positions from the separable axis table instead (no 201 MB tensor)."""
+        if self._grid_vertices is None:
+            R = self.resolution
+            x = torch.linspace(*self.points_range, R)
+            x, y, z = torch.meshgrid(x, x, x, indexing="ij")
+            self._grid_vertices = torch.cat([x.reshape(-1, 1), y.reshape(-1, 1), z.reshape(-1, 1)], dim=-1)
+        return self._grid_vertices
+
+    def __call__(self, level: torch.Tensor):
+        """level = -(density - threshold) as the reference passes it; returns (v_pos in [0,1], faces int64)."""
+        R = self.resolution
+        vol = (-level).reshape(R, R, R).contiguous()
+        return ops.marching_cubes(vol, 0.0, reference_order=True, vert_div=R - 1.0, vert_mul=1.0, vert_add=0.0)
+
+
+class TriplaneNeRFRenderer:
+    """tsr/models/nerf_renderer.py:17-91 (mesh path only; the volume renderer is never called)."""
+
+    def __init__(self, cfg):
+        self.cfg = type("Cfg", (), dict(cfg))()
+        assert cfg.get("feature_reduction", "concat") == "concat"
+        assert cfg.get("density_activation", "exp") == "exp"
+        self.chunk_size = 0
+
+    def set_chunk_size(self, chunk_size: int):
+        assert chunk_size >= 0, "chunk_size must be a non-negative integer (0 for no chunking)."
+        self.chunk_size = chunk_size  # kept for API parity; the fused kernel needs no chunking
+
+    def query_triplane(self, decoder, positions, triplane):
+        return ops.triplane_query(triplane.contiguous(), decoder, positions, radius=self.cfg.radius,
+                                  density_bias=self.cfg.density_bias)
+
+
+def _bf(x, dev):
+    return torch.as_tensor(x).to(device=dev, dtype=BF16).contiguous()
+
+
+def _f32(x, dev):
+    return torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()
+
+
+class TSR:
+    def __init__(self, cfg=None, pos_embed_mode="scale_factor"):
+        self.cfg = cfg or DEFAULT_CFG
+        self.pos_embed_mode = pos_embed_mode
+        self._spec = param_spec(self.cfg)
+        self._sd = None
+        self.device = None
+        self.renderer = TriplaneNeRFRenderer(self.cfg["renderer"])
+        self.image_processor = ImagePreprocessor()
+        self.isosurface_helper = None
+        self.decoder = None  # ops.PackedMLP after to(device)
+        self.mesh_sink = None  # callable(verts, faces, colors, name); default: bpy if importable
+        self._w = None
+        self._pos_cache = {}
+        self._buf = {}
+
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, config_name: str, weight_name: str):
+        """system.py:51-66.  config.yaml is read with PyYAML (the ${tokenizer.num_channels}
+        interpolation is resolved by hand); ViT hyper-parameters come from checkpoints/config.json."""
+        if not os.path.isdir(pretrained_model_name_or_path):
+            raise FileNotFoundError("Checkpoint directory given doesnt exist")
+        cfg = load_config(os.path.join(pretrained_model_name_or_path, config_name),
+                          os.path.join(pretrained_model_name_or_path, "config.json"))
+        model = cls(cfg)
+        ckpt = torch.load(os.path.join(pretrained_model_name_or_path, weight_name), map_location="cpu")
+        model.load_state_dict(ckpt)
+        return model
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def load_state_dict(self, sd, strict=True):
+        sd = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v) for k, v in sd.items()}
+        missing = [k for k in self._spec if k not in sd]
+        unexpected = [k for k in sd if k not in self._spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for TSR: missing %s unexpected %s"
+                               % (missing[:5], unexpected[:5]))
+        for k, shp in self._spec.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shp):
+                raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), shp))
+        self._sd = {k: sd[k].detach().to(torch.float32) for k in self._spec if k in sd}
+        if self.device is not None:
+            self._prepare(self.device)
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.SculptError("TSR runs on an MI355X only (device %s requested; there is no CPU fallback)" % device)
+        self.device = device
+        if self._sd is not None:
+            self._prepare(device)
+        return self
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self, dev):
+        sd, cfg = self._sd, self.cfg
+        v, b = cfg["image_tokenizer"], cfg["backbone"]
+        H = v["hidden_size"]
+        w = {}
+        p = "image_tokenizer.model."
+        w["patch_w"] = _bf(sd[p + "embeddings.patch_embeddings.projection.weight"].reshape(H, -1), dev)
+        w["patch_b"] = _f32(sd[p + "embeddings.patch_embeddings.projection.bias"], dev)
+        w["cls"] = _f32(sd[p + "embeddings.cls_token"].reshape(H), dev)
+        w["vit"] = []
+        for i in range(v["num_hidden_layers"]):
+            q = p + "encoder.layer.%d." % i
+            L = {}
+            L["ln1_w"], L["ln1_b"] = _f32(sd[q + "layernorm_before.weight"], dev), _f32(sd[q + "layernorm_before.bias"], dev)
+            L["ln2_w"], L["ln2_b"] = _f32(sd[q + "layernorm_after.weight"], dev), _f32(sd[q + "layernorm_after.bias"], dev)
+            L["qk_w"] = _bf(torch.cat([sd[q + "attention.attention.query.weight"], sd[q + "attention.attention.key.weight"]], 0), dev)
+            L["qk_b"] = _f32(torch.cat([sd[q + "attention.attention.query.bias"], sd[q + "attention.attention.key.bias"]], 0), dev)
+            L["v_w"] = _bf(sd[q + "attention.attention.value.weight"], dev)
+            L["v_b"] = _f32(sd[q + "attention.attention.value.bias"], dev)
+            L["o_w"], L["o_b"] = _bf(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
+            L["f1_w"], L["f1_b"] = _bf(sd[q + "intermediate.dense.weight"], dev), _f32(sd[q + "intermediate.dense.bias"], dev)
+            L["f2_w"], L["f2_b"] = _bf(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
+            w["vit"].append(L)
+        w["vit_ln_w"], w["vit_ln_b"] = _f32(sd[p + "layernorm.weight"], dev), _f32(sd[p + "layernorm.bias"], dev)
+
+        t = cfg["tokenizer"]
+        C, S = t["num_channels"], t["plane_size"]
+        emb = sd["tokenizer.embeddings"]  # [3, C, S, S]
+        emb_ct = emb.permute(1, 0, 2, 3).reshape(C, 3 * S * S).contiguous()  # "Np Ct Hp Wp -> Ct (Np Hp Wp)"
+        w["emb_ct"] = _f32(emb_ct, dev)
+        w["emb_tc"] = _f32(emb_ct.t().contiguous(), dev)  # residual in token-major layout
+        w["gn_w"], w["gn_b"] = _f32(sd["backbone.norm.weight"], dev), _f32(sd["backbone.norm.bias"], dev)
+        w["pin_w"], w["pin_b"] = _bf(sd["backbone.proj_in.weight"], dev), _f32(sd["backbone.proj_in.bias"], dev)
+        w["pout_w"], w["pout_b"] = _bf(sd["backbone.proj_out.weight"], dev), _f32(sd["backbone.proj_out.bias"], dev)
+        w["blocks"] = []
+        for i in range(b["num_layers"]):
+            q = "backbone.transformer_blocks.%d." % i
+            L = {}
+            for j, ln in enumerate(("norm1", "norm2", "norm3")):
+                L["n%d_w" % (j + 1)], L["n%d_b" % (j + 1)] = _f32(sd[q + ln + ".weight"], dev), _f32(sd[q + ln + ".bias"], dev)
+            L["sa_qk"] = _bf(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"]], 0), dev)
+            L["sa_v"] = _bf(sd[q + "attn1.to_v.weight"], dev)
+            L["sa_o"], L["sa_ob"] = _bf(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
+            L["ca_q"] = _bf(sd[q + "attn2.to_q.weight"], dev)
+            L["ca_k"] = _bf(sd[q + "attn2.to_k.weight"], dev)
+            L["ca_v"] = _bf(sd[q + "attn2.to_v.weight"], dev)
+            L["ca_o"], L["ca_ob"] = _bf(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
+            L["ff1"], L["ff1_b"] = _bf(sd[q + "ff.net.0.proj.weight"], dev), _f32(sd[q + "ff.net.0.proj.bias"], dev)
+            L["ff2"], L["ff2_b"] = _bf(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
+            w["blocks"].append(L)
+        # ConvTranspose2d(k2,s2) as a GEMM: rows (co,dy,dx), K = Cin; rows padded to a multiple of 128
+        up = sd["post_processor.upsample.weight"]  # [Cin, Co, 2, 2]
+        Co = up.shape[1]
+        rows = up.permute(1, 2, 3, 0).reshape(4 * Co, up.shape[0])
+        npad = ((4 * Co + 127) // 128) * 128
+        upw = torch.zeros(npad, up.shape[0])
+        upw[: 4 * Co] = rows
+        w["up_w"], w["up_b"] = _bf(upw, dev), _f32(sd["post_processor.upsample.bias"], dev)
+        self._w = w
+        d = cfg["decoder"]
+        n = d["n_hidden_layers"] + 1
+        self.decoder = ops.PackedMLP([sd["decoder.layers.%d.weight" % (2 * i)] for i in range(n)],
+                                     [sd["decoder.layers.%d.bias" % (2 * i)] for i in range(n)], dev)
+        self._pos_cache = {}
+        self._buf = {}
+
+    def _pos(self, n_side, dev):
+        if n_side not in self._pos_cache:
+            pe = self._sd["image_tokenizer.model.embeddings.position_embeddings"].numpy()
+            self._pos_cache[n_side] = _f32(interpolate_pos_embedding(pe, n_side, self.pos_embed_mode), dev)
+        return self._pos_cache[n_side]
+
+    def _b(self, name, shape, dtype, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._buf.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def image_tokens(self, image_hwc: torch.Tensor):
+        """DINOSingleImageTokenizer.forward for one [S,S,3] fp32 image on the device ->
+        (ctx bf16 [T, H] for cross attention, ctx fp32 [T, H])."""
+        v, w = self.cfg["image_tokenizer"], self._w
+        H, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
+        S = image_hwc.shape[0]
+        n_side = S // P
+        npatch = n_side * n_side
+        T = npatch + 1
+        Tp = ((T + 63) // 64) * 64
+        patches = self._b("patches", (npatch, 3 * P * P), BF16)
+        ops.vit_patchify(image_hwc, P, IMAGE_MEAN, IMAGE_STD, patches)
+        pout = self._b("patch_out", (npatch, H), torch.float32)
+        ops.gemm(patches, w["patch_w"], bias=w["patch_b"], out_f32=pout)
+        h = self._b("vit_h", (T, H), torch.float32)
+        ops.vit_assemble(pout, w["cls"], self._pos(n_side, image_hwc.device), h)
+        xn = self._b("vit_xn", (T, H), BF16)
+        qk = self._b("vit_qk", (T, 2 * H), BF16)
+        vt = self._b("vit_vt", (H, Tp), BF16, zero=True)
+        att = self._b("vit_att", (T, H), BF16)
+        ff = self._b("vit_ff", (T, v["intermediate_size"]), BF16)
+        eps = v["layer_norm_eps"]
+        for L in w["vit"]:
+            ops.layernorm(h, L["ln1_w"], L["ln1_b"], eps, y=xn)
+            ops.gemm(xn, L["qk_w"], bias=L["qk_b"], out_bf16=qk)
+            ops.gemm(xn, L["v_w"], bias=L["v_b"], out_t=vt)
+            ops.attention(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
+            ops.gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
+            ops.layernorm(h, L["ln2_w"], L["ln2_b"], eps, y=xn)
+            ops.gemm(xn, L["f1_w"], bias=L["f1_b"], out_bf16=ff, epilogue=_lib.EPI_GELU)
+            ops.gemm(ff, L["f2_w"], bias=L["f2_b"], residual=h, out_f32=h)
+        ctx = self._b("ctx", (T, H), BF16)
+        ctx32 = self._b("ctx32", (T, H), torch.float32)
+        ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y=ctx, y_f32=ctx32)
+        return ctx, ctx32
+
+    def _run_blocks(self, h: torch.Tensor, ctx: torch.Tensor):
+        """All BasicTransformerBlocks on the fp32 residual stream h [T, D] (updated in place)."""
+        b, w = self.cfg["backbone"], self._w
+        nh, hd = b["num_attention_heads"], b["attention_head_dim"]
+        D = nh * hd
+        T, Tc = h.shape[0], ctx.shape[0]
+        Tcp = ((Tc + 63) // 64) * 64
+        Tp = ((T + 63) // 64) * 64
+        xn = self._b("bb_xn", (T, D), BF16)
+        qk = self._b("bb_qk", (T, 2 * D), BF16)
+        q = self._b("bb_q", (T, D), BF16)
+        vt = self._b("bb_vt", (D, Tp), BF16, zero=True)
+        ck = self._b("bb_ck", (Tc, D), BF16)
+        cvt = self._b("bb_cvt", (D, Tcp), BF16, zero=True)
+        att = self._b("bb_att", (T, D), BF16)
+        ff = self._b("bb_ff", (T, 4 * D), BF16)
+        scale = 1.0 / math.sqrt(hd)
+        for L in w["blocks"]:
+            ops.layernorm(h, L["n1_w"], L["n1_b"], 1e-5, y=xn)
+            ops.gemm(xn, L["sa_qk"], out_bf16=qk)
+            ops.gemm(xn, L["sa_v"], out_t=vt)
+            ops.attention(qk[:, :D], qk[:, D:], vt, att, T, T, nh, scale)
+            ops.gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
+            ops.layernorm(h, L["n2_w"], L["n2_b"], 1e-5, y=xn)
+            ops.gemm(xn, L["ca_q"], out_bf16=q)
+            ops.gemm(ctx, L["ca_k"], out_bf16=ck, M=Tc)
+            ops.gemm(ctx, L["ca_v"], out_t=cvt, M=Tc)
+            ops.attention(q, ck, cvt, att, T, Tc, nh, scale)
+            ops.gemm(att, L["ca_o"], bias=L["ca_ob"], residual=h, out_f32=h)
+            ops.layernorm(h, L["n3_w"], L["n3_b"], 1e-5, y=xn)
+            ops.gemm(xn, L["ff1"], bias=L["ff1_b"], out_bf16=ff, epilogue=_lib.EPI_GEGLU)
+            ops.gemm(ff, L["ff2"], bias=L["ff2_b"], residual=h, out_f32=h)
+        return h
+
+    def backbone_tokens(self, ctx: torch.Tensor):
+        """Triplane1DTokenizer + Transformer1D for one image; ctx bf16 [Tc, cross_dim].
+        Returns the output tokens token-major: fp32 [3*S*S, C] (+ bf16 copy)."""
+        b, w = self.cfg["backbone"], self._w
+        C = self.cfg["tokenizer"]["num_channels"]
+        nh, hd = b["num_attention_heads"], b["attention_head_dim"]
+        D = nh * hd
+        T = w["emb_ct"].shape[1]
+        Tc = ctx.shape[0]
+        Tcp = ((Tc + 63) // 64) * 64
+        xn = self._b("bb_xn", (T, D), BF16)
+        stats = self._b("gn_stats", (2 * b["norm_num_groups"],), torch.float32)
+        ops.groupnorm_tokens(w["emb_ct"], b["norm_num_groups"], w["gn_w"], w["gn_b"], 1e-6, xn, stats)
+        h = self._b("bb_h", (T, D), torch.float32)
+        ops.gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
+        h = self._run_blocks(h, ctx)
+        hb = self._b("bb_hb", (T, D), BF16)
+        ops.cast_bf16(h, hb)
+        out = self._b("bb_out", (T, C), torch.float32)
+        outb = self._b("bb_outb", (T, C), BF16)
+        ops.gemm(hb, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out_f32=out, out_bf16=outb)
+        return out, outb
+
+    def scene_code(self, tokens_bf16: torch.Tensor):
+        """detokenize + TriplaneUpsampleNetwork: tokens [3*S*S, C] -> planes fp32 [3, Co, 2S, 2S]."""
+        w = self._w
+        S = self.cfg["tokenizer"]["plane_size"]
+        Co = self.cfg["post_processor"]["out_channels"]
+        g = self._b("up_g", (tokens_bf16.shape[0], w["up_w"].shape[0]), torch.float32)
+        ops.gemm(tokens_bf16, w["up_w"], out_f32=g)
+        planes = torch.empty((3, Co, 2 * S, 2 * S), dtype=torch.float32, device=tokens_bf16.device)
+        ops.upsample_scatter(g, w["up_b"], planes, S, Co)
+        return planes
+
+    def forward(self, image, device=None) -> torch.Tensor:
+        """system.py:82-115: image(s) -> scene_codes fp32 [B, 3, 40, 64, 64] on the device."""
+        if self._w is None:
+            if device is not None and self._sd is not None:
+                self.to(device)
+            else:
+                raise _lib.SculptError("TSR: call load_state_dict() and to(device) before forward()")
+        rgb = self.image_processor(image, self.cfg["cond_image_size"])  # [B, S, S, 3] fp32 on the host
+        if rgb.shape[-1] != 3:
+            raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
+        codes = []
+        for i in range(rgb.shape[0]):
+            img = rgb[i].to(self.device, non_blocking=True).contiguous()
+            ctx, _ = self.image_tokens(img)
+            _, outb = self.backbone_tokens(ctx)
+            codes.append(self.scene_code(outb))
+        return torch.stack(codes, 0)
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ mesh extraction
+    def set_marching_cubes_resolution(self, resolution: int):
+        if self.isosurface_helper is not None and self.isosurface_helper.resolution == resolution:
+            return
+        self.isosurface_helper = MarchingCubeHelper(resolution)
+
+    def extract_meshes(self, scene_codes, enable_texture=False, resolution: int = 256, threshold: float = 25.0,
+                       x_range=None) -> List[Mesh]:
+        """The arithmetic of system.py:171-200 without the Blender sink: returns device tensors."""
+        self.set_marching_cubes_resolution(resolution)
+        r = self.renderer.cfg.radius
+        R = resolution
+        out = []
+        for scene_code in scene_codes:
+            planes = scene_code.contiguous()
+            # density_act - threshold == -(-(density_act - threshold))  (system.py:184, isosurface.py:45)
+            vol = ops.density_grid(planes, self.decoder, R, radius=r, density_bias=self.renderer.cfg.density_bias,
+                                   out_add=-threshold)
+            v_pos, t_pos_idx = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
+                                                  vert_mul=r - (-r), vert_add=-r)
+            color = None
+            if enable_texture:
+                color = self.renderer.query_triplane(self.decoder, v_pos, planes)["color"]
+            out.append(Mesh(v_pos, t_pos_idx, color))
+        return out
+
+    def extract_mesh(self, scene_codes, enable_texture=False, mesh_name="NewMesh", resolution: int = 256,
+                     threshold: float = 25.0):
+        """system.py:171-200: same signature; pushes each mesh into the sink (Blender when `bpy` is
+        importable, exactly like the reference's import_obj_blender) and also returns the meshes."""
+        meshes = self.extract_meshes(scene_codes, enable_texture, resolution, threshold)
+        sink = self.mesh_sink or _default_sink()
+        for m in meshes:
+            if sink is not None:
+                sink(m.vertices.cpu().numpy(), m.faces.cpu().numpy(),
+                     None if m.vertex_colors is None else m.vertex_colors.cpu().numpy(), mesh_name)
+        return meshes
+
+    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False) -> List[Mesh]:
+        """Headless entry point: images -> list of Mesh with host (NumPy) arrays."""
+        with torch.no_grad():
+            codes = self.forward(images, self.device)
+            meshes = self.extract_meshes(codes, enable_texture, mc_resolution, threshold)
+        return [Mesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(),
+                     None if m.vertex_colors is None else m.vertex_colors.cpu().numpy()) for m in meshes]
+
+
+def _default_sink():
+    try:
+        import bpy  # noqa: F401
+    except Exception:
+        return None
+    from .blender_sink import import_obj_blender
+
+    return import_obj_blender
+
+
+def load_config(yaml_path: str, vit_json_path: Optional[str] = None):
+    """checkpoints/config.yaml (+ config.json for the ViT) -> the dict TSR takes."""
+    import json
+
+    import yaml
+
+    with open(yaml_path) as f:
+        y = yaml.safe_load(f)
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULT_CFG.items()}
+    cfg["cond_image_size"] = y.get("cond_image_size", cfg["cond_image_size"])
+    tok = y.get("tokenizer", {})
+    cfg["tokenizer"].update({k: tok[k] for k in ("plane_size", "num_channels") if k in tok})
+    bb = dict(y.get("backbone", {}))
+    if isinstance(bb.get("in_channels"), str):  # "${tokenizer.num_channels}"
+        bb["in_channels"] = cfg["tokenizer"]["num_channels"]
+    cfg["backbone"].update({k: bb[k] for k in cfg["backbone"] if k in bb})
+    cfg["post_processor"].update(y.get("post_processor", {}))
+    cfg["decoder"].update(y.get("decoder", {}))
+    cfg["renderer"].update(y.get("renderer", {}))
+    if vit_json_path and os.path.exists(vit_json_path):
+        with open(vit_json_path) as f:
+            j = json.load(f)
+        for k in cfg["image_tokenizer"]:
+            if k in j:
+                cfg["image_tokenizer"][k] = j[k]
+    return cfg

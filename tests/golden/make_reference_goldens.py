@@ -118,6 +118,92 @@ def make_upsample():
     print("upsample:", y.shape, float(np.abs(y).max()))
 
 
+VIT_MAP = (("attention.attention.query", "attention.q_proj"), ("attention.attention.key", "attention.k_proj"),
+           ("attention.attention.value", "attention.v_proj"), ("attention.output.dense", "attention.o_proj"),
+           ("intermediate.dense", "mlp.fc1"), ("output.dense", "mlp.fc2"), ("encoder.layer.", "layers."))
+
+
+def to_installed_vit_name(k):
+    """HF-4.38 checkpoint names (what the reference's model.ckpt uses) -> names of the installed transformers."""
+    for a, b in VIT_MAP:
+        k = k.replace(a, b)
+    return k
+
+
+def make_tiny():
+    """G2: the reference's whole TSR.forward (system.py:82-115) at a tiny configuration."""
+    from transformers.models.vit.modeling_vit import ViTConfig, ViTModel
+    from sculptmate_amd.tsr.spec import TINY_CFG as C
+
+    v = C["image_tokenizer"]
+    tiny_vit = ViTConfig(hidden_size=v["hidden_size"], num_hidden_layers=v["num_hidden_layers"],
+                         num_attention_heads=v["num_attention_heads"], intermediate_size=v["intermediate_size"],
+                         image_size=v["image_size"], patch_size=v["patch_size"], layer_norm_eps=v["layer_norm_eps"],
+                         hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ViTModel.config_class.from_pretrained = classmethod(lambda cls, *a, **k: tiny_vit)
+    from tsr.system import TSR
+
+    b = C["backbone"]
+    cfg = {
+        "cond_image_size": C["cond_image_size"],
+        "image_tokenizer_cls": "x", "image_tokenizer": {},
+        "tokenizer_cls": "x", "tokenizer": dict(C["tokenizer"]),
+        "backbone_cls": "x", "backbone": dict(in_channels=b["in_channels"], num_attention_heads=b["num_attention_heads"],
+                                              attention_head_dim=b["attention_head_dim"], num_layers=b["num_layers"],
+                                              cross_attention_dim=b["cross_attention_dim"]),
+        "post_processor_cls": "x", "post_processor": dict(C["post_processor"]),
+        "decoder_cls": "x", "decoder": dict(C["decoder"]),
+        "renderer_cls": "x", "renderer": dict(C["renderer"]),
+    }
+    model = TSR(cfg).eval()
+    sd = synth.tsr_state(seed=21, cfg=C)
+    ref_sd = {}
+    for k, val in sd.items():
+        rk = to_installed_vit_name(k) if k.startswith("image_tokenizer.") else k
+        ref_sd[rk] = T(val)
+    missing, unexpected = model.load_state_dict(ref_sd, strict=False)
+    assert not unexpected and all("image_mean" in m or "image_std" in m for m in missing), (missing, unexpected)
+    img = synth.composite_rgb(synth.image_rgba(seed=22, size=C["cond_image_size"]))
+    ctx = model.image_tokenizer(T(img).permute(2, 0, 1)[None, None])[0, 0].t().contiguous()  # [T, H]
+    codes = model([img], device="cpu")
+    np.savez_compressed(os.path.join(HERE, "tsr_tiny.npz"), scene_codes=codes.numpy(), ctx=ctx.numpy(),
+                        meta=np.array("tsr_state(seed=21, TINY_CFG); image composite_rgb(image_rgba(22, 64)); "
+                                      "transformers %s ('size' pos-embed mode)" % __import__("transformers").__version__))
+    print("tiny:", codes.shape, float(codes.abs().max()), ctx.shape)
+
+
+def make_block():
+    """G3: one full-size BasicTransformerBlock(1024, 16, 64, cross 768) on [3072,1024] x [1025,768]
+    (basic_transformer_block.py:149-206)."""
+    from sculptmate_amd.tsr.spec import make_cfg
+    from tsr.models.transformer.basic_transformer_block import BasicTransformerBlock
+
+    cfg = make_cfg(vit_layers=1, layers=1)
+    sd = synth.tsr_state(seed=23, cfg=cfg)
+    blk = BasicTransformerBlock(1024, 16, 64, cross_attention_dim=768, activation_fn="geglu", attention_bias=False).eval()
+    pre = "backbone.transformer_blocks.0."
+    blk.load_state_dict({k[len(pre):]: T(v) for k, v in sd.items() if k.startswith(pre)}, strict=True)
+    h = np.random.default_rng(24).standard_normal((3072, 1024), dtype=np.float32)
+    ctx = np.random.default_rng(25).standard_normal((1025, 768), dtype=np.float32)
+    y = blk(T(h)[None], encoder_hidden_states=T(ctx)[None])[0].numpy()
+    idx = np.unique(np.random.default_rng(26).integers(0, y.size, 8192)).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "tsr_block.npz"), idx=idx, y=y.reshape(-1)[idx],
+                        ysum=np.array([y.astype(np.float64).sum(), np.abs(y).astype(np.float64).sum()]),
+                        meta=np.array("tsr_state(23, make_cfg(vit_layers=1, layers=1)) block 0; h rng 24, ctx rng 25"))
+    print("block:", y.shape, float(np.abs(y).max()))
+
+
+def make_preproc():
+    """G1: ImagePreprocessor 1024^2 -> 512^2 antialiased bilinear (utils.py:62-112)."""
+    from tsr.utils import ImagePreprocessor
+
+    img = synth.composite_rgb(synth.image_rgba(seed=27, size=1024))
+    y = ImagePreprocessor()(img, 512).numpy()
+    idx = np.unique(np.random.default_rng(28).integers(0, y.size, 8192)).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "preproc.npz"), idx=idx, y=y.reshape(-1)[idx], ysum=np.array(y.astype(np.float64).sum()))
+    print("preproc:", y.shape)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["query", "grid", "upsample"]
     for w in which:

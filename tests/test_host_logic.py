@@ -1,0 +1,104 @@
+"""Host-side mirror of the reference interface (no GPU): spec, config, facade return codes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sculptmate_amd import synth
+from sculptmate_amd.tsr.spec import DEFAULT_CFG, SMALL_CFG, param_spec
+
+
+def test_checkpoint_inventory_matches_reference_counts():
+    """549 tensors / 419 275 628 parameters measured on the reference."""
+    spec = param_spec(DEFAULT_CFG)
+    assert len(spec) == 549
+    assert sum(int(np.prod(s)) for s in spec.values()) == 419275628
+    assert spec["backbone.transformer_blocks.15.ff.net.0.proj.weight"] == (8192, 1024)
+    assert spec["image_tokenizer.model.encoder.layer.11.attention.attention.query.weight"] == (768, 768)
+    assert spec["post_processor.upsample.weight"] == (1024, 40, 2, 2)
+    assert spec["decoder.layers.18.weight"] == (4, 64)
+
+
+def test_synthetic_state_covers_the_inventory():
+    sd = synth.tsr_state(0, SMALL_CFG)
+    spec = param_spec(SMALL_CFG)
+    assert set(sd) == set(spec)
+    assert all(tuple(sd[k].shape) == tuple(spec[k]) and sd[k].dtype == np.float32 for k in spec)
+
+
+def test_strict_state_dict_loading():
+    from sculptmate_amd.tsr import TSR
+
+    sd = synth.tsr_state(0, SMALL_CFG)
+    m = TSR(SMALL_CFG)
+    m.load_state_dict(sd)
+    bad = dict(sd)
+    bad.pop("backbone.proj_in.bias")
+    with pytest.raises(RuntimeError):
+        TSR(SMALL_CFG).load_state_dict(bad)
+    bad = dict(sd)
+    bad["extra.weight"] = np.zeros(1, np.float32)
+    with pytest.raises(RuntimeError):
+        TSR(SMALL_CFG).load_state_dict(bad)
+    bad = dict(sd)
+    bad["backbone.proj_in.bias"] = np.zeros(3, np.float32)
+    with pytest.raises(RuntimeError):
+        TSR(SMALL_CFG).load_state_dict(bad)
+
+
+def test_reference_config_files_parse(tmp_path):
+    from sculptmate_amd.tsr import load_config
+
+    (tmp_path / "config.yaml").write_text(
+        "cond_image_size: 512\ntokenizer:\n  plane_size: 32\n  num_channels: 1024\n"
+        "backbone:\n  in_channels: ${tokenizer.num_channels}\n  num_attention_heads: 16\n  attention_head_dim: 64\n"
+        "  num_layers: 16\n  cross_attention_dim: 768\npost_processor:\n  in_channels: 1024\n  out_channels: 40\n"
+        "decoder:\n  in_channels: 120\n  n_neurons: 64\n  n_hidden_layers: 9\n  activation: silu\n"
+        "renderer:\n  radius: 0.87\n  feature_reduction: concat\n  density_activation: exp\n  density_bias: -1.0\n"
+        "  num_samples_per_ray: 128\n")
+    (tmp_path / "config.json").write_text('{"hidden_size": 768, "num_hidden_layers": 12, "num_attention_heads": 12, '
+                                          '"intermediate_size": 3072, "patch_size": 16, "image_size": 224, "layer_norm_eps": 1e-12}')
+    cfg = load_config(str(tmp_path / "config.yaml"), str(tmp_path / "config.json"))
+    assert param_spec(cfg) == param_spec(DEFAULT_CFG)
+    assert cfg["renderer"]["radius"] == 0.87
+
+
+def test_generator_facade_return_codes(tmp_path):
+    """TripoGenerator: 1 = model not loaded, 2 = initialisation error (generate.py:17-43)."""
+    from sculptmate_amd.generate import TripoGenerator
+
+    g = TripoGenerator(torch.device("cpu"))
+    assert g.chunk_size == 8192 and g.mc_resolution == 256 and g.model is None
+    assert g.generate_mesh(np.zeros((512, 512, 3), np.float32)) == 1
+    g.checkpoint_dir = str(tmp_path / "nope")
+    assert g.initiate_model() == 2
+    assert g.model is None
+
+
+def test_tsr_refuses_cpu_device():
+    from sculptmate_amd._lib import SculptError
+    from sculptmate_amd.tsr import TSR
+
+    with pytest.raises(SculptError):
+        TSR(SMALL_CFG).to("cpu")
+
+
+def test_from_pretrained_missing_dir():
+    from sculptmate_amd.tsr import TSR
+
+    with pytest.raises(FileNotFoundError):
+        TSR.from_pretrained("/nonexistent/dir", "config.yaml", "model.ckpt")
+
+
+def test_scale_tensor_and_renderer_chunk_api():
+    from sculptmate_amd.tsr import TriplaneNeRFRenderer
+    from sculptmate_amd.tsr.utils import scale_tensor
+
+    x = torch.tensor([0.0, 0.5, 1.0])
+    y = scale_tensor(x, (0, 1), (-0.87, 0.87))
+    assert torch.equal(y, x * (0.87 - (-0.87)) + (-0.87))
+    r = TriplaneNeRFRenderer(DEFAULT_CFG["renderer"])
+    r.set_chunk_size(8192)
+    with pytest.raises(AssertionError):
+        r.set_chunk_size(-1)
