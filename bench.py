@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- meshes/sec of the TripoSR generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one image -> mesh: TSR.forward (ViT-B/16 + 16-block triplane transformer, bf16 MFMA)
++ extract_mesh at 256^3 (fused triplane sample + NeRF-MLP on fp32 MFMA, Lewiner marching cubes).
+Workload = BASELINE.json configs[1] "TripoSR single image, mc_resolution=256, bf16 on 1xMI355X";
+with N GPUs each rank runs the same per-GPU workload on its own images (configs[2]: one image per
+GPU, no collectives on the data path) -> "scaling": "weak".
+Inputs are resident in HBM when the timed region starts (synthetic 512x512 RGBA composited on grey,
+random-init weights of the reference architecture; the decoder's density bias is calibrated so
+that ~1.5 % of the voxels are inside the iso-surface).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
+MC_RES = 256
+THRESHOLD = 25.0
+
+
+def build_model(device, seed):
+    from sculptmate_amd import ops, synth
+    from sculptmate_amd.tsr import TSR
+
+    sd = synth.tsr_state(seed=seed)
+    model = TSR(pos_embed_mode="scale_factor")
+    model.load_state_dict(sd)
+    model.to(device)
+    return model, sd
+
+
+def calibrate(model, sd, img_dev, inside=0.015):
+    """Shift decoder.layers.18.bias[0] so that `inside` of the voxels exceed the threshold."""
+    from sculptmate_amd import ops, synth
+
+    ctx, _ = model.image_tokens(img_dev)
+    _, outb = model.backbone_tokens(ctx)
+    planes = model.scene_code(outb)
+    probe = ops.density_grid(planes, model.decoder, 64)
+    pre = torch.log(probe).cpu().numpy().astype(np.float64) + 1.0  # density before the -1 bias
+    shift = synth.calibrate_density_bias(pre, inside_fraction=inside, threshold=THRESHOLD)
+    k = "decoder.layers.18.bias"
+    b = sd[k].copy()
+    b[0] += np.float32(shift)
+    sd[k] = b
+    model.load_state_dict(sd)
+    return shift
+
+
+def one_step(model, img_dev, events=None):
+    ctx, _ = model.image_tokens(img_dev)
+    _, outb = model.backbone_tokens(ctx)
+    planes = model.scene_code(outb)
+    from sculptmate_amd import ops
+
+    r = model.renderer.cfg.radius
+    vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
+                           out_add=-THRESHOLD, events=events)
+    v, f = ops.marching_cubes(vol.view(MC_RES, MC_RES, MC_RES), 0.0, reference_order=True, vert_div=MC_RES - 1.0,
+                              vert_mul=r - (-r), vert_add=-r)
+    return v, f
+
+
+def cpu_baseline(sd, img_np, planes_np):
+    """The oracle (CPU restatement of the reference) timed on this box's host cores on a bounded
+    sample of the same workload: full TSR.forward for one image (torch fp32, all cores), the dense
+    query on 8 of the 256 lattice planes (1/32 of the grid, C oracle with OpenMP), and marching
+    cubes on the full 256^3 volume (C oracle, single thread like scikit-image)."""
+    from oracle import capi, tsr_ref
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import DEFAULT_CFG
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    tsr_ref.tsr_forward(sd, img_np, DEFAULT_CFG, pos_mode="scale_factor")
+    t_fwd = time.time() - t0
+    Ws, bs = synth.decoder_lists(sd)
+    R = MC_RES
+    planes_sub = 8
+    t0 = time.time()
+    capi.density_grid(planes_np, Ws, bs, R, begin=0, end=planes_sub * R * R)
+    t_q = (time.time() - t0) * (R / planes_sub)
+    g = np.linspace(-0.87, 0.87, R, dtype=np.float32)
+    x, y, z = np.meshgrid(g, g, g, indexing="ij")
+    vol = (25.0 * np.exp(9.0 * (0.5 - np.sqrt(x * x + 1.3 * y * y + 0.8 * z * z))) - 25.0).astype(np.float32)
+    t0 = time.time()
+    capi.marching_cubes(vol, 0.0)
+    t_mc = time.time() - t0
+    total = t_fwd + t_q + t_mc
+    return {"value": 1.0 / total, "unit": "meshes/s", "cores": cores, "kind": "port",
+            "sample": "1 image: full TSR.forward %.1fs + dense query on 8/256 lattice planes scaled x32 = %.1fs "
+                      "+ marching cubes 256^3 %.2fs" % (t_fwd, t_q, t_mc)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from sculptmate_amd import synth
+
+    model, sd = build_model(device, seed=0)  # every rank holds a full replica (no weight sharding)
+    imgs_np = [synth.composite_rgb(synth.image_rgba(seed=100 + rank * 8 + i)) for i in range(4)]
+    imgs = [torch.from_numpy(a).to(device).contiguous() for a in imgs_np]
+    with torch.no_grad():
+        calibrate(model, sd, imgs[0])
+        for i in range(args.warmup):
+            one_step(model, imgs[i % len(imgs)])
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nv = nf = 0
+        for i in range(args.steps):
+            v, f = one_step(model, imgs[i % len(imgs)], events=ev[i])
+            nv, nf = v.shape[0], f.shape[0]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if rank == 0:
+        achieved = FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_density_grid.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "meshes/sec + ms/image, TripoSR 256^3 grid, at 1/2/4/8 MI355X",
+            "value": args.gpus * args.steps / elapsed,
+            "unit": "meshes/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 (density MLP + marching cubes) / bf16 (transformer)",
+            "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
+            "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
+                       "mc_resolution": MC_RES, "threshold": THRESHOLD, "images_per_gpu_per_step": 1,
+                       "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
+            "roofline": {"kernel": "density_grid_kernel (fused triplane-sum + NeRF-MLP, fp32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            with torch.no_grad():
+                ctx, _ = model.image_tokens(imgs[0])
+                _, outb = model.backbone_tokens(ctx)
+                planes_np = model.scene_code(outb).cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sd, imgs_np[0], planes_np)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

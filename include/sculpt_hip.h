@@ -8,6 +8,7 @@
  *   sculpt_triplane_query        TriplaneNeRFRenderer.query_triplane + NeRFMLP.forward
  *                                  TripoSR/tsr/models/nerf_renderer.py:41-91
  *                                  TripoSR/tsr/models/network_utils.py:116-124
+ *   sculpt_plane_features +
  *   sculpt_density_grid          TSR.extract_mesh's dense query over MarchingCubeHelper.grid_vertices
  *                                  TripoSR/tsr/system.py:171-183, TripoSR/tsr/models/isosurface.py:25-39
  *   sculpt_mc_*                  MarchingCubeHelper.forward -> skimage.measure.marching_cubes(vol, 0.0)
@@ -71,19 +72,29 @@ int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *
                           float *density, float *features, float *density_act, float *color,
                           sculpt_stream_t stream);
 
-/* Dense density grid: density_act at lattice points (ix,iy,iz), ix in [x_begin,x_end), flat order
- * ix*R*R + iy*R + iz (isosurface.py:34-37), positions taken from axis_coords[R] (the lattice is
- * separable; axis_coords[i] is the coordinate in (-radius,radius) of index i, computed by the host
- * exactly as the reference does: linspace(0,1,R) then scale_tensor, system.py:177-181).
- *   workspace   sculpt_density_grid_workspace_bytes(R, x_end-x_begin) bytes of scratch
- *   out         f32 [(x_end-x_begin)*R*R] = density_act + out_add   (out_add = -threshold gives the
- *               volume the reference hands to marching cubes, system.py:184 + isosurface.py:45)
- * The first MLP layer is applied per plane before the per-point sum (linear in the bilinear
- * samples); see DESIGN.md "fused sample+MLP kernel". */
+/* Dense density grid over the lattice slab ix in [x_begin,x_end), flat order ix*R*R + iy*R + iz
+ * (isosurface.py:34-37), in two launches:
+ *
+ * 1. sculpt_plane_features: the lattice is separable, and the first MLP layer is linear in the three
+ *    bilinear plane samples, so it is evaluated once per lattice PAIR and plane:
+ *      FA[ix][iy] = W0[:, 0:C]   . sample(plane0; x=ix, y=iy) + b0
+ *      FB[ix][iz] = W0[:, C:2C]  . sample(plane1; x=ix, z=iz)
+ *      FC[iy][iz] = W0[:, 2C:3C] . sample(plane2; y=iy, z=iz)      (nerf_renderer.py:57-68)
+ *    axis_coords[R]: coordinate in (-radius,radius) of lattice index i, computed by the host exactly
+ *    as the reference does (linspace(0,1,R) then scale_tensor, isosurface.py:28-32, system.py:177-181).
+ *    workspace: sculpt_density_grid_workspace_bytes(R, x_end-x_begin) bytes, holds FA|FB|FC.
+ * 2. sculpt_density_grid: per point silu(FA+FB+FC) -> hidden layers (fp32 MFMA) -> density row of the
+ *    last layer -> out = exp(density + density_bias) + out_add, f32 [(x_end-x_begin)*R*R].
+ *    out_add = -threshold gives the volume the reference hands to marching cubes
+ *    (system.py:184 + isosurface.py:45).
+ * Linearity only regroups the fp32 sum of layer 0 (see DESIGN.md "fused sample+MLP kernel"). */
 size_t sculpt_density_grid_workspace_bytes(int R, int nx);
-int sculpt_density_grid(const float *planes, int C, int H, int W, const void *mlp_packed,
-                        int n_hidden_64, const float *axis_coords, int R, int x_begin, int x_end, float radius,
-                        float density_bias, float out_add, void *workspace, float *out, sculpt_stream_t stream);
+int sculpt_plane_features(const float *planes, int C, int H, int W, const void *mlp_packed,
+                          const float *axis_coords, int R, int x_begin, int x_end, float radius,
+                          void *workspace, sculpt_stream_t stream);
+int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
+                        float density_bias, float out_add, const void *workspace, float *out,
+                        sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Marching cubes (Lewiner), output identical to skimage.measure.marching_cubes(vol, level)

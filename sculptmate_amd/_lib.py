@@ -39,7 +39,8 @@ SIGNATURES = {
     "sculpt_mlp_pack": (_i, [_pp, _pp, _i, _vp, _vp, _sz]),
     "sculpt_triplane_query": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sculpt_density_grid_workspace_bytes": (_sz, [_i, _i]),
-    "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _pi64, _pi64, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _f, _f, _f, _vp, _vp, _vp]),

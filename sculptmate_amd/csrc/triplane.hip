@@ -468,16 +468,13 @@ size_t sculpt_density_grid_workspace_bytes(int R, int nx) {
     return ((size_t)2 * nx * R + (size_t)R * R) * 64 * sizeof(float);
 }
 
-int sculpt_density_grid(const float *planes, int C, int H, int W, const void *mlp_packed,
-                        int n_hidden_64, const float *axis_coords, int R, int x_begin, int x_end, float radius,
-                        float density_bias, float out_add, void *workspace, float *out, sculpt_stream_t stream) {
+int sculpt_plane_features(const float *planes, int C, int H, int W, const void *mlp_packed,
+                          const float *axis_coords, int R, int x_begin, int x_end, float radius,
+                          void *workspace, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
-    SC_REQUIRE(C == 40, "density_grid: built for C=40 channels per plane (got %d)", C);
-    SC_REQUIRE(planes && mlp_packed && axis_coords && workspace && out, "density_grid: null argument");
-    SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "density_grid: bad range [%d,%d) of %d", x_begin, x_end, R);
-    SC_REQUIRE(n_hidden_64 >= 0, "density_grid: bad n_hidden_64");
-    const size_t lds = lds_bytes_for(n_hidden_64);
-    SC_REQUIRE(lds <= 160 * 1024, "density_grid: %d hidden layers do not fit LDS", n_hidden_64);
+    SC_REQUIRE(C == 40, "plane_features: built for C=40 channels per plane (got %d)", C);
+    SC_REQUIRE(planes && mlp_packed && axis_coords && workspace, "plane_features: null argument");
+    SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "plane_features: bad range [%d,%d) of %d", x_begin, x_end, R);
     const int nx = x_end - x_begin;
     float *FA = reinterpret_cast<float *>(workspace);
     float *FB = FA + (size_t)nx * R * 64;
@@ -488,6 +485,22 @@ int sculpt_density_grid(const float *planes, int C, int H, int W, const void *ml
                        reinterpret_cast<const float *>(mlp_packed), axis_coords, R, x_begin, nx, radius,
                        span, FA, FB, FC);
     SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
+                        float density_bias, float out_add, const void *workspace, float *out,
+                        sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    SC_REQUIRE(mlp_packed && workspace && out, "density_grid: null argument");
+    SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "density_grid: bad range [%d,%d) of %d", x_begin, x_end, R);
+    SC_REQUIRE(n_hidden_64 >= 0, "density_grid: bad n_hidden_64");
+    const size_t lds = lds_bytes_for(n_hidden_64);
+    SC_REQUIRE(lds <= 160 * 1024, "density_grid: %d hidden layers do not fit LDS", n_hidden_64);
+    const int nx = x_end - x_begin;
+    const float *FA = reinterpret_cast<const float *>(workspace);
+    const float *FB = FA + (size_t)nx * R * 64;
+    const float *FC = FB + (size_t)nx * R * 64;
     SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
     const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());

@@ -92,22 +92,38 @@ def _workspace(key, nbytes, device):
 
 
 def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None,
-                 out_add=0.0):
+                 out_add=0.0, events=None):
     """density_act (+ out_add) over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]
-    (TSR.extract_mesh's dense query, system.py:171-183; out_add=-threshold folds system.py:184)."""
+    (TSR.extract_mesh's dense query, system.py:171-183; out_add=-threshold folds system.py:184).
+    events: optional (start, stop) torch.cuda.Event pair recorded around the fused MLP launch only."""
     planes = _req(planes, torch.float32, "planes")
     R = int(resolution)
     x_end = R if x_end is None else int(x_end)
     nx = x_end - x_begin
     _, C, H, W = planes.shape
-    axis = grid_axis_coords(R, radius).to(planes.device)
+    axis = _axis_table(R, radius, planes.device)
     ws = _workspace(("dg", planes.device), lib.sculpt_density_grid_workspace_bytes(R, nx), planes.device)
     if out is None:
         out = torch.empty(nx * R * R, dtype=torch.float32, device=planes.device)
-    check(lib.sculpt_density_grid(_ptr(planes), C, H, W, _ptr(mlp.blob), mlp.n_hidden, _ptr(axis), R,
-                                  int(x_begin), x_end, float(radius), float(density_bias), float(out_add), _ptr(ws),
-                                  _ptr(out), _stream()))
+    check(lib.sculpt_plane_features(_ptr(planes), C, H, W, _ptr(mlp.blob), _ptr(axis), R, int(x_begin), x_end,
+                                    float(radius), _ptr(ws), _stream()))
+    if events is not None:
+        events[0].record()
+    check(lib.sculpt_density_grid(_ptr(mlp.blob), mlp.n_hidden, R, int(x_begin), x_end, float(density_bias),
+                                  float(out_add), _ptr(ws), _ptr(out), _stream()))
+    if events is not None:
+        events[1].record()
     return out
+
+
+_axis_cache = {}
+
+
+def _axis_table(R, radius, device):
+    key = (R, float(radius), device)
+    if key not in _axis_cache:
+        _axis_cache[key] = grid_axis_coords(R, radius).to(device)
+    return _axis_cache[key]
 
 
 # ----------------------------------------------------------------------------------------------
