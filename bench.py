@@ -84,8 +84,9 @@ def cpu_baseline(sd, img_np, planes_np):
     from sculptmate_amd import synth
     from sculptmate_amd.tsr.spec import DEFAULT_CFG
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # more threads than this only oversubscribes torch's CPU GEMMs
     torch.set_num_threads(cores)
+    capi.set_threads(cores)
     t0 = time.time()
     tsr_ref.tsr_forward(sd, img_np, DEFAULT_CFG, pos_mode="scale_factor")
     t_fwd = time.time() - t0

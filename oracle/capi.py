@@ -49,8 +49,15 @@ def lib():
         L.oracle_density_grid.restype = None
         L.oracle_grid_point.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
         L.oracle_grid_point.restype = None
+        L.oracle_set_threads.argtypes = [ctypes.c_int]
+        L.oracle_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+    return lib().oracle_max_threads()
 
 
 class MCError(ValueError):

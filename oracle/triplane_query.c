@@ -128,3 +128,12 @@ void oracle_density_grid(const float *planes, int C, int H, int W, int R, float 
                     NULL, NULL, out + (i - begin), NULL);
     }
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int oracle_max_threads(void) { return omp_get_max_threads(); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+int oracle_max_threads(void) { return 1; }
+#endif
