@@ -12,14 +12,17 @@
 //         B operand of the second product (k order permuted to key = 16s + 8(j>>2) + 4h + (j&3));
 //         the A operand V^T is read from LDS in that same key order.  V arrives already transposed
 //         ([head*64+d][key], written by the QKV GEMM epilogue), so no transposing read is needed.
-// K and V^T tiles are register-prefetched one tile ahead into double-buffered LDS (one barrier per
-// tile); K rows use the (row>>1)&7 chunk swizzle so ds_read_b128 is conflict-free.
+// K and V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4) one tile ahead into double-buffered
+// LDS (one barrier per tile); rows use the (row>>1)&7 chunk swizzle (applied to the source address
+// and to the read address) so ds_read_b128 is conflict-free.
 #include "common.h"
 
 namespace sculpt {
 
 typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *alds_ptr_t;
+typedef const __attribute__((address_space(1))) void *agbl_ptr_t;
 
 __device__ __forceinline__ int a_lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
@@ -42,43 +45,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const abf16x8 *>(Q + (long)qld * ldq + head * 64 + ks * 16 + h * 8);
 
-    // staging: K tile 64 keys x 8 chunks, V^T tile 64 d x 8 chunks; 2 chunks each per thread
+    // staging by LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 8 tile rows (1 KiB);
+    // each wave fills rows 16*wave .. 16*wave+15 of the K tile and of the V^T tile.  The chunk XOR
+    // is applied to the per-lane source address (the LDS image is lane-linear).
     const int nt = (Tk + 63) / 64;
-    uint4 kreg[2], vreg[2];
-    int sdst[2], srow[2], scol[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + 256 * i;
-        srow[i] = id >> 3; scol[i] = id & 7;
-        sdst[i] = a_lds_off(srow[i], scol[i]);
-    }
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = min(t * 64 + srow[i], Tk - 1);
-            kreg[i] = *reinterpret_cast<const uint4 *>(K + (long)key * ldk + head * 64 + scol[i] * 8);
-            vreg[i] = *reinterpret_cast<const uint4 *>(Vt + (long)(head * 64 + srow[i]) * ldvt + t * 64 + scol[i] * 8);
-        }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4 *>(&Ks[buf][sdst[i]]) = kreg[i];
-            *reinterpret_cast<uint4 *>(&Vs[buf][sdst[i]]) = vreg[i];
-        }
-    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int r0 = 16 * wave_u + srow, r1 = r0 + 8;
+    const int c0s = (sslot ^ ((r0 >> 1) & 7)) << 3, c1s = (sslot ^ ((r1 >> 1) & 7)) << 3;
+    const uint16_t *vsrc0 = Vt + (long)(head * 64 + r0) * ldvt + c0s;
+    const uint16_t *vsrc1 = Vt + (long)(head * 64 + r1) * ldvt + c1s;
+    const uint16_t *kptr = K + head * 64;
+    const int sdst = wave_u * 2048;
+#define STAGE(buf, t)                                                                                         \
+    do {                                                                                                      \
+        const int key0 = min((t) * 64 + r0, Tk - 1), key1 = min((t) * 64 + r1, Tk - 1);                        \
+        __builtin_amdgcn_global_load_lds((agbl_ptr_t)(kptr + (long)key0 * ldk + c0s), (alds_ptr_t)(&Ks[buf][sdst]), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((agbl_ptr_t)(kptr + (long)key1 * ldk + c1s), (alds_ptr_t)(&Ks[buf][sdst + 1024]), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((agbl_ptr_t)(vsrc0 + (t) * 64), (alds_ptr_t)(&Vs[buf][sdst]), 16, 0, 0);                      \
+        __builtin_amdgcn_global_load_lds((agbl_ptr_t)(vsrc1 + (t) * 64), (alds_ptr_t)(&Vs[buf][sdst + 1024]), 16, 0, 0);               \
+    } while (0)
 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    gload(0);
-    swrite(0);
-    __syncthreads();
+    STAGE(0, 0);
+    __syncthreads();  // vmcnt(0) for the LDS-DMA + barrier
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) gload(t + 1);
+        if (t + 1 < nt) STAGE(buf ^ 1, t + 1);
         // ---- S^T = K . Q^T
         f32x16 s0, s1;
 #pragma unroll
@@ -137,9 +134,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
         }
-        if (t + 1 < nt) swrite(buf ^ 1);
         __syncthreads();
     }
+#undef STAGE
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q < Tq) {

@@ -9,23 +9,27 @@
 //
 // out[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] ) (+ residual[m][n])
 //
-// Tiling: 128 activation rows x 128 weight rows per 256-thread workgroup (4 waves as 2x2), BK = 64,
-// v_mfma_f32_16x16x32_bf16.  The WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B
-// operand, so a lane ends up holding 4 consecutive output columns n of one row m: bias / GEGLU /
-// residual are per-lane vector ops and the store is one 16-byte (fp32) or 8-byte (bf16) write.
-// Both operands are K-contiguous in HBM, which is exactly the fragment shape (8 consecutive k per
-// lane), so tiles are staged row-major into LDS with 16-byte chunks XOR-swizzled by (row>>1)&7:
-// every ds_read_b128 lane group then covers all 64 banks (conflict-free).
-// Global->LDS staging is register-prefetched one K-tile ahead (loads issued before the MFMA
-// block, ds_write after it), LDS double-buffered: one barrier per K-tile.
+// Tiling: 128 activation rows x BW (128 or 64) weight rows per 256-thread workgroup (4 waves as
+// 2x2), BK = 64, v_mfma_f32_16x16x32_bf16.  The WEIGHT tile is the MFMA A operand and the ACTIVATION
+// tile the B operand, so a lane ends up holding 4 consecutive output columns n of one row m: bias /
+// GEGLU / residual are per-lane vector ops and the store is one 16-byte (fp32) or 8-byte (bf16) write.
+// Both operands are K-contiguous in HBM = the fragment shape (8 consecutive k per lane).
+// Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), double-buffered, next K-tile
+// issued before the MFMA block of the current one; one barrier per K-tile.  The LDS image is
+// lane-linear per wave instruction (8 rows x 128 B); the (row>>1)&7 chunk XOR that makes every
+// ds_read_b128 lane group cover all 64 banks is applied to the per-lane SOURCE address and to the
+// read address (guide rule 21).
+// The 64-row weight tile is chosen when the 128x128 grid would leave CUs idle (N=1024, M=3072 is
+// only 192 tiles for 256 CUs).
 #include "common.h"
 
 namespace sculpt {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 static constexpr int BM = 128;   // activation rows per block
-static constexpr int BW = 128;   // weight rows per block
 static constexpr int BK = 64;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -43,95 +47,114 @@ struct GemmArgs {
     int M, N, K;
 };
 
-template <int EPI>
+// EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
+template <int EPI, int BW>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][BM * 128];  // [buf][W|A][tile]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WT = BW * 128;  // bytes of a weight tile
+    constexpr int AT = BM * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (WT + AT)];  // [buf][W | A]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware order is irrelevant here (tiles share little); plain 2D grid: x = n tile, y = m tile
-    constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? 64 : 128;  // output columns per block
+    constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? BW / 2 : BW;  // output columns per block
+    constexpr int TI = BW / 32;                                     // 16-row weight sub-tiles per wave
     const int n0 = blockIdx.x * NOUT;
     const int m0 = blockIdx.y * BM;
 
-    // global row of tile row j of the weight operand
-    auto wrow = [&](int j) -> int {
-        if (EPI == SCULPT_EPI_GEGLU) {
-            const int sub = j >> 4, within = j & 15;
-            return ((sub & 1) ? g.N : 0) + n0 + (sub >> 1) * 16 + within;
-        }
-        return n0 + j;
-    };
-
-    // staging: 1024 chunks per operand tile, 4 per thread: chunk id = tid + 256*i -> row id>>3, c id&7
-    const uint16_t *wsrc[4];
-    const uint16_t *asrc[4];
-    int sdst[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i, r = id >> 3, c = id & 7;
-        wsrc[i] = g.W + (long)wrow(r) * g.ldw + c * 8;
-        const int m = min(m0 + r, g.M - 1);
-        asrc[i] = g.A + (long)m * g.lda + c * 8;
-        sdst[i] = lds_off(r, c);
+    // ---- staging addresses.  One wave instruction fills 8 tile rows (1 KiB).  Lane l of the
+    // instruction that fills rows 8q..8q+7 writes LDS chunk (row = 8q + l/8, slot = l%8) and must
+    // therefore READ source chunk slot ^ ((row>>1)&7) of that row.
+    const int srow = lane >> 3, sslot = lane & 7;
+    constexpr int WI = BW / 32;  // wave instructions per wave for the weight tile (BW/8 rows-of-8 / 4 waves)
+    const uint16_t *wsrc0, *wsrc1, *wsrc2, *wsrc3;
+    const uint16_t *asrc0, *asrc1, *asrc2, *asrc3;
+    {
+        auto wrow = [&](int j) -> int {
+            if (EPI == SCULPT_EPI_GEGLU) {
+                const int sub = j >> 4, within = j & 15;
+                return ((sub & 1) ? g.N : 0) + n0 + (sub >> 1) * 16 + within;
+            }
+            return n0 + j;
+        };
+        auto wp = [&](int q) -> const uint16_t * {
+            const int r = 8 * (wave * WI + q) + srow;
+            return g.W + (long)wrow(r) * g.ldw + ((sslot ^ ((r >> 1) & 7)) << 3);
+        };
+        auto ap = [&](int q) -> const uint16_t * {
+            const int r = 8 * (wave * 4 + q) + srow;
+            const int m = min(m0 + r, g.M - 1);
+            return g.A + (long)m * g.lda + ((sslot ^ ((r >> 1) & 7)) << 3);
+        };
+        wsrc0 = wp(0); wsrc1 = wp(1 % WI); wsrc2 = wp(2 % WI); wsrc3 = wp(3 % WI);
+        asrc0 = ap(0); asrc1 = ap(1); asrc2 = ap(2); asrc3 = ap(3);
     }
-    uint4 wreg[4], areg[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wreg[i] = *reinterpret_cast<const uint4 *>(wsrc[i] + kt * BK);
-            areg[i] = *reinterpret_cast<const uint4 *>(asrc[i] + kt * BK);
-        }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4 *>(&smem[buf][0][sdst[i]]) = wreg[i];
-            *reinterpret_cast<uint4 *>(&smem[buf][1][sdst[i]]) = areg[i];
-        }
-    };
+    const int wdst = (wave * WI) * 1024, adst = (wave * 4) * 1024;  // wave-uniform LDS byte offsets
 
-    f32x4 acc[4][4];
+#define STAGE(buf, kt)                                                                                       \
+    do {                                                                                                     \
+        unsigned char *wb = smem + (buf) * (WT + AT);                                                        \
+        unsigned char *ab = wb + WT;                                                                         \
+        const int ko = (kt) * BK;                                                                            \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc0 + ko), (lds_ptr_t)(wb + wdst), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc1 + ko), (lds_ptr_t)(wb + wdst + 1024), 16, 0, 0);  \
+        if (WI == 4) {                                                                                       \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc2 + ko), (lds_ptr_t)(wb + wdst + 2048), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc3 + ko), (lds_ptr_t)(wb + wdst + 3072), 16, 0, 0); \
+        }                                                                                                    \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc0 + ko), (lds_ptr_t)(ab + adst), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc1 + ko), (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc2 + ko), (lds_ptr_t)(ab + adst + 2048), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc3 + ko), (lds_ptr_t)(ab + adst + 3072), 16, 0, 0);  \
+    } while (0)
+
+    f32x4 acc[TI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
-    gload(0);
-    swrite(0);
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
+    // fragment read offsets (bytes) for ks = 0; ks = 1 flips chunk bit 2 -> XOR 64 bytes
+    int aoff[TI], boff[4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) aoff[i] = lds_off(wr * (BW / 2) + i * 16 + fr, fq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = lds_off(wc * 64 + j * 16 + fr, fq);
+
+    STAGE(0, 0);
+    __syncthreads();  // emits vmcnt(0) for the LDS-DMA in flight
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) STAGE(buf ^ 1, kt + 1);
+        const unsigned char *wb = smem + buf * (WT + AT);
+        const unsigned char *ab = wb + WT;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t af[4], bfr[4];
+            bf16x8_t af[TI], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[i] = *reinterpret_cast<const bf16x8_t *>(&smem[buf][0][lds_off(wr * 64 + i * 16 + fr, ks * 4 + fq)]);
+            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8_t *>(wb + (aoff[i] ^ (ks << 6)));
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8_t *>(&smem[buf][1][lds_off(wc * 64 + j * 16 + fr, ks * 4 + fq)]);
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t *>(ab + (boff[j] ^ (ks << 6)));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) swrite(buf ^ 1);
         __syncthreads();
     }
+#undef STAGE
 
-    // epilogue: acc[i][j][r] = out[m = m0 + wc*64 + j*16 + fr][tile row = wr*64 + i*16 + fq*4 + r]
+    // epilogue: acc[i][j][r] = out[m = m0 + wc*64 + j*16 + fr][tile row = wr*(BW/2) + i*16 + fq*4 + r]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wc * 64 + j * 16 + fr;
         if (m >= g.M) continue;
         if (EPI == SCULPT_EPI_GEGLU) {
 #pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {
-                const int n = n0 + (wr * 2 + ip) * 16 + fq * 4;  // output column of r = 0
+            for (int ip = 0; ip < TI / 2; ++ip) {
+                const int n = n0 + (wr * (TI / 2) + ip) * 16 + fq * 4;  // output column of r = 0
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -149,8 +172,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wr * 64 + i * 16 + fq * 4;
+            for (int i = 0; i < TI; ++i) {
+                const int n = n0 + wr * (BW / 2) + i * 16 + fq * 4;
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -198,15 +221,20 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     if (epilogue == SCULPT_EPI_GEGLU) {
         SC_REQUIRE(N % 64 == 0, "gemm_bf16(GEGLU): N=%d must be a multiple of 64", N);
         SC_REQUIRE(!residual && !out_bf16_t, "gemm_bf16(GEGLU): residual/transposed output unsupported");
-        hipLaunchKernelGGL(gemm_bf16_kernel<SCULPT_EPI_GEGLU>, dim3(N / 64, mt), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GEGLU, 128>), dim3(N / 64, mt), dim3(256), 0, st, g);
     } else {
         SC_REQUIRE(N % 128 == 0, "gemm_bf16: N=%d must be a multiple of 128", N);
-        if (epilogue == SCULPT_EPI_GELU)
-            hipLaunchKernelGGL(gemm_bf16_kernel<SCULPT_EPI_GELU>, dim3(N / 128, mt), dim3(256), 0, st, g);
-        else if (epilogue == SCULPT_EPI_NONE)
-            hipLaunchKernelGGL(gemm_bf16_kernel<SCULPT_EPI_NONE>, dim3(N / 128, mt), dim3(256), 0, st, g);
-        else
+        // fill the chip: with fewer than ~1.5 tiles per CU use the 64-row weight tile
+        const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
+        if (epilogue == SCULPT_EPI_GELU) {
+            if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 64>), dim3(N / 64, mt), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 128>), dim3(N / 128, mt), dim3(256), 0, st, g);
+        } else if (epilogue == SCULPT_EPI_NONE) {
+            if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64>), dim3(N / 64, mt), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128>), dim3(N / 128, mt), dim3(256), 0, st, g);
+        } else {
             SC_REQUIRE(false, "gemm_bf16: unknown epilogue %d", epilogue);
+        }
     }
     SC_LAUNCH_CHECK();
     return 0;

@@ -377,7 +377,7 @@ struct McHeader {            // first 64 bytes of the workspace
 
 __global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(const float *__restrict__ vol, Grid g, double level,
                                                             int classic, int *__restrict__ block_counts,
-                                                            McHeader *__restrict__ hdr) {
+                                                            float2 *__restrict__ block_minmax) {
     const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
     int packed = 0;
     float mn = FLT_MAX, mx = -FLT_MAX;
@@ -429,23 +429,30 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(const float *__restr
             mx = fmaxf(mx, s_mx[w]);
         }
         block_counts[blockIdx.x] = tot;
-        atomicMin(&hdr->min_ord, f2ord(mn));
-        atomicMax(&hdr->max_ord, f2ord(mx));
+        block_minmax[blockIdx.x] = make_float2(mn, mx);  // reduced by the scan kernel (no contended atomics)
     }
 }
 
 // single-workgroup exclusive scan of packed block counts -> separate tri/vert offsets
-__global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ block_counts, int nblocks,
+__global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ block_counts,
+                                                       const float2 *__restrict__ block_minmax, int nblocks,
                                                        unsigned *__restrict__ tri_ofs, unsigned *__restrict__ vert_ofs,
                                                        McHeader *__restrict__ hdr) {
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long carry_s;
+    __shared__ float s_mn[16], s_mx[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
+    float mn = FLT_MAX, mx = -FLT_MAX;
     for (int base = 0; base < nblocks; base += 1024) {
         const int i = base + threadIdx.x;
         const int pk = i < nblocks ? block_counts[i] : 0;
+        if (i < nblocks) {
+            const float2 mm = block_minmax[i];
+            mn = fminf(mn, mm.x);
+            mx = fmaxf(mx, mm.y);
+        }
         // 64-bit packed (tri low 32, vert high 32) so totals cannot overflow
         const unsigned long long val = (unsigned long long)(pk & 0xffff) | ((unsigned long long)(pk >> 16) << 32);
         unsigned long long inc = val;
@@ -470,9 +477,19 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ b
         if (threadIdx.x == 0) carry_s += tot;
         __syncthreads();
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, d, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
         hdr->total_tri = carry_s & 0xffffffffull;
         hdr->total_vert = carry_s >> 32;
+        hdr->min_ord = f2ord(mn);
+        hdr->max_ord = f2ord(mx);
     }
 }
 
@@ -634,7 +651,7 @@ static int make_grid(int n0, int n1, int n2, Grid *g) {
 }
 
 struct WsLayout {
-    size_t off_counts, off_tri, off_vert, off_map, total;
+    size_t off_counts, off_minmax, off_tri, off_vert, off_map, total;
     int nblocks;
 };
 static WsLayout ws_layout(const Grid &g) {
@@ -643,6 +660,7 @@ static WsLayout ws_layout(const Grid &g) {
     size_t o = 64;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     w.off_counts = o; o = al(o + sizeof(int) * w.nblocks);
+    w.off_minmax = o; o = al(o + sizeof(float2) * w.nblocks);
     w.off_tri = o;    o = al(o + sizeof(unsigned) * w.nblocks);
     w.off_vert = o;   o = al(o + sizeof(unsigned) * w.nblocks);
     w.off_map = o;    o = al(o + sizeof(int) * 3 * (size_t)g.n0 * g.n1 * g.n2);
@@ -679,10 +697,10 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsig
     SC_HIP(hipMemcpyAsync(hdr, &init, sizeof(init), hipMemcpyHostToDevice, st));
     const int classic = (flags & SCULPT_MC_USE_CLASSIC) ? 1 : 0;
     hipLaunchKernelGGL(mc_count_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, classic,
-                       reinterpret_cast<int *>(ws + w.off_counts), hdr);
+                       reinterpret_cast<int *>(ws + w.off_counts), reinterpret_cast<float2 *>(ws + w.off_minmax));
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
-                       w.nblocks, reinterpret_cast<unsigned *>(ws + w.off_tri),
+                       reinterpret_cast<const float2 *>(ws + w.off_minmax), w.nblocks, reinterpret_cast<unsigned *>(ws + w.off_tri),
                        reinterpret_cast<unsigned *>(ws + w.off_vert), hdr);
     SC_LAUNCH_CHECK();
     McHeader res;
