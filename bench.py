@@ -124,14 +124,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # noqa: F811
+    from sculptmate_amd import parallel, synth
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
-    from sculptmate_amd import synth
+    dist = parallel.init("nccl", device) if world > 1 else None
 
     model, sd = build_model(device, seed=0)  # every rank holds a full replica (no weight sharding)
     imgs_np = [synth.composite_rgb(synth.image_rgba(seed=100 + rank * 8 + i)) for i in range(4)]
@@ -155,10 +150,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed, device)
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0:
