@@ -110,16 +110,23 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
 #define SCULPT_MC_FACES_I64 1u
 #define SCULPT_MC_REFERENCE_ORDER 2u
 #define SCULPT_MC_USE_CLASSIC 4u
+/* slab mode (512^3 split along axis 0): SLAB = do not fail on an empty slab;
+ * SLAB_HALO_LOW = lattice plane 0 is the previous slab's last plane: its x/y-edge vertices are owned
+ * there, faces reference them as -(1 + axis*n1*n2 + i1*n2 + i2) and are resolved after the gather
+ * through the previous slab's top_plane_map (int32 [2][n1][n2], -1 = no vertex). */
+#define SCULPT_MC_SLAB 8u
+#define SCULPT_MC_SLAB_HALO_LOW 16u
 #define SCULPT_ERR_MC_LEVEL 11
 #define SCULPT_ERR_MC_EMPTY 12
 
 size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2);
 int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsigned flags,
                     void *workspace, int64_t *n_verts_host, int64_t *n_faces_host,
-                    sculpt_stream_t stream);
+                    float *minmax_host /* [2] data min,max or NULL */, sculpt_stream_t stream);
 int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsigned flags,
                    void *workspace, float vert_div, float vert_mul, float vert_add,
-                   float *verts, void *faces, sculpt_stream_t stream);
+                   int axis0_offset /* slab: global index of lattice plane 0 */,
+                   float *verts, void *faces, int *top_plane_map /* or NULL */, sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Transformer primitives (bf16 storage, fp32 accumulate).  bf16 values are uint16_t bit patterns.

@@ -42,8 +42,8 @@ SIGNATURES = {
     "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sculpt_mc_count": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _pi64, _pi64, _vp]),
-    "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _f, _f, _f, _vp, _vp, _vp]),
+    "sculpt_mc_count": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _pi64, _pi64, _vp, _vp]),
+    "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sculpt_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp]),
@@ -63,6 +63,8 @@ for _name, (_res, _args) in SIGNATURES.items():
 MC_FACES_I64 = 1
 MC_REFERENCE_ORDER = 2
 MC_USE_CLASSIC = 4
+MC_SLAB = 8
+MC_SLAB_HALO_LOW = 16
 ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
 EPI_NONE, EPI_GELU, EPI_GEGLU = 0, 1, 2

@@ -261,6 +261,8 @@ struct Grid {
     int n0, n1, n2;   // voxels
     int c0, c1, c2;   // cells
     long ncells;
+    int halo_low;     // slab mode: lattice plane 0 belongs to the previous slab (its x/y edges are not owned here)
+    int z_off;        // slab mode: global index of this slab's lattice plane 0 (added to axis-0 coordinates)
 };
 
 __device__ __forceinline__ void load_cell(const float *__restrict__ vol, const Grid &g, int z, int y, int x,
@@ -278,7 +280,8 @@ __device__ __forceinline__ void load_cell(const float *__restrict__ vol, const G
 }
 
 // does cell (x,y,z) own edge e (is it the first cell, in sweep order, that touches it)?
-__device__ __forceinline__ bool owns_edge(int e, int x, int y, int z) {
+__device__ __forceinline__ bool owns_edge(int e, int x, int y, int z, int halo_low) {
+    if (halo_low && z == 0 && e < 4) return false;  // owned by the last cell layer of the previous slab
     switch (e) {
         case 0: return y == 0 && z == 0;
         case 1: return z == 0;
@@ -319,7 +322,7 @@ __device__ __forceinline__ long edge_slot(int e, int x, int y, int z, const Grid
 }
 
 // number of triangles / owned vertices of a classified cell, packed (ntri | nown << 16)
-__device__ int cell_counts(const Tiling &t, int x, int y, int z) {
+__device__ int cell_counts(const Tiling &t, int x, int y, int z, int halo_low) {
     if (t.len == 0) return 0;
     unsigned seen = 0;
     int nown = 0;
@@ -327,7 +330,7 @@ __device__ int cell_counts(const Tiling &t, int x, int y, int z) {
         const int e = tiling_entry(t, i);
         if (!(seen >> e & 1u)) {
             seen |= 1u << e;
-            nown += owns_edge(e, x, y, z) ? 1 : 0;
+            nown += owns_edge(e, x, y, z, halo_low) ? 1 : 0;
         }
     }
     return (t.len / 3) | (nown << 16);
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(const float *__restr
         }
         if (any) {
             Tiling t = classify(v, classic != 0);
-            packed = cell_counts(t, x, y, z);
+            packed = cell_counts(t, x, y, z, g.halo_low);
         }
     }
     // block reduce counts and min/max
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
         for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
         if (idx != 0 && idx != 255) {
             t = classify(v, classic != 0);
-            nown = cell_counts(t, x, y, z) >> 16;
+            nown = cell_counts(t, x, y, z, g.halo_low) >> 16;
         }
     }
     int total;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
         const int e = tiling_entry(t, i);
         if (seen >> e & 1u) continue;
         seen |= 1u << e;
-        if (!owns_edge(e, x, y, z)) continue;
+        if (!owns_edge(e, x, y, z, g.halo_low)) continue;
         double px, py, pz;  // skimage's internal (x,y,z) = (axis2, axis1, axis0)
         if (e == 12) {
             // centre vertex: inverse-|value| weighted mean of the 8 corners, summed in corner order
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
             const double fz = ((w[4] + w[5]) + w[6]) + w[7];
             px = (double)x + fx / ff;
             py = (double)y + fy / ff;
-            pz = (double)z + fz / ff;
+            pz = (double)(z + g.z_off) + fz / ff;
         } else {
             // corner pairs (near = lower lattice coordinate along the edge axis, far = near+1)
             int cn, cf, lx = x, ly = y, lz = z, axis;
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
             // cell origin + (1.0 or fr): the off-axis offsets are exactly 0.0 or 1.0
             px = (axis == 0) ? (double)x + fr : (double)lx;
             py = (axis == 1) ? (double)y + fr : (double)ly;
-            pz = (axis == 2) ? (double)z + fr : (double)lz;
+            pz = (axis == 2) ? (double)(z + g.z_off) + fr : (double)(lz + g.z_off);
             edge_map[edge_slot(e, x, y, z, g)] = (int)id;
         }
         // output columns (axis0, axis1, axis2) = (z, y, x): skimage's fliplr of its (x,y,z)
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restr
         for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
         if (idx != 0 && idx != 255) {
             t = classify(v, classic != 0);
-            packed = cell_counts(t, x, y, z);
+            packed = cell_counts(t, x, y, z, g.halo_low);
         }
     }
     int total;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restr
             if (seen >> e & 1u) continue;
             seen |= 1u << e;
             if (e == 12) { centre_id = (int)vown0 + rank; break; }
-            rank += owns_edge(e, x, y, z) ? 1 : 0;
+            rank += owns_edge(e, x, y, z, g.halo_low) ? 1 : 0;
         }
     }
     const int ntri = t.len / 3;
@@ -632,7 +635,13 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restr
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int e = tiling_entry(t, 3 * k + j);
-            id[j] = (e == 12) ? centre_id : edge_map[edge_slot(e, x, y, z, g)];
+            if (e == 12) id[j] = centre_id;
+            else if (g.halo_low && z == 0 && e < 4) {
+                // vertex lives in the previous slab: encode the edge of lattice plane 0 as -(1 + slot),
+                // slot = axis*(n1*n2) + ly*n2 + lx; resolved after the gather (sculptmate_amd/slab.py)
+                const int axis = e & 1, lx = x + (e == 1), ly = y + (e == 2);
+                id[j] = -(1 + axis * g.n1 * g.n2 + ly * g.n2 + lx);
+            } else id[j] = edge_map[edge_slot(e, x, y, z, g)];
         }
         // internal (a,b,c); skimage 'descent' flips to (c,b,a); the reference then takes [1,0,2] -> (b,c,a)
         IdxT *f = faces + 3 * (size_t)(tri0 + k);
@@ -641,11 +650,31 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restr
     }
 }
 
+// lattice-edge -> vertex-id map of the LAST lattice plane (x and y edges), -1 where the edge has no crossing
+__global__ __launch_bounds__(256) void mc_top_plane_kernel(const float *__restrict__ vol, Grid g, double level,
+                                                           const int *__restrict__ edge_map, int *__restrict__ out) {
+    const int plane = g.n1 * g.n2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * plane) return;
+    const int axis = i / plane, rem = i % plane, ly = rem / g.n2, lx = rem % g.n2;
+    const int lz = g.n0 - 1;
+    const int lx2 = lx + (axis == 0), ly2 = ly + (axis == 1);
+    int v = -1;
+    if (lx2 < g.n2 && ly2 < g.n1) {
+        const float *p = vol + (long)lz * plane;
+        const bool a = ((double)p[ly * g.n2 + lx] - level) > 0.0, b = ((double)p[ly2 * g.n2 + lx2] - level) > 0.0;
+        if (a != b) v = edge_map[(long)axis * g.n0 * plane + (long)lz * plane + ly * g.n2 + lx];
+    }
+    out[i] = v;
+}
+
 static int make_grid(int n0, int n1, int n2, Grid *g) {
     SC_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "marching_cubes: input array must be at least 2x2x2");
     g->n0 = n0; g->n1 = n1; g->n2 = n2;
     g->c0 = n0 - 1; g->c1 = n1 - 1; g->c2 = n2 - 1;
     g->ncells = (long)g->c0 * g->c1 * g->c2;
+    g->halo_low = 0;
+    g->z_off = 0;
     SC_REQUIRE(g->ncells / MC_BLOCK < 0x7fffffffL, "marching_cubes: volume too large");
     return 0;
 }
@@ -681,10 +710,11 @@ size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2) {
 }
 
 int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsigned flags, void *workspace,
-                    int64_t *n_verts_host, int64_t *n_faces_host, sculpt_stream_t stream) {
+                    int64_t *n_verts_host, int64_t *n_faces_host, float *minmax_host, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     Grid g;
     if (int rc = make_grid(n0, n1, n2, &g)) return rc;
+    g.halo_low = (flags & SCULPT_MC_SLAB_HALO_LOW) ? 1 : 0;
     SC_REQUIRE(vol && workspace && n_verts_host && n_faces_host, "mc_count: null argument");
     if (int rc = upload_tables()) return rc;
     const WsLayout w = ws_layout(g);
@@ -710,6 +740,8 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsig
     *n_faces_host = (int64_t)res.total_tri;
     // skimage: "Surface level must be within volume data range." (ValueError)
     const float mn = ord2f(res.min_ord), mx = ord2f(res.max_ord);
+    if (minmax_host) { minmax_host[0] = mn; minmax_host[1] = mx; }
+    if (flags & SCULPT_MC_SLAB) return 0;  // a slab may be empty; the caller decides globally
     if ((double)level < (double)mn || (double)level > (double)mx) {
         set_error("Surface level must be within volume data range.");
         return SCULPT_ERR_MC_LEVEL;
@@ -723,11 +755,13 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsig
 }
 
 int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsigned flags, void *workspace,
-                   float vert_div, float vert_mul, float vert_add, float *verts, void *faces,
-                   sculpt_stream_t stream) {
+                   float vert_div, float vert_mul, float vert_add, int axis0_offset, float *verts, void *faces,
+                   int *top_plane_map, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     Grid g;
     if (int rc = make_grid(n0, n1, n2, &g)) return rc;
+    g.halo_low = (flags & SCULPT_MC_SLAB_HALO_LOW) ? 1 : 0;
+    g.z_off = axis0_offset;
     SC_REQUIRE(vol && workspace && verts && faces, "mc_emit: null argument");
     const WsLayout w = ws_layout(g);
     char *ws = reinterpret_cast<char *>(workspace);
@@ -746,6 +780,11 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsign
         hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level,
                            classic, tri, vrt, emap, reinterpret_cast<int *>(faces), ref);
     SC_LAUNCH_CHECK();
+    if (top_plane_map) {
+        hipLaunchKernelGGL(mc_top_plane_kernel, dim3(cdiv(2L * n1 * n2, 256)), dim3(256), 0, st, vol, g, (double)level,
+                           emap, top_plane_map);
+        SC_LAUNCH_CHECK();
+    }
     return 0;
 }
 

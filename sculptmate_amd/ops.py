@@ -130,13 +130,15 @@ def _axis_table(R, radius, device):
 # marching cubes
 # ----------------------------------------------------------------------------------------------
 def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul=1.0, vert_add=0.0,
-                   use_classic=False):
+                   use_classic=False, slab=None):
     """skimage.measure.marching_cubes(vol, level) on the GPU.
 
     reference_order=False: (verts f32[nv,3] voxel units, faces i32[nf,3]) exactly as skimage returns.
     reference_order=True : faces int64 with columns [1,0,2] and verts/(vert_div)*vert_mul+vert_add
                            (MarchingCubeHelper.forward + scale_tensor, isosurface.py:49-53, system.py:185-189).
     Raises ValueError / RuntimeError like skimage for an out-of-range level / empty surface.
+    slab=dict(axis0_offset=int, halo_low=bool): slab mode for the axis-0 split (sculptmate_amd/slab.py);
+        returns (verts, faces, top_plane_map int32[2,n1,n2], (min, max)) and never raises on an empty slab.
     """
     vol = _req(vol, torch.float32, "vol")
     assert vol.dim() == 3
@@ -147,9 +149,16 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
         flags |= _lib.MC_REFERENCE_ORDER | _lib.MC_FACES_I64
     if use_classic:
         flags |= _lib.MC_USE_CLASSIC
+    off = 0
+    if slab is not None:
+        flags |= _lib.MC_SLAB
+        if slab.get("halo_low"):
+            flags |= _lib.MC_SLAB_HALO_LOW
+        off = int(slab.get("axis0_offset", 0))
     nv, nf = ctypes.c_int64(), ctypes.c_int64()
+    mm = (ctypes.c_float * 2)()
     rc = lib.sculpt_mc_count(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), ctypes.byref(nv),
-                             ctypes.byref(nf), _stream())
+                             ctypes.byref(nf), ctypes.cast(mm, ctypes.c_void_p), _stream())
     if rc == _lib.ERR_MC_LEVEL:
         raise ValueError(_lib.last_error())
     if rc == _lib.ERR_MC_EMPTY:
@@ -157,8 +166,15 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     check(rc)
     verts = torch.empty((nv.value, 3), dtype=torch.float32, device=vol.device)
     faces = torch.empty((nf.value, 3), dtype=torch.int64 if reference_order else torch.int32, device=vol.device)
-    check(lib.sculpt_mc_emit(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), float(vert_div),
-                             float(vert_mul), float(vert_add), _ptr(verts), _ptr(faces), _stream()))
+    top = torch.empty((2, n1, n2), dtype=torch.int32, device=vol.device) if slab is not None else None
+    if nv.value > 0 or slab is not None:
+        # dummy non-null pointers for empty outputs
+        vp = verts if nv.value else torch.empty(3, device=vol.device)
+        fp = faces if nf.value else torch.empty(3, dtype=faces.dtype, device=vol.device)
+        check(lib.sculpt_mc_emit(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), float(vert_div),
+                                 float(vert_mul), float(vert_add), off, _ptr(vp), _ptr(fp), _ptr(top), _stream()))
+    if slab is not None:
+        return verts, faces, top, (float(mm[0]), float(mm[1]))
     return verts, faces
 
 

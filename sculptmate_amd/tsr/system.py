@@ -385,6 +385,28 @@ class TSR:
             out.append(Mesh(v_pos, t_pos_idx, color))
         return out
 
+    def extract_mesh_sharded(self, scene_code, resolution: int = 512, threshold: float = 25.0, enable_texture=False):
+        """BASELINE config 5: the voxel grid of ONE image split into slabs along the slowest lattice axis over
+        the ranks of the default process group (RCCL over xGMI), one padded all-gather of the per-slab
+        triangles, identical result on every rank and identical to the single-GPU mesh
+        (sculptmate_amd/slab.py).  Without a process group the slabs run one after the other here."""
+        import torch.distributed as dist
+
+        from .. import slab
+
+        r = self.renderer.cfg.radius
+        planes = scene_code.contiguous()
+        kw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, threshold=threshold)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            part = slab.extract_slab(planes, self.decoder, resolution, dist.get_rank(), dist.get_world_size(), **kw)
+            v_pos, t_pos_idx = slab.gather_and_assemble(part, planes.device)
+        else:
+            v_pos, t_pos_idx = slab.extract_mesh_slabs_local(planes, self.decoder, resolution, 1, **kw)
+        color = None
+        if enable_texture:
+            color = self.renderer.query_triplane(self.decoder, v_pos, planes)["color"]
+        return Mesh(v_pos, t_pos_idx, color)
+
     def extract_mesh(self, scene_codes, enable_texture=False, mesh_name="NewMesh", resolution: int = 256,
                      threshold: float = 25.0):
         """system.py:171-200: same signature; pushes each mesh into the sink (Blender when `bpy` is
