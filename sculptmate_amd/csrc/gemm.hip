@@ -14,8 +14,9 @@
 // tile the B operand, so a lane ends up holding 4 consecutive output columns n of one row m: bias /
 // GEGLU / residual are per-lane vector ops and the store is one 16-byte (fp32) or 8-byte (bf16) write.
 // Both operands are K-contiguous in HBM = the fragment shape (8 consecutive k per lane).
-// Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), double-buffered, next K-tile
-// issued before the MFMA block of the current one; one barrier per K-tile.  The LDS image is
+// Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 3-stage LDS ring with two
+// K-tiles in flight (counted s_waitcnt vmcnt + raw s_barrier, one barrier per K-tile): these GEMMs are
+// small (M <= 3072, ~1.5 workgroups per CU), so the load latency has to be hidden inside the workgroup.  The LDS image is
 // lane-linear per wave instruction (8 rows x 128 B); the (row>>1)&7 chunk XOR that makes every
 // ds_read_b128 lane group cover all 64 banks is applied to the per-lane SOURCE address and to the
 // read address (guide rule 21).
@@ -32,7 +33,21 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 static constexpr int BM = 128;   // activation rows per block
 static constexpr int BK = 64;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU(erf).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, below fp32 noise of the GEMM that
+// feeds it): ~12 VALU + v_exp + v_rcp instead of libm erff's ~50 instructions -- the GEGLU epilogue
+// evaluates 32 of these per thread and was ~30 % of the FF1 kernel.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+    const float r = 1.0f - p * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 // byte offset of 16-byte chunk c (0..7) of row r in a [rows][64 bf16] LDS tile
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -52,7 +67,12 @@ template <int EPI, int BW>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int WT = BW * 128;  // bytes of a weight tile
     constexpr int AT = BM * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (WT + AT)];  // [buf][W | A]
+    // LDS ring depth: 3 stages (two K-tiles in flight) for the 64-row tile, 2 for the 128-row tile --
+    // either way 64-72 KiB, i.e. two workgroups per CU (a third stage at 96 KiB measured slower: one
+    // workgroup per CU leaves the epilogue and the ramp-up uncovered).
+    constexpr int NSTAGE = (BW == 64) ? 3 : 2;
+    constexpr int DIST = NSTAGE - 1;  // prefetch distance in K-tiles
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * (WT + AT)];  // [stage][W | A]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -122,11 +142,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) boff[j] = lds_off(wc * 64 + j * 16 + fr, fq);
 
+    // 3-stage ring, two K-tiles in flight: wait for tile kt only (counted vmcnt), one raw barrier per
+    // K-tile (a __syncthreads() here would drain the LDS-DMA queue: guide "Pipelining across barriers").
+    constexpr int LPT = WI + 4;  // LDS-DMA instructions per thread per K-tile
     STAGE(0, 0);
-    __syncthreads();  // emits vmcnt(0) for the LDS-DMA in flight
+    if (DIST > 1 && nk > 1) STAGE(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) STAGE(buf ^ 1, kt + 1);
+        const int buf = kt % NSTAGE;
+        // wait until tile kt has landed; tiles kt+1 .. kt+DIST-1 (if issued) stay in flight
+        if (DIST > 1 && kt + 1 < nk) {
+            if (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // every wave finished reading stage (kt-1)%NSTAGE == (kt+DIST)%NSTAGE before it passed the barrier
+        if (kt + DIST < nk) STAGE((kt + DIST) % NSTAGE, kt + DIST);
         const unsigned char *wb = smem + buf * (WT + AT);
         const unsigned char *ab = wb + WT;
 #pragma unroll
@@ -142,7 +174,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
 #undef STAGE
 
