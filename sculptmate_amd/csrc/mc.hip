@@ -279,6 +279,19 @@ __device__ __forceinline__ void load_cell(const float *__restrict__ vol, const G
     v[7] = (double)p[sz + sy] - level;
 }
 
+// Workgroup -> cells: a workgroup covers up to 256 consecutive x of ONE (z,y) row, so the cell
+// coordinates need one scalar division per workgroup instead of three 64-bit divisions per thread, the
+// corner loads of a wave are contiguous, and workgroup order == cell order (needed by the scans).
+__device__ __forceinline__ bool cell_of_block(const Grid &g, int &x, int &y, int &z) {
+    const int bpr = (g.c2 + MC_BLOCK - 1) / MC_BLOCK;          // workgroups per row
+    const unsigned row = blockIdx.x / (unsigned)bpr;             // wave-uniform
+    const int seg = (int)(blockIdx.x - row * (unsigned)bpr);
+    x = seg * MC_BLOCK + (int)threadIdx.x;
+    y = (int)(row % (unsigned)g.c1);
+    z = (int)(row / (unsigned)g.c1);
+    return x < g.c2;
+}
+
 // does cell (x,y,z) own edge e (is it the first cell, in sweep order, that touches it)?
 __device__ __forceinline__ bool owns_edge(int e, int x, int y, int z, int halo_low) {
     if (halo_low && z == 0 && e < 4) return false;  // owned by the last cell layer of the previous slab
@@ -381,11 +394,10 @@ struct McHeader {            // first 64 bytes of the workspace
 __global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(const float *__restrict__ vol, Grid g, double level,
                                                             int classic, int *__restrict__ block_counts,
                                                             float2 *__restrict__ block_minmax) {
-    const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
     int packed = 0;
     float mn = FLT_MAX, mx = -FLT_MAX;
-    if (c < g.ncells) {
-        const int x = (int)(c % g.c2), y = (int)((c / g.c2) % g.c1), z = (int)(c / ((long)g.c2 * g.c1));
+    int x, y, z;
+    if (cell_of_block(g, x, y, z)) {
         double v[8];
         load_cell(vol, g, z, y, x, level, v);
         {
@@ -507,14 +519,12 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
                                                             int classic, const unsigned *__restrict__ vert_ofs,
                                                             int *__restrict__ edge_map, float *__restrict__ verts,
                                                             float vdiv, float vmul, float vadd, int affine) {
-    const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
     int x = 0, y = 0, z = 0;
     double v[8];
     Tiling t;
     t.ofs = 0; t.len = 0;
     int nown = 0;
-    if (c < g.ncells) {
-        x = (int)(c % g.c2); y = (int)((c / g.c2) % g.c1); z = (int)(c / ((long)g.c2 * g.c1));
+    if (cell_of_block(g, x, y, z)) {
         load_cell(vol, g, z, y, x, level, v);
         int idx = 0;
 #pragma unroll
@@ -594,13 +604,11 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restr
                                                             const unsigned *__restrict__ vert_ofs,
                                                             const int *__restrict__ edge_map, IdxT *__restrict__ faces,
                                                             int ref_order) {
-    const long c = (long)blockIdx.x * MC_BLOCK + threadIdx.x;
     int x = 0, y = 0, z = 0;
     Tiling t;
     t.ofs = 0; t.len = 0;
     int packed = 0;
-    if (c < g.ncells) {
-        x = (int)(c % g.c2); y = (int)((c / g.c2) % g.c1); z = (int)(c / ((long)g.c2 * g.c1));
+    if (cell_of_block(g, x, y, z)) {
         double v[8];
         load_cell(vol, g, z, y, x, level, v);
         int idx = 0;
@@ -675,7 +683,7 @@ static int make_grid(int n0, int n1, int n2, Grid *g) {
     g->ncells = (long)g->c0 * g->c1 * g->c2;
     g->halo_low = 0;
     g->z_off = 0;
-    SC_REQUIRE(g->ncells / MC_BLOCK < 0x7fffffffL, "marching_cubes: volume too large");
+    SC_REQUIRE((long)g->c0 * g->c1 * cdiv(g->c2, MC_BLOCK) < 0x7fffffffL, "marching_cubes: volume too large");
     return 0;
 }
 
@@ -685,7 +693,7 @@ struct WsLayout {
 };
 static WsLayout ws_layout(const Grid &g) {
     WsLayout w;
-    w.nblocks = cdiv(g.ncells, MC_BLOCK);
+    w.nblocks = g.c0 * g.c1 * cdiv(g.c2, MC_BLOCK);
     size_t o = 64;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     w.off_counts = o; o = al(o + sizeof(int) * w.nblocks);

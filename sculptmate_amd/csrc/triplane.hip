@@ -18,6 +18,7 @@
 //     evaluated once per lattice *pair* and plane (plane_features_kernel) and the per-point
 //     layer-0 pre-activation is the sum of three table rows.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -346,7 +347,8 @@ __device__ __forceinline__ void load_row32(const float *row, f32x16 &a, f32x16 &
     }
 }
 
-__global__ __launch_bounds__(512) void density_grid_kernel(
+template <int NT>
+__global__ __launch_bounds__(NT) void density_grid_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
     const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -501,11 +503,19 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
     const float *FA = reinterpret_cast<const float *>(workspace);
     const float *FB = FA + (size_t)nx * R * 64;
     const float *FC = FB + (size_t)nx * R * 64;
-    SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
-    const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
-    hipLaunchKernelGGL(density_grid_kernel, dim3(grid), dim3(512), lds, st,
-                       reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out);
+    static int nthreads = getenv("SCULPT_DENSITY_THREADS") ? atoi(getenv("SCULPT_DENSITY_THREADS")) : 1024;
+    if (nthreads == 1024) {
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
+        hipLaunchKernelGGL(density_grid_kernel<1024>, dim3(grid), dim3(1024), lds, st,
+                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out);
+    } else {
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
+        hipLaunchKernelGGL(density_grid_kernel<512>, dim3(grid), dim3(512), lds, st,
+                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out);
+    }
     SC_LAUNCH_CHECK();
     return 0;
 }
