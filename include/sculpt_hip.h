@@ -183,6 +183,24 @@ int sculpt_vit_assemble(const float *patch_out, const float *cls, const float *p
 int sculpt_upsample_scatter(const float *g, int ldg, const float *bias, float *planes, int S, int Co,
                             sculpt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * UV-space texture baker (StableFast "next" row).  Replaces the exports of
+ * StableFast/sf3d/texture_baker/texture_baker.dll (ABI declared at baker.py:31-57, 91-118; semantics
+ * restated in common.py:104-142, 214-229): pixel (x,y) samples (x/res, 1 - y/res); rast = (u,v,w,tri) or
+ * (0,0,0,-1); where several triangles cover a sample the LOWEST index wins.
+ * ------------------------------------------------------------------------------------------ */
+size_t sculpt_bake_workspace_bytes(int res);
+/* uv f32 [nv][2], idx i32 [nf][3] (DEVICE), out f32 [res][res][4] */
+int sculpt_bake_rasterize(const float *uv, size_t nv, const int *idx, size_t nf, int res, void *workspace,
+                          float *out, sculpt_stream_t stream);
+/* attr f32 [nv][3], rast f32 [res][res][4] (DEVICE) -> out f32 [res][res][3] */
+int sculpt_bake_interpolate(const float *attr, size_t nv, const int *idx, size_t nf, const float *rast, int res,
+                            float *out, sculpt_stream_t stream);
+/* The DLL's own entry points (HOST pointers, same names/signatures as baker.py declares): */
+void rasterize_cpu(const float *uv, size_t nv, const int *idx, size_t nf, long long res, float *out);
+void interpolate_cpu(const float *attr, size_t nv, const int *idx, size_t nf, const float *rast, long long res,
+                     float *out);
+
 /* fp32 -> bf16 (round to nearest even), n elements */
 int sculpt_cast_bf16(const float *x, uint16_t *y, int64_t n, sculpt_stream_t stream);
 

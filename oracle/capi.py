@@ -15,7 +15,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("mc_lewiner.c", "triplane_query.c", "mc_luts.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("mc_lewiner.c", "triplane_query.c", "baker.c", "mc_luts.h", "Makefile")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -49,6 +49,10 @@ def lib():
         L.oracle_density_grid.restype = None
         L.oracle_grid_point.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
         L.oracle_grid_point.restype = None
+        L.oracle_bake_rasterize.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_bake_rasterize.restype = None
+        L.oracle_bake_interpolate.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_bake_interpolate.restype = None
         L.oracle_set_threads.argtypes = [ctypes.c_int]
         L.oracle_max_threads.restype = ctypes.c_int
         _lib = L
@@ -140,4 +144,21 @@ def grid_points(R, radius=0.87, idx=None):
     for j, i in enumerate(idx):
         L.oracle_grid_point(int(i), R, radius, tmp.ctypes.data)
         out[j] = tmp
+    return out
+
+
+def bake_rasterize(uv, faces, res):
+    """rasterize_cpu (texture_baker/common.py:123-142) -> f32 [res, res, 4] (u, v, w, triangle id | -1)."""
+    uv = np.ascontiguousarray(uv, np.float32); faces = np.ascontiguousarray(faces, np.int32)
+    out = np.empty((res, res, 4), np.float32)
+    lib().oracle_bake_rasterize(uv.ctypes.data, uv.shape[0], faces.ctypes.data, faces.shape[0], res, out.ctypes.data)
+    return out
+
+
+def bake_interpolate(attr, faces, rast):
+    """interpolate_cpu (texture_baker/common.py:214-229) -> f32 [res, res, 3]."""
+    attr = np.ascontiguousarray(attr, np.float32); faces = np.ascontiguousarray(faces, np.int32)
+    rast = np.ascontiguousarray(rast, np.float32)
+    out = np.empty(rast.shape[:2] + (3,), np.float32)
+    lib().oracle_bake_interpolate(attr.ctypes.data, faces.ctypes.data, rast.ctypes.data, rast.shape[0], out.ctypes.data)
     return out

@@ -244,3 +244,28 @@ def upsample_scatter(g, bias, planes, S, Co):
 
 def cast_bf16(x, y):
     check(lib.sculpt_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()))
+
+
+# ----------------------------------------------------------------------------------------------
+# UV-space texture baker (StableFast)
+# ----------------------------------------------------------------------------------------------
+def bake_rasterize(uv, face_indices, bake_resolution):
+    """TextureBaker.rasterize (sf3d/texture_baker/baker.py:12-59) on the GPU -> f32 [res, res, 4]."""
+    uv = _req(uv.contiguous(), torch.float32, "uv")
+    idx = _req(face_indices.to(torch.int32).contiguous(), torch.int32, "face_indices")
+    res = int(bake_resolution)
+    ws = _workspace(("bake", uv.device), lib.sculpt_bake_workspace_bytes(res), uv.device)
+    out = torch.empty((res, res, 4), dtype=torch.float32, device=uv.device)
+    check(lib.sculpt_bake_rasterize(_ptr(uv), uv.shape[0], _ptr(idx), idx.shape[0], res, _ptr(ws), _ptr(out), _stream()))
+    return out
+
+
+def bake_interpolate(attr, rast, face_indices):
+    """TextureBaker.interpolate (baker.py:71-120) on the GPU -> f32 [res, res, 3]."""
+    attr = _req(attr.contiguous(), torch.float32, "attr")
+    rast = _req(rast.contiguous(), torch.float32, "rast")
+    idx = _req(face_indices.to(torch.int32).contiguous(), torch.int32, "face_indices")
+    res = rast.shape[0]
+    out = torch.empty((res, res, 3), dtype=torch.float32, device=attr.device)
+    check(lib.sculpt_bake_interpolate(_ptr(attr), attr.shape[0], _ptr(idx), idx.shape[0], _ptr(rast), res, _ptr(out), _stream()))
+    return out

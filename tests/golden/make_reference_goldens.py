@@ -204,6 +204,42 @@ def make_preproc():
     print("preproc:", y.shape)
 
 
+def uv_test_mesh(seed=0, n=9):
+    """A non-overlapping UV layout: jittered (n x n) vertex grid over [0.06, 0.94]^2, two triangles per quad,
+    alternating diagonals; plus per-vertex 3-vectors to interpolate."""
+    rng = np.random.default_rng(seed)
+    g = np.linspace(0.06, 0.94, n)
+    u, v = np.meshgrid(g, g, indexing="ij")
+    uv = np.stack([u, v], -1).astype(np.float64)
+    uv[1:-1, 1:-1] += (rng.random((n - 2, n - 2, 2)) - 0.5) * 0.04
+    uv = uv.reshape(-1, 2).astype(np.float32)
+    faces = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            a, b, c, d = i * n + j, (i + 1) * n + j, (i + 1) * n + j + 1, i * n + j + 1
+            faces += [[a, b, c], [a, c, d]] if (i + j) % 2 == 0 else [[a, b, d], [b, c, d]]
+    faces = np.array(faces, np.int32)
+    attr = rng.standard_normal((n * n, 3)).astype(np.float32)
+    return uv, faces, attr
+
+
+def make_baker():
+    """SF3D texture baker semantics from the reference's own Python restatement
+    (StableFast/sf3d/texture_baker/common.py:123-142 rasterize_cpu, :214-229 interpolate_cpu)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("tb_common", "/root/reference/StableFast/sf3d/texture_baker/common.py")
+    tb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tb)
+    uv, faces, attr = uv_test_mesh(seed=0, n=9)
+    res = 40
+    rast = tb.rasterize_cpu(uv, faces, res)
+    inter = tb.interpolate_cpu(attr, faces, rast)
+    np.savez_compressed(os.path.join(HERE, "baker.npz"), uv=uv, faces=faces, attr=attr, rast=rast.astype(np.float32),
+                        inter=inter.astype(np.float32), meta=np.array("common.py rasterize_cpu/interpolate_cpu, res 40, numpy %s" % np.__version__))
+    print("baker:", rast.shape, int((rast[..., 3] >= 0).sum()), "covered pixels")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["query", "grid", "upsample"]
     for w in which:

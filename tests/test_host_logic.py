@@ -102,3 +102,34 @@ def test_scale_tensor_and_renderer_chunk_api():
     r.set_chunk_size(8192)
     with pytest.raises(AssertionError):
         r.set_chunk_size(-1)
+
+
+def _write_checkpoint(dirpath, cfg, seed=5):
+    """A checkpoint directory laid out like the reference's TripoSR/checkpoints (config.yaml, config.json, model.ckpt)."""
+    import json
+
+    import yaml
+
+    sd = synth.tsr_state(seed, cfg)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, os.path.join(dirpath, "model.ckpt"))
+    b, t = cfg["backbone"], cfg["tokenizer"]
+    y = {"cond_image_size": cfg["cond_image_size"], "tokenizer": dict(t),
+         "backbone": {"in_channels": "${tokenizer.num_channels}", "num_attention_heads": b["num_attention_heads"],
+                      "attention_head_dim": b["attention_head_dim"], "num_layers": b["num_layers"],
+                      "cross_attention_dim": b["cross_attention_dim"]},
+         "post_processor": dict(cfg["post_processor"]), "decoder": dict(cfg["decoder"]), "renderer": dict(cfg["renderer"])}
+    with open(os.path.join(dirpath, "config.yaml"), "w") as f:
+        yaml.safe_dump(y, f)
+    with open(os.path.join(dirpath, "config.json"), "w") as f:
+        json.dump(cfg["image_tokenizer"], f)
+    return sd
+
+
+def test_from_pretrained_reads_reference_style_checkpoint(tmp_path):
+    from sculptmate_amd.tsr import TSR
+
+    sd = _write_checkpoint(str(tmp_path), SMALL_CFG)
+    m = TSR.from_pretrained(str(tmp_path), config_name="config.yaml", weight_name="model.ckpt")
+    assert param_spec(m.cfg) == param_spec(SMALL_CFG)
+    got = m.state_dict()
+    assert set(got) == set(sd) and all(np.array_equal(got[k].numpy(), sd[k]) for k in sd)
