@@ -170,6 +170,11 @@ int sculpt_groupnorm_tokens(const float *x, int C, int T, int G, const float *ga
 int sculpt_transpose_add(const float *x_tc, const float *residual_ct, float *out_ct, int T, int C,
                          sculpt_stream_t stream);
 
+/* ImagePreprocessor resize (tsr/utils.py:82-88): F.interpolate(bilinear, align_corners=False, antialias=True)
+ * on an HWC fp32 image; tmp = Hin*Wout*C floats of scratch. */
+int sculpt_resize_aa_bilinear(const float *in_hwc, int Hin, int Win, int C, float *tmp, float *out_hwc, int Hout,
+                              int Wout, sculpt_stream_t stream);
+
 /* ViT front end (tokenizers/image.py:48 + HF ViTEmbeddings): normalise (x-mean)/std and cut
  * [3][S][S] fp32 image into patch rows [S/P * S/P][3*P*P] bf16 (conv16/16 stride 16 as a GEMM) */
 int sculpt_vit_patchify(const float *image_hwc, int S, int P, const float *mean3_host, const float *std3_host,

@@ -296,3 +296,66 @@ int sculpt_cast_bf16(const float *x, uint16_t *y, int64_t n, sculpt_stream_t str
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// ImagePreprocessor resize: F.interpolate(bilinear, align_corners=False, antialias=True) on an HWC
+// float image (TripoSR/tsr/utils.py:82-88; the add-on feeds 1024^2, preprocessing.py:126).
+// torch's separable triangle filter: scale = in/out, support = max(scale, 1), centre = scale*(i+0.5),
+// taps [xmin, xmin+xsize), weights max(0, 1 - |(j + xmin - centre + 0.5)/max(scale,1)|) normalised;
+// width pass first, then height pass (fp32 intermediate), like the CPU kernel.
+// ---------------------------------------------------------------------------------------------
+namespace sculpt {
+
+__device__ __forceinline__ void aa_taps(int i, int in_size, float scale, int *xmin, int *xsize, float *support_inv,
+                                        float *center) {
+    const float support = scale >= 1.0f ? scale : 1.0f;
+    *center = scale * ((float)i + 0.5f);
+    *xmin = max(0, (int)(*center - support + 0.5f));
+    *xsize = min(in_size, (int)(*center + support + 0.5f)) - *xmin;
+    *support_inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+}
+
+// dir = 0: resize along x (in [H][Win][C] -> out [H][Wout][C]); dir = 1: along y ([Hin][W][C] -> [Hout][W][C])
+__global__ __launch_bounds__(256) void resize_aa_kernel(const float *__restrict__ in, float *__restrict__ out, int H,
+                                                        int W, int C, int in_size, int out_size, float scale, int dir) {
+    const long total = (long)H * W * C;  // output elements
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int x = (int)((e / C) % W), y = (int)(e / ((long)C * W));
+        const int i = dir == 0 ? x : y;
+        int xmin, xsize;
+        float inv, center;
+        aa_taps(i, in_size, scale, &xmin, &xsize, &inv, &center);
+        float tw = 0.f;
+        for (int j = 0; j < xsize; ++j) {
+            const float t = fabsf(((float)(j + xmin) - center + 0.5f) * inv);
+            tw += t < 1.0f ? 1.0f - t : 0.f;
+        }
+        float acc = 0.f;
+        for (int j = 0; j < xsize; ++j) {
+            const float t = fabsf(((float)(j + xmin) - center + 0.5f) * inv);
+            const float wgt = (t < 1.0f ? 1.0f - t : 0.f) / tw;
+            const long src = dir == 0 ? ((long)y * in_size + (xmin + j)) * C + c : ((long)(xmin + j) * W + x) * C + c;
+            acc += in[src] * wgt;
+        }
+        out[e] = acc;
+    }
+}
+
+}  // namespace sculpt
+
+extern "C" int sculpt_resize_aa_bilinear(const float *in_hwc, int Hin, int Win, int C, float *tmp, float *out_hwc,
+                                         int Hout, int Wout, sculpt_stream_t stream) {
+    using namespace sculpt;
+    SC_REQUIRE(in_hwc && tmp && out_hwc && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0, "resize_aa: bad argument");
+    hipStream_t st = as_stream(stream);
+    // width pass: [Hin][Win][C] -> tmp [Hin][Wout][C]
+    hipLaunchKernelGGL(resize_aa_kernel, dim3(grid_for((long)Hin * Wout * C)), dim3(256), 0, st, in_hwc, tmp, Hin, Wout, C,
+                       Win, Wout, (float)Win / (float)Wout, 0);
+    SC_LAUNCH_CHECK();
+    // height pass: tmp [Hin][Wout][C] -> out [Hout][Wout][C]
+    hipLaunchKernelGGL(resize_aa_kernel, dim3(grid_for((long)Hout * Wout * C)), dim3(256), 0, st, tmp, out_hwc, Hout, Wout, C,
+                       Hin, Hout, (float)Hin / (float)Hout, 1);
+    SC_LAUNCH_CHECK();
+    return 0;
+}

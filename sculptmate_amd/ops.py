@@ -269,3 +269,14 @@ def bake_interpolate(attr, rast, face_indices):
     out = torch.empty((res, res, 3), dtype=torch.float32, device=attr.device)
     check(lib.sculpt_bake_interpolate(_ptr(attr), attr.shape[0], _ptr(idx), idx.shape[0], _ptr(rast), res, _ptr(out), _stream()))
     return out
+
+
+def resize_aa_bilinear(img_hwc, size):
+    """F.interpolate(bilinear, align_corners=False, antialias=True) to (size, size) on an HWC fp32 device image
+    (ImagePreprocessor.convert_and_resize, tsr/utils.py:82-88)."""
+    img = _req(img_hwc.contiguous(), torch.float32, "image")
+    H, W, C = img.shape
+    tmp = torch.empty((H, size, C), dtype=torch.float32, device=img.device)
+    out = torch.empty((size, size, C), dtype=torch.float32, device=img.device)
+    check(lib.sculpt_resize_aa_bilinear(_ptr(img), H, W, C, _ptr(tmp), _ptr(out), size, size, _stream()))
+    return out

@@ -346,12 +346,16 @@ class TSR:
                 self.to(device)
             else:
                 raise _lib.SculptError("TSR: call load_state_dict() and to(device) before forward()")
-        rgb = self.image_processor(image, self.cfg["cond_image_size"])  # [B, S, S, 3] fp32 on the host
-        if rgb.shape[-1] != 3:
-            raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
+        size = self.cfg["cond_image_size"]
         codes = []
-        for i in range(rgb.shape[0]):
-            img = rgb[i].to(self.device, non_blocking=True).contiguous()
+        for im in _as_image_list(image):
+            # ImagePreprocessor (tsr/utils.py:62-112): uint8/PIL -> float/255 on the host, then the
+            # antialiased bilinear resize to cond_image_size -- on the GPU (sculpt_resize_aa_bilinear)
+            img = _to_float_hwc(im).to(self.device, non_blocking=True).contiguous()
+            if img.shape[-1] != 3:
+                raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
+            if img.shape[0] != size or img.shape[1] != size:
+                img = ops.resize_aa_bilinear(img, size)
             ctx, _ = self.image_tokens(img)
             _, outb = self.backbone_tokens(ctx)
             codes.append(self.scene_code(outb))
@@ -426,6 +430,21 @@ class TSR:
             meshes = self.extract_meshes(codes, enable_texture, mc_resolution, threshold)
         return [Mesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(),
                      None if m.vertex_colors is None else m.vertex_colors.cpu().numpy()) for m in meshes]
+
+
+def _as_image_list(image):
+    if isinstance(image, (np.ndarray, torch.Tensor)) and image.ndim == 4:
+        return [image[i] for i in range(image.shape[0])]
+    return image if isinstance(image, (list, tuple)) else [image]
+
+
+def _to_float_hwc(image):
+    """ImagePreprocessor.convert_and_resize's conversion step (tsr/utils.py:68-77), without the resize."""
+    if not isinstance(image, (np.ndarray, torch.Tensor)):  # PIL.Image
+        image = np.array(image)
+    if isinstance(image, np.ndarray):
+        image = torch.from_numpy(image.astype(np.float32) / 255.0) if image.dtype == np.uint8 else torch.from_numpy(image)
+    return image.to(torch.float32)
 
 
 def _default_sink():
