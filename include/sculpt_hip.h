@@ -139,11 +139,13 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsign
  *   A, W bf16 (K contiguous); bias fp32 or NULL; residual fp32 [M][ldr] or NULL;
  *   outputs (any subset, at least one): out_f32 [M][ldo] fp32, out_bf16 [M][ldo] bf16,
  *   out_bf16_t [N][ldt] bf16 = the transposed result (used to hand V^T to the attention kernel).
+ *   n_split (0 or N = off): columns n < n_split go to out_f32/out_bf16 only, columns n >= n_split go to
+ *   out_bf16_t only, at row n - n_split (one launch for a fused [Q|K|V] projection: Q,K token-major, V^T).
  *   lda/ldw/ldo/ldt are row strides in elements.  K % 64 == 0; N % 128 == 0 (GEGLU: W has 2N rows,
  *   N % 64 == 0); any M >= 1 (ragged last tile handled). */
 int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
                      const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
-                     uint16_t *out_bf16_t, int ldt, int M, int N, int K, int epilogue,
+                     uint16_t *out_bf16_t, int ldt, int n_split, int M, int N, int K, int epilogue,
                      sculpt_stream_t stream);
 
 /* softmax(Q K^T * scale) V per head, no mask (attention.py:629-631; HF ViTSelfAttention).

@@ -60,6 +60,7 @@ struct GemmArgs {
     float *out_f32; uint16_t *out_bf16; int ldo;
     uint16_t *out_t; int ldt;
     int M, N, K;
+    int n_split;  // columns >= n_split go ONLY to out_t (row n - n_split); columns < n_split skip out_t
 };
 
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
@@ -216,16 +217,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                     const float4 rs = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n);
                     o[0] += rs.x; o[1] += rs.y; o[2] += rs.z; o[3] += rs.w;
                 }
-                if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
-                if (g.out_bf16) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-                    *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
+                const bool tpart = n >= g.n_split;  // wave-uniform per sub-tile (n_split is a multiple of 16)
+                if (!tpart) {
+                    if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (g.out_bf16) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
+                    }
                 }
-                if (g.out_t) {
+                if (g.out_t && (tpart || g.n_split >= g.N)) {
+                    const int nt0 = tpart ? n - g.n_split : n;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) g.out_t[(long)(n + r) * g.ldt + m] = f32_to_bf16(o[r]);
+                    for (int r = 0; r < 4; ++r) g.out_t[(long)(nt0 + r) * g.ldt + m] = f32_to_bf16(o[r]);
                 }
             }
         }
@@ -238,7 +243,7 @@ using namespace sculpt;
 
 extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
                                 const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
-                                uint16_t *out_bf16_t, int ldt, int M, int N, int K, int epilogue,
+                                uint16_t *out_bf16_t, int ldt, int n_split, int M, int N, int K, int epilogue,
                                 sculpt_stream_t stream) {
     SC_REQUIRE(A && W, "gemm_bf16: null operand");
     SC_REQUIRE(out_f32 || out_bf16 || out_bf16_t, "gemm_bf16: no output");
@@ -246,7 +251,10 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     SC_REQUIRE(K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", K, BK);
     SC_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, "gemm_bf16: lda/ldw must be multiples of 8 elements (16-byte rows)");
     SC_REQUIRE(ldo % 4 == 0 && (!residual || ldr % 4 == 0), "gemm_bf16: ldo/ldr must be multiples of 4");
-    GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K};
+    if (n_split <= 0 || n_split > N) n_split = N;  // no split: every column goes to every given output
+    SC_REQUIRE(n_split % 16 == 0, "gemm_bf16: n_split=%d must be a multiple of 16", n_split);
+    SC_REQUIRE(n_split == N || out_bf16_t, "gemm_bf16: n_split needs the transposed output");
+    GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split};
     const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     if (epilogue == SCULPT_EPI_GEGLU) {

@@ -184,7 +184,7 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
 BF16 = torch.bfloat16
 
 
-def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0):
+def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0, n_split=0):
     """out[m][n] = epi(A[m][:] . W[n][:] + bias[n]) (+ residual[m][n]); see sculpt_gemm_bf16.
     A [>=M][K] bf16, W [N or 2N][K] bf16 (row stride = K).  Outputs are caller-allocated."""
     K = A.shape[1]
@@ -195,7 +195,7 @@ def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None
         assert out_f32.stride(0) == out_bf16.stride(0)
     check(lib.sculpt_gemm_bf16(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
                                residual.stride(0) if residual is not None else 0, _ptr(out_f32), _ptr(out_bf16),
-                               ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, M, N, K,
+                               ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, int(n_split), M, N, K,
                                epilogue, _stream()))
 
 

@@ -169,10 +169,8 @@ class TSR:
             L = {}
             L["ln1_w"], L["ln1_b"] = _f32(sd[q + "layernorm_before.weight"], dev), _f32(sd[q + "layernorm_before.bias"], dev)
             L["ln2_w"], L["ln2_b"] = _f32(sd[q + "layernorm_after.weight"], dev), _f32(sd[q + "layernorm_after.bias"], dev)
-            L["qk_w"] = _bf(torch.cat([sd[q + "attention.attention.query.weight"], sd[q + "attention.attention.key.weight"]], 0), dev)
-            L["qk_b"] = _f32(torch.cat([sd[q + "attention.attention.query.bias"], sd[q + "attention.attention.key.bias"]], 0), dev)
-            L["v_w"] = _bf(sd[q + "attention.attention.value.weight"], dev)
-            L["v_b"] = _f32(sd[q + "attention.attention.value.bias"], dev)
+            L["qkv_w"] = _bf(torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0), dev)
+            L["qkv_b"] = _f32(torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0), dev)
             L["o_w"], L["o_b"] = _bf(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
             L["f1_w"], L["f1_b"] = _bf(sd[q + "intermediate.dense.weight"], dev), _f32(sd[q + "intermediate.dense.bias"], dev)
             L["f2_w"], L["f2_b"] = _bf(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
@@ -194,16 +192,17 @@ class TSR:
             L = {}
             for j, ln in enumerate(("norm1", "norm2", "norm3")):
                 L["n%d_w" % (j + 1)], L["n%d_b" % (j + 1)] = _f32(sd[q + ln + ".weight"], dev), _f32(sd[q + ln + ".bias"], dev)
-            L["sa_qk"] = _bf(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"]], 0), dev)
-            L["sa_v"] = _bf(sd[q + "attn1.to_v.weight"], dev)
+            L["sa_qkv"] = _bf(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), dev)
             L["sa_o"], L["sa_ob"] = _bf(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
             L["ca_q"] = _bf(sd[q + "attn2.to_q.weight"], dev)
-            L["ca_k"] = _bf(sd[q + "attn2.to_k.weight"], dev)
-            L["ca_v"] = _bf(sd[q + "attn2.to_v.weight"], dev)
+            L["_ca_k"], L["_ca_v"] = sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]
             L["ca_o"], L["ca_ob"] = _bf(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
             L["ff1"], L["ff1_b"] = _bf(sd[q + "ff.net.0.proj.weight"], dev), _f32(sd[q + "ff.net.0.proj.bias"], dev)
             L["ff2"], L["ff2_b"] = _bf(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
             w["blocks"].append(L)
+        # the cross-attention K/V projections of ALL layers depend only on the image tokens: one GEMM
+        # [Tc, 768] x [L*2*D, 768]^T per image, rows ordered [K of layer 0..L-1 | V of layer 0..L-1]
+        w["ca_kv_all"] = _bf(torch.cat([L.pop("_ca_k") for L in w["blocks"]] + [L.pop("_ca_v") for L in w["blocks"]], 0), dev)
         # ConvTranspose2d(k2,s2) as a GEMM: rows (co,dy,dx), K = Cin; rows padded to a multiple of 128
         up = sd["post_processor.upsample.weight"]  # [Cin, Co, 2, 2]
         Co = up.shape[1]
@@ -259,8 +258,7 @@ class TSR:
         eps = v["layer_norm_eps"]
         for L in w["vit"]:
             ops.layernorm(h, L["ln1_w"], L["ln1_b"], eps, y=xn)
-            ops.gemm(xn, L["qk_w"], bias=L["qk_b"], out_bf16=qk)
-            ops.gemm(xn, L["v_w"], bias=L["v_b"], out_t=vt)
+            ops.gemm(xn, L["qkv_w"], bias=L["qkv_b"], out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
             ops.attention(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
             ops.gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
             ops.layernorm(h, L["ln2_w"], L["ln2_b"], eps, y=xn)
@@ -283,21 +281,21 @@ class TSR:
         qk = self._b("bb_qk", (T, 2 * D), BF16)
         q = self._b("bb_q", (T, D), BF16)
         vt = self._b("bb_vt", (D, Tp), BF16, zero=True)
-        ck = self._b("bb_ck", (Tc, D), BF16)
-        cvt = self._b("bb_cvt", (D, Tcp), BF16, zero=True)
+        nL = len(w["blocks"])
+        ck_all = self._b("bb_ck", (Tc, nL * D), BF16)
+        cvt_all = self._b("bb_cvt", (nL * D, Tcp), BF16, zero=True)
+        ops.gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Tc)
         att = self._b("bb_att", (T, D), BF16)
         ff = self._b("bb_ff", (T, 4 * D), BF16)
         scale = 1.0 / math.sqrt(hd)
-        for L in w["blocks"]:
+        for li, L in enumerate(w["blocks"]):
+            ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
             ops.layernorm(h, L["n1_w"], L["n1_b"], 1e-5, y=xn)
-            ops.gemm(xn, L["sa_qk"], out_bf16=qk)
-            ops.gemm(xn, L["sa_v"], out_t=vt)
+            ops.gemm(xn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
             ops.attention(qk[:, :D], qk[:, D:], vt, att, T, T, nh, scale)
             ops.gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
             ops.layernorm(h, L["n2_w"], L["n2_b"], 1e-5, y=xn)
             ops.gemm(xn, L["ca_q"], out_bf16=q)
-            ops.gemm(ctx, L["ca_k"], out_bf16=ck, M=Tc)
-            ops.gemm(ctx, L["ca_v"], out_t=cvt, M=Tc)
             ops.attention(q, ck, cvt, att, T, Tc, nh, scale)
             ops.gemm(att, L["ca_o"], bias=L["ca_ob"], residual=h, out_f32=h)
             ops.layernorm(h, L["n3_w"], L["n3_b"], 1e-5, y=xn)
