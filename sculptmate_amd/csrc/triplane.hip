@@ -359,6 +359,11 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int p = lane & 31, h = lane >> 5;
+    // Measured (rocprofv3 PMC, profiles/round1/pmc_density_counters.txt): the matrix pipe is busy 78 % of
+    // the kernel at 2.38 GHz; the rest is the SiLU VALU work (v_exp/v_rcp + 3 full-rate ops per value),
+    // which does NOT overlap the fp32 MFMAs of the other waves on the SIMD -- removing the transcendental
+    // part of SiLU brings the kernel to 93 % MFMA-busy, static per-wave priorities change nothing.  The
+    // fp32-input MFMA runs at exactly the fp32 VALU rate, i.e. it appears to share that datapath.
     const int nzb = (R + 31) / 32;
     const long ntiles = (long)nx * nzb * R;
     // contiguous tile range per wave: consecutive tiles share (ix, zb) and walk iy
