@@ -391,68 +391,136 @@ struct McHeader {            // first 64 bytes of the workspace
     unsigned pad[10];
 };
 
-__global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(const float *__restrict__ vol, Grid g, double level,
-                                                            int classic, int *__restrict__ block_counts,
-                                                            float2 *__restrict__ block_minmax) {
-    int packed = 0;
+// One record per ACTIVE cell, stored compactly per workgroup (slot b*256 + rank, rank in cell order):
+//   w0 = x_local | len << 8 | classic << 15 | ofs << 16      (the chosen tiling: no re-classification later)
+//   w1 = exclusive prefix inside the workgroup of (ntri | nown << 16)
+struct CellRec { unsigned w0, w1; };
+
+// Pass 1 over the full grid: sign pattern of every cell (float compares only), ballot + popcount
+// compaction of the active cells of the workgroup into LDS, then the expensive part (Lewiner face /
+// interior tests in fp64, triangle and owned-vertex counts, their prefix) runs on DENSE lanes.
+__global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__restrict__ vol, Grid g, float levelf,
+                                                               int classic, CellRec *__restrict__ recs,
+                                                               int *__restrict__ block_counts,
+                                                               int *__restrict__ block_nact,
+                                                               float2 *__restrict__ block_minmax) {
+    __shared__ unsigned char s_list[MC_BLOCK];
+    __shared__ int s_wcnt[MC_BLOCK / 64];
+    __shared__ float s_mn[MC_BLOCK / 64], s_mx[MC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float mn = FLT_MAX, mx = -FLT_MAX;
     int x, y, z;
-    if (cell_of_block(g, x, y, z)) {
-        double v[8];
-        load_cell(vol, g, z, y, x, level, v);
-        {
-            const long sy = g.n2, sz = (long)g.n1 * g.n2;
-            const float *p = vol + z * sz + y * sy + x;
-            const float f[8] = {p[0], p[1], p[sy], p[sy + 1], p[sz], p[sz + 1], p[sz + sy], p[sz + sy + 1]};
+    bool active = false;
+    const bool valid = cell_of_block(g, x, y, z);
+    if (valid) {
+        const long sy = g.n2, sz = (long)g.n1 * g.n2;
+        const float *p = vol + z * sz + y * sy + x;
+        const float f[8] = {p[0], p[1], p[sy + 1], p[sy], p[sz], p[sz + 1], p[sz + sy + 1], p[sz + sy]};
+        int idx = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                mn = fminf(mn, f[k]);
-                mx = fmaxf(mx, f[k]);
-            }
+        for (int k = 0; k < 8; ++k) {
+            mn = fminf(mn, f[k]);
+            mx = fmaxf(mx, f[k]);
+            idx |= (f[k] > levelf) ? (1 << k) : 0;  // == ((double)f - level > 0) for a float-valued level
         }
-        // wave early-out: most waves see no sign change at all
-        bool any = false;
-        {
-            int idx = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
-            any = idx != 0 && idx != 255;
-        }
-        if (any) {
-            Tiling t = classify(v, classic != 0);
-            packed = cell_counts(t, x, y, z, g.halo_low);
-        }
+        active = idx != 0 && idx != 255;
     }
-    // block reduce counts and min/max
-    __shared__ int s_cnt[MC_BLOCK / 64];
-    __shared__ float s_mn[MC_BLOCK / 64], s_mx[MC_BLOCK / 64];
-    int sum = packed;
+    const unsigned long long bal = __ballot(active);
+    const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        sum += __shfl_xor(sum, d, 64);
         mn = fminf(mn, __shfl_xor(mn, d, 64));
         mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_cnt[wave] = sum; s_mn[wave] = mn; s_mx[wave] = mx; }
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
     __syncthreads();
+    int wbase = 0, nact = 0;
+#pragma unroll
+    for (int w = 0; w < MC_BLOCK / 64; ++w) {
+        if (w < wave) wbase += s_wcnt[w];
+        nact += s_wcnt[w];
+    }
+    if (active) s_list[wbase + wrank] = (unsigned char)threadIdx.x;
+    __syncthreads();
+    // dense part
+    int packed = 0;
+    unsigned w0 = 0;
+    if ((int)threadIdx.x < nact) {
+        const int xl = s_list[threadIdx.x];
+        const int cx = x - (int)threadIdx.x + xl;  // same row segment
+        double v[8];
+        load_cell(vol, g, z, y, cx, (double)levelf, v);
+        const Tiling t = classify(v, classic != 0);
+        packed = cell_counts(t, cx, y, z, g.halo_low);
+        const unsigned ofs = t.ofs < 0 ? (unsigned)(-t.ofs - 1) : (unsigned)t.ofs;
+        w0 = (unsigned)xl | ((unsigned)t.len << 8) | ((t.ofs < 0 ? 1u : 0u) << 15) | (ofs << 16);
+    }
+    int total;
+    const int pre = block_exclusive_scan(packed, &total);
+    if ((int)threadIdx.x < nact) {
+        CellRec r;
+        r.w0 = w0; r.w1 = (unsigned)pre;
+        recs[(long)blockIdx.x * MC_BLOCK + threadIdx.x] = r;
+    }
     if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < MC_BLOCK / 64; ++w) {
-            tot += s_cnt[w];
-            mn = fminf(mn, s_mn[w]);
-            mx = fmaxf(mx, s_mx[w]);
-        }
-        block_counts[blockIdx.x] = tot;
-        block_minmax[blockIdx.x] = make_float2(mn, mx);  // reduced by the scan kernel (no contended atomics)
+        for (int w = 0; w < MC_BLOCK / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        block_counts[blockIdx.x] = total;
+        block_nact[blockIdx.x] = nact;
+        block_minmax[blockIdx.x] = make_float2(mn, mx);
     }
 }
 
-// single-workgroup exclusive scan of packed block counts -> separate tri/vert offsets
-__global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ block_counts,
-                                                       const float2 *__restrict__ block_minmax, int nblocks,
-                                                       unsigned *__restrict__ tri_ofs, unsigned *__restrict__ vert_ofs,
-                                                       McHeader *__restrict__ hdr) {
+// two-level exclusive scan of the packed per-workgroup counts (tri low 16 | vert high 16 of an int):
+// level 1: every workgroup scans 1024 entries and publishes its 64-bit total (tri | vert << 32)
+__global__ __launch_bounds__(1024) void mc_scan1_kernel(const int *__restrict__ block_counts,
+                                                        const float2 *__restrict__ block_minmax, int nblocks,
+                                                        unsigned *__restrict__ tri_ofs, unsigned *__restrict__ vert_ofs,
+                                                        unsigned long long *__restrict__ group_tot,
+                                                        float2 *__restrict__ group_minmax) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ float s_mn[16], s_mx[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int pk = i < nblocks ? block_counts[i] : 0;
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    if (i < nblocks) { const float2 mm = block_minmax[i]; mn = mm.x; mx = mm.y; }
+    const unsigned long long val = (unsigned long long)(pk & 0xffff) | ((unsigned long long)(pk >> 16) << 32);
+    unsigned long long inc = val;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, d, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 63) wsum[wave] = inc;
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
+    unsigned long long wbase = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wbase += wsum[w];
+        tot += wsum[w];
+    }
+    const unsigned long long ex = wbase + inc - val;
+    if (i < nblocks) {
+        tri_ofs[i] = (unsigned)(ex & 0xffffffffull);   // local to the group; the group base is added by the consumers
+        vert_ofs[i] = (unsigned)(ex >> 32);
+    }
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        group_tot[blockIdx.x] = tot;
+        group_minmax[blockIdx.x] = make_float2(mn, mx);
+    }
+}
+
+// level 2: one workgroup turns the group totals into exclusive group bases (in place) and the grand totals
+__global__ __launch_bounds__(1024) void mc_scan2_kernel(unsigned long long *__restrict__ group_tot,
+                                                        const float2 *__restrict__ group_minmax, int ngroups,
+                                                        McHeader *__restrict__ hdr) {
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long carry_s;
     __shared__ float s_mn[16], s_mx[16];
@@ -460,16 +528,10 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ b
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     float mn = FLT_MAX, mx = -FLT_MAX;
-    for (int base = 0; base < nblocks; base += 1024) {
+    for (int base = 0; base < ngroups; base += 1024) {
         const int i = base + threadIdx.x;
-        const int pk = i < nblocks ? block_counts[i] : 0;
-        if (i < nblocks) {
-            const float2 mm = block_minmax[i];
-            mn = fminf(mn, mm.x);
-            mx = fmaxf(mx, mm.y);
-        }
-        // 64-bit packed (tri low 32, vert high 32) so totals cannot overflow
-        const unsigned long long val = (unsigned long long)(pk & 0xffff) | ((unsigned long long)(pk >> 16) << 32);
+        const unsigned long long val = i < ngroups ? group_tot[i] : 0ull;
+        if (i < ngroups) { const float2 mm = group_minmax[i]; mn = fminf(mn, mm.x); mx = fmaxf(mx, mm.y); }
         unsigned long long inc = val;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -483,11 +545,7 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const int *__restrict__ b
             if (w < wave) wbase += wsum[w];
             tot += wsum[w];
         }
-        const unsigned long long ex = wbase + inc - val;
-        if (i < nblocks) {
-            tri_ofs[i] = (unsigned)(ex & 0xffffffffull);
-            vert_ofs[i] = (unsigned)(ex >> 32);
-        }
+        if (i < ngroups) group_tot[i] = wbase + inc - val;
         __syncthreads();
         if (threadIdx.x == 0) carry_s += tot;
         __syncthreads();
@@ -515,29 +573,33 @@ __device__ __forceinline__ double edge_frac(double v_near, double v_far) {
     return t_far / (t_near + t_far);
 }
 
+__device__ __forceinline__ Tiling tiling_of(unsigned w0) {
+    Tiling t;
+    t.len = (int)((w0 >> 8) & 0x7f);
+    const int ofs = (int)(w0 >> 16);
+    t.ofs = (w0 >> 15 & 1u) ? -(ofs + 1) : ofs;
+    return t;
+}
+
+// Pass 2, active cells only (dense lanes): the owner of every crossing edge writes the vertex and the
+// lattice-edge -> id map.
 __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restrict__ vol, Grid g, double level,
-                                                            int classic, const unsigned *__restrict__ vert_ofs,
+                                                            const CellRec *__restrict__ recs,
+                                                            const int *__restrict__ block_nact,
+                                                            const unsigned *__restrict__ vert_ofs,
+                                                            const unsigned long long *__restrict__ group_base,
                                                             int *__restrict__ edge_map, float *__restrict__ verts,
                                                             float vdiv, float vmul, float vadd, int affine) {
-    int x = 0, y = 0, z = 0;
+    const int nact = block_nact[blockIdx.x];
+    if ((int)threadIdx.x >= nact) return;
+    int x, y, z;
+    cell_of_block(g, x, y, z);
+    const CellRec rec = recs[(long)blockIdx.x * MC_BLOCK + threadIdx.x];
+    x = x - (int)threadIdx.x + (int)(rec.w0 & 0xffu);
+    const Tiling t = tiling_of(rec.w0);
     double v[8];
-    Tiling t;
-    t.ofs = 0; t.len = 0;
-    int nown = 0;
-    if (cell_of_block(g, x, y, z)) {
-        load_cell(vol, g, z, y, x, level, v);
-        int idx = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
-        if (idx != 0 && idx != 255) {
-            t = classify(v, classic != 0);
-            nown = cell_counts(t, x, y, z, g.halo_low) >> 16;
-        }
-    }
-    int total;
-    const int pre = block_exclusive_scan(nown, &total);
-    if (nown == 0) return;
-    unsigned id = vert_ofs[blockIdx.x] + (unsigned)pre;
+    load_cell(vol, g, z, y, x, level, v);
+    unsigned id = (unsigned)(group_base[blockIdx.x >> 10] >> 32) + vert_ofs[blockIdx.x] + (rec.w1 >> 16);
     unsigned seen = 0;
     for (int i = 0; i < t.len; ++i) {
         const int e = tiling_entry(t, i);
@@ -598,32 +660,25 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
     }
 }
 
+// Pass 3, active cells only: triangles through the lattice-edge -> id map (no volume reads at all).
 template <typename IdxT>
-__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(const float *__restrict__ vol, Grid g, double level,
-                                                            int classic, const unsigned *__restrict__ tri_ofs,
+__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(Grid g, const CellRec *__restrict__ recs,
+                                                            const int *__restrict__ block_nact,
+                                                            const unsigned *__restrict__ tri_ofs,
                                                             const unsigned *__restrict__ vert_ofs,
+                                                            const unsigned long long *__restrict__ group_base,
                                                             const int *__restrict__ edge_map, IdxT *__restrict__ faces,
                                                             int ref_order) {
-    int x = 0, y = 0, z = 0;
-    Tiling t;
-    t.ofs = 0; t.len = 0;
-    int packed = 0;
-    if (cell_of_block(g, x, y, z)) {
-        double v[8];
-        load_cell(vol, g, z, y, x, level, v);
-        int idx = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) idx |= (v[k] > 0.0) ? (1 << k) : 0;
-        if (idx != 0 && idx != 255) {
-            t = classify(v, classic != 0);
-            packed = cell_counts(t, x, y, z, g.halo_low);
-        }
-    }
-    int total;
-    const int pre = block_exclusive_scan(packed, &total);
-    if (t.len == 0) return;
-    const unsigned tri0 = tri_ofs[blockIdx.x] + (unsigned)(pre & 0xffff);
-    const unsigned vown0 = vert_ofs[blockIdx.x] + (unsigned)(pre >> 16);
+    const int nact = block_nact[blockIdx.x];
+    if ((int)threadIdx.x >= nact) return;
+    int x, y, z;
+    cell_of_block(g, x, y, z);
+    const CellRec rec = recs[(long)blockIdx.x * MC_BLOCK + threadIdx.x];
+    x = x - (int)threadIdx.x + (int)(rec.w0 & 0xffu);
+    const Tiling t = tiling_of(rec.w0);
+    const unsigned long long gb = group_base[blockIdx.x >> 10];
+    const unsigned tri0 = (unsigned)(gb & 0xffffffffull) + tri_ofs[blockIdx.x] + (rec.w1 & 0xffffu);
+    const unsigned vown0 = (unsigned)(gb >> 32) + vert_ofs[blockIdx.x] + (rec.w1 >> 16);
     // id of the centre vertex = own base + rank among owned vertices in first-appearance order
     int centre_id = -1;
     {
@@ -688,7 +743,8 @@ static int make_grid(int n0, int n1, int n2, Grid *g) {
 }
 
 struct WsLayout {
-    size_t off_counts, off_minmax, off_tri, off_vert, off_map, total;
+    size_t off_counts, off_nact, off_minmax, off_tri, off_vert, off_gtot, off_gmm, off_recs, off_map, total;
+    int ngroups;
     int nblocks;
 };
 static WsLayout ws_layout(const Grid &g) {
@@ -696,8 +752,13 @@ static WsLayout ws_layout(const Grid &g) {
     w.nblocks = g.c0 * g.c1 * cdiv(g.c2, MC_BLOCK);
     size_t o = 64;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    w.ngroups = cdiv(w.nblocks, 1024);
     w.off_counts = o; o = al(o + sizeof(int) * w.nblocks);
+    w.off_nact = o;   o = al(o + sizeof(int) * w.nblocks);
     w.off_minmax = o; o = al(o + sizeof(float2) * w.nblocks);
+    w.off_gtot = o;   o = al(o + sizeof(unsigned long long) * w.ngroups);
+    w.off_gmm = o;    o = al(o + sizeof(float2) * w.ngroups);
+    w.off_recs = o;   o = al(o + sizeof(CellRec) * (size_t)w.nblocks * MC_BLOCK);
     w.off_tri = o;    o = al(o + sizeof(unsigned) * w.nblocks);
     w.off_vert = o;   o = al(o + sizeof(unsigned) * w.nblocks);
     w.off_map = o;    o = al(o + sizeof(int) * 3 * (size_t)g.n0 * g.n1 * g.n2);
@@ -734,12 +795,17 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsig
     init.max_ord = 0u;
     SC_HIP(hipMemcpyAsync(hdr, &init, sizeof(init), hipMemcpyHostToDevice, st));
     const int classic = (flags & SCULPT_MC_USE_CLASSIC) ? 1 : 0;
-    hipLaunchKernelGGL(mc_count_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, classic,
-                       reinterpret_cast<int *>(ws + w.off_counts), reinterpret_cast<float2 *>(ws + w.off_minmax));
+    hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, level, classic,
+                       reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
+                       reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax));
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
-                       reinterpret_cast<const float2 *>(ws + w.off_minmax), w.nblocks, reinterpret_cast<unsigned *>(ws + w.off_tri),
-                       reinterpret_cast<unsigned *>(ws + w.off_vert), hdr);
+    hipLaunchKernelGGL(mc_scan1_kernel, dim3(w.ngroups), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
+                       reinterpret_cast<const float2 *>(ws + w.off_minmax), w.nblocks,
+                       reinterpret_cast<unsigned *>(ws + w.off_tri), reinterpret_cast<unsigned *>(ws + w.off_vert),
+                       reinterpret_cast<unsigned long long *>(ws + w.off_gtot), reinterpret_cast<float2 *>(ws + w.off_gmm));
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mc_scan2_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<unsigned long long *>(ws + w.off_gtot),
+                       reinterpret_cast<const float2 *>(ws + w.off_gmm), w.ngroups, hdr);
     SC_LAUNCH_CHECK();
     McHeader res;
     SC_HIP(hipMemcpyAsync(&res, hdr, sizeof(res), hipMemcpyDeviceToHost, st));
@@ -778,15 +844,18 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsign
     const unsigned *tri = reinterpret_cast<const unsigned *>(ws + w.off_tri);
     const unsigned *vrt = reinterpret_cast<const unsigned *>(ws + w.off_vert);
     int *emap = reinterpret_cast<int *>(ws + w.off_map);
-    hipLaunchKernelGGL(mc_verts_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, classic, vrt,
-                       emap, verts, vert_div, vert_mul, vert_add, ref);
+    const CellRec *recs = reinterpret_cast<const CellRec *>(ws + w.off_recs);
+    const int *nact = reinterpret_cast<const int *>(ws + w.off_nact);
+    const unsigned long long *gbase = reinterpret_cast<const unsigned long long *>(ws + w.off_gtot);
+    hipLaunchKernelGGL(mc_verts_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, recs, nact, vrt,
+                       gbase, emap, verts, vert_div, vert_mul, vert_add, ref);
     SC_LAUNCH_CHECK();
     if (flags & SCULPT_MC_FACES_I64)
-        hipLaunchKernelGGL(mc_faces_kernel<long long>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level,
-                           classic, tri, vrt, emap, reinterpret_cast<long long *>(faces), ref);
+        hipLaunchKernelGGL(mc_faces_kernel<long long>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, g, recs, nact, tri, vrt,
+                           gbase, emap, reinterpret_cast<long long *>(faces), ref);
     else
-        hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level,
-                           classic, tri, vrt, emap, reinterpret_cast<int *>(faces), ref);
+        hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, g, recs, nact, tri, vrt, gbase,
+                           emap, reinterpret_cast<int *>(faces), ref);
     SC_LAUNCH_CHECK();
     if (top_plane_map) {
         hipLaunchKernelGGL(mc_top_plane_kernel, dim3(cdiv(2L * n1 * n2, 256)), dim3(256), 0, st, vol, g, (double)level,
