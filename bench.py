@@ -126,7 +126,11 @@ def main():
     device = torch.device("cuda", local_rank)
     from sculptmate_amd import parallel, synth
 
-    dist = parallel.init("nccl", device) if world > 1 else None
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"  # keep stdout to the one JSON line (RCCL prints its banner there)
+
+    # SCULPT_FORCE_DIST=1 exercises the RCCL path with a single rank (used to validate it on a 1-GPU box)
+    dist = parallel.init("nccl", device) if (world > 1 or os.environ.get("SCULPT_FORCE_DIST")) else None
 
     model, sd = build_model(device, seed=0)  # every rank holds a full replica (no weight sharding)
     imgs_np = [synth.composite_rgb(synth.image_rgba(seed=100 + rank * 8 + i)) for i in range(4)]
