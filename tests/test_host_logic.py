@@ -133,3 +133,17 @@ def test_from_pretrained_reads_reference_style_checkpoint(tmp_path):
     assert param_spec(m.cfg) == param_spec(SMALL_CFG)
     got = m.state_dict()
     assert set(got) == set(sd) and all(np.array_equal(got[k].numpy(), sd[k]) for k in sd)
+
+
+def test_obj_round_trip(tmp_path):
+    from sculptmate_amd import meshio
+
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((50, 3)).astype(np.float32)
+    f = rng.integers(0, 50, (80, 3)).astype(np.int64)
+    c = rng.random((50, 3)).astype(np.float32)
+    meshio.write_obj(str(tmp_path / "m.obj"), v, f, c)
+    v2, f2, c2 = meshio.read_obj(str(tmp_path / "m.obj"))
+    assert np.array_equal(f2, f) and np.allclose(v2, v, rtol=1e-6) and np.allclose(c2, c, atol=1e-5)
+    meshio.write_obj(str(tmp_path / "n.obj"), v, f)
+    assert meshio.read_obj(str(tmp_path / "n.obj"))[2] is None
