@@ -208,6 +208,17 @@ void rasterize_cpu(const float *uv, size_t nv, const int *idx, size_t nf, long l
 void interpolate_cpu(const float *attr, size_t nv, const int *idx, size_t nf, const float *rast, long long res,
                      float *out);
 
+/* StableFast geometry tail:
+ *   dilate_fill (sf3d/models/utils.py:96-133): img f32 [3][H][W], mask f32 [H][W]; scratch 8*H*W floats
+ *   vertex normals / tangents (sf3d/models/mesh.py:66-139): area-weighted face normal / UV tangent splat
+ *   (float atomics: the sum order is not reproducible to the last bit), normalise, Gram-Schmidt. */
+int sculpt_dilate_fill(const float *img, const float *mask, int H, int W, int iterations, float *scratch, float *out,
+                       sculpt_stream_t stream);
+int sculpt_vertex_normals(const float *v_pos, size_t nv, const void *faces, int faces_i64, size_t nf, float *out,
+                          sculpt_stream_t stream);
+int sculpt_vertex_tangents(const float *v_pos, const float *v_tex, const float *v_nrm, size_t nv, const void *faces,
+                           int faces_i64, size_t nf, float *count_scratch, float *out, sculpt_stream_t stream);
+
 /* fp32 -> bf16 (round to nearest even), n elements */
 int sculpt_cast_bf16(const float *x, uint16_t *y, int64_t n, sculpt_stream_t stream);
 

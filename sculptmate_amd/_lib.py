@@ -53,6 +53,9 @@ SIGNATURES = {
     "sculpt_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sculpt_upsample_scatter": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "sculpt_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "sculpt_dilate_fill": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sculpt_vertex_normals": (_i, [_vp, _sz, _vp, _i, _sz, _vp, _vp]),
+    "sculpt_vertex_tangents": (_i, [_vp, _vp, _vp, _sz, _vp, _i, _sz, _vp, _vp, _vp]),
     "sculpt_resize_aa_bilinear": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "sculpt_bake_workspace_bytes": (_sz, [_i]),
     "sculpt_bake_rasterize": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp, _vp]),

@@ -280,3 +280,39 @@ def resize_aa_bilinear(img_hwc, size):
     out = torch.empty((size, size, C), dtype=torch.float32, device=img.device)
     check(lib.sculpt_resize_aa_bilinear(_ptr(img), H, W, C, _ptr(tmp), _ptr(out), size, size, _stream()))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# StableFast geometry tail
+# ----------------------------------------------------------------------------------------------
+def dilate_fill(img, mask, iterations=10):
+    """dilate_fill (sf3d/models/utils.py:96-133): img [1,3,H,W] f32, mask [1,1,H,W] (bool or float) -> [1,3,H,W]."""
+    img = _req(img.contiguous(), torch.float32, "img")
+    H, W = img.shape[-2:]
+    m = _req(mask.to(torch.float32).contiguous(), torch.float32, "mask")
+    scratch = torch.empty(8 * H * W, dtype=torch.float32, device=img.device)
+    out = torch.empty_like(img)
+    check(lib.sculpt_dilate_fill(_ptr(img), _ptr(m), H, W, int(iterations), _ptr(scratch), _ptr(out), _stream()))
+    return out
+
+
+def vertex_normals(v_pos, faces):
+    """Mesh._compute_vertex_normal (sf3d/models/mesh.py:66-92)."""
+    v = _req(v_pos.contiguous(), torch.float32, "v_pos")
+    f = faces.contiguous()
+    out = torch.empty_like(v)
+    check(lib.sculpt_vertex_normals(_ptr(v), v.shape[0], _ptr(f), int(f.dtype == torch.int64), f.shape[0], _ptr(out), _stream()))
+    return out
+
+
+def vertex_tangents(v_pos, v_tex, v_nrm, faces):
+    """Mesh._compute_vertex_tangent (sf3d/models/mesh.py:94-139)."""
+    v = _req(v_pos.contiguous(), torch.float32, "v_pos")
+    t = _req(v_tex.contiguous(), torch.float32, "v_tex")
+    n = _req(v_nrm.contiguous(), torch.float32, "v_nrm")
+    f = faces.contiguous()
+    cnt = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+    out = torch.empty_like(v)
+    check(lib.sculpt_vertex_tangents(_ptr(v), _ptr(t), _ptr(n), v.shape[0], _ptr(f), int(f.dtype == torch.int64), f.shape[0],
+                                     _ptr(cnt), _ptr(out), _stream()))
+    return out

@@ -240,6 +240,52 @@ def make_baker():
     print("baker:", rast.shape, int((rast[..., 3] >= 0).sum()), "covered pixels")
 
 
+def _sf3d_shims():
+    """jaxtyping / gpytoolbox stand-ins so StableFast/sf3d/models/{utils,mesh}.py import (no arithmetic here)."""
+    import types
+
+    class _Sub:
+        def __class_getitem__(cls, item):
+            return cls
+
+    jt = types.ModuleType("jaxtyping")
+    for n in ("Float", "Int", "Num", "Integer", "Bool"):
+        setattr(jt, n, _Sub)
+    sys.modules["jaxtyping"] = jt
+    sys.modules["gpytoolbox"] = types.ModuleType("gpytoolbox")
+    import PIL.Image  # noqa: F401  (sf3d/models/utils.py uses PIL.Image after a bare `import PIL`)
+    if "/root/reference/StableFast" not in sys.path:
+        sys.path.insert(0, "/root/reference/StableFast")
+
+
+def sf3d_tail_inputs():
+    rng = np.random.default_rng(33)
+    H = W = 48
+    yy, xx = np.mgrid[0:H, 0:W]
+    mask = ((xx - 20) ** 2 + (yy - 26) ** 2 < 12 ** 2) | ((xx > 30) & (xx < 36) & (yy > 5) & (yy < 40))
+    img = rng.random((1, 3, H, W)).astype(np.float32) * mask[None, None]
+    uv, faces, _ = uv_test_mesh(seed=2, n=8)
+    v_pos = np.concatenate([uv * 2 - 1, (0.3 * np.sin(uv[:, :1] * 6) * np.cos(uv[:, 1:] * 5))], 1).astype(np.float32)
+    return img.astype(np.float32), mask[None, None], v_pos, uv, faces.astype(np.int64)
+
+
+def make_sf3d_tail():
+    """dilate_fill (sf3d/models/utils.py:96-133) and Mesh vertex normals / tangents (sf3d/models/mesh.py:66-139)."""
+    _sf3d_shims()
+    from sf3d.models.mesh import Mesh
+    from sf3d.models.utils import dilate_fill
+
+    img, mask, v_pos, uv, faces = sf3d_tail_inputs()
+    out = dilate_fill(T(img), T(mask), iterations=10).numpy()
+    m = Mesh(T(v_pos), T(faces))
+    m._v_tex = T(uv)
+    nrm = m._compute_vertex_normal()
+    m._v_nrm = nrm
+    tng = m._compute_vertex_tangent()
+    np.savez_compressed(os.path.join(HERE, "sf3d_tail.npz"), dilate=out, v_nrm=nrm.numpy(), v_tng=tng.numpy())
+    print("sf3d_tail:", out.shape, nrm.shape, tng.shape)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["query", "grid", "upsample"]
     for w in which:
