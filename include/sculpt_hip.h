@@ -148,6 +148,15 @@ int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, con
                      uint16_t *out_bf16_t, int ldt, int n_split, int M, int N, int K, int epilogue,
                      sculpt_stream_t stream);
 
+/* fp32 "parity mode" of the same stack (exact-fp32 MFMA, ~5x slower; not timed by bench.py):
+ *   out[m][n] = epi(alpha * A[m][:].W[n][:] + bias[n]) (+ residual); A, W, out fp32; K % 16 == 0; N % 4 == 0
+ *   (w_rows = valid rows of W when N is padded; 0 = N); n_split / out_t as in sculpt_gemm_bf16. */
+int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
+                    float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K,
+                    float alpha, int epilogue, sculpt_stream_t stream);
+/* in-place softmax over the first `cols` columns of each row; columns [cols, pad_cols) are set to 0 */
+int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, sculpt_stream_t stream);
+
 /* softmax(Q K^T * scale) V per head, no mask (attention.py:629-631; HF ViTSelfAttention).
  *   Q [Tq][ldq], K [Tk][ldk] bf16 with head h at columns h*64 .. h*64+63;
  *   Vt [heads*64][ldvt] bf16 = V transposed (row = h*64 + d, column = key); ldvt >= round_up(Tk, 64)
@@ -165,8 +174,8 @@ int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const 
 /* GroupNorm over x [C][T] fp32 (groups of C/G channels x T tokens, transformer_1d.py:183) written
  * transposed as tokens y [T][C] bf16 */
 int sculpt_groupnorm_tokens(const float *x, int C, int T, int G, const float *gamma, const float *beta,
-                            float eps, uint16_t *y, float *stats_ws /* 2*G floats scratch */,
-                            sculpt_stream_t stream);
+                            float eps, uint16_t *y, float *y_f32 /* either output may be NULL */,
+                            float *stats_ws /* 2*G floats scratch */, sculpt_stream_t stream);
 
 /* out[c][t] = x[t][c] + residual[c][t]  (proj_out permute + residual, transformer_1d.py:211-217) */
 int sculpt_transpose_add(const float *x_tc, const float *residual_ct, float *out_ct, int T, int C,
@@ -180,7 +189,7 @@ int sculpt_resize_aa_bilinear(const float *in_hwc, int Hin, int Win, int C, floa
 /* ViT front end (tokenizers/image.py:48 + HF ViTEmbeddings): normalise (x-mean)/std and cut
  * [3][S][S] fp32 image into patch rows [S/P * S/P][3*P*P] bf16 (conv16/16 stride 16 as a GEMM) */
 int sculpt_vit_patchify(const float *image_hwc, int S, int P, const float *mean3_host, const float *std3_host,
-                        uint16_t *patches, sculpt_stream_t stream);
+                        uint16_t *patches, float *patches_f32 /* either may be NULL */, sculpt_stream_t stream);
 /* tokens[0] = cls + pos[0]; tokens[1+i] = patch_out[i] + pos[1+i]  (fp32 residual stream) */
 int sculpt_vit_assemble(const float *patch_out, const float *cls, const float *pos, float *tokens,
                         int n_patches, int hidden, sculpt_stream_t stream);

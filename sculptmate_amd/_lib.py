@@ -45,11 +45,13 @@ SIGNATURES = {
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sculpt_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp]),
-    "sculpt_groupnorm_tokens": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "sculpt_groupnorm_tokens": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sculpt_transpose_add": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
-    "sculpt_vit_patchify": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "sculpt_vit_patchify": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "sculpt_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sculpt_upsample_scatter": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "sculpt_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(1024) void groupnorm_stats_kernel(const float *__re
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float *__restrict__ x, int C, int T, int cpg,
                                                               const float *__restrict__ stats,
                                                               const float *__restrict__ gamma,
-                                                              const float *__restrict__ beta, uint16_t *__restrict__ y) {
+                                                              const float *__restrict__ beta, uint16_t *__restrict__ y,
+                                                              float *__restrict__ yf) {
     __shared__ float tile[64][65];
     const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float *__res
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         const int t = t0 + r, c = c0 + tx;
-        if (t < T && c < C) y[(long)t * C + c] = f32_to_bf16(tile[tx][r]);
+        if (t < T && c < C) {
+            if (y) y[(long)t * C + c] = f32_to_bf16(tile[tx][r]);
+            if (yf) yf[(long)t * C + c] = tile[tx][r];
+        }
     }
 }
 
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void transpose_add_kernel(const float *__restr
 // image [S][S][3] fp32 (HWC, 0..1) -> patches [ (S/P)^2 ][3*P*P] bf16, column = c*P*P + py*P + px
 __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, int S, int P, float m0, float m1,
                                                        float m2, float s0, float s1, float s2,
-                                                       uint16_t *__restrict__ patches) {
+                                                       uint16_t *__restrict__ patches, float *__restrict__ patches_f32) {
     const int np = S / P, cols = 3 * P * P;
     const long total = (long)np * np * cols;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -173,7 +177,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
         const int gy = (patch / np) * P + py, gx = (patch % np) * P + px;
         const float v = img[((long)gy * S + gx) * 3 + c];
         const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        patches[i] = f32_to_bf16((v - mean) / sd);
+        const float o = (v - mean) / sd;
+        if (patches) patches[i] = f32_to_bf16(o);
+        if (patches_f32) patches_f32[i] = o;
     }
 }
 
@@ -234,8 +240,8 @@ int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const 
 }
 
 int sculpt_groupnorm_tokens(const float *x, int C, int T, int G, const float *gamma, const float *beta, float eps,
-                            uint16_t *y, float *stats_ws, sculpt_stream_t stream) {
-    SC_REQUIRE(x && gamma && beta && y && stats_ws, "groupnorm: null argument");
+                            uint16_t *y, float *y_f32, float *stats_ws, sculpt_stream_t stream) {
+    SC_REQUIRE(x && gamma && beta && (y || y_f32) && stats_ws, "groupnorm: null argument");
     SC_REQUIRE(G >= 1 && C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
     const long ge = (long)(C / G) * T;
     SC_REQUIRE(ge % 4 == 0, "groupnorm: group size must be a multiple of 4");
@@ -243,7 +249,7 @@ int sculpt_groupnorm_tokens(const float *x, int C, int T, int G, const float *ga
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(G), dim3(1024), 0, st, x, ge, eps, stats_ws);
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(cdiv(T, 64), cdiv(C, 64)), dim3(256), 0, st, x, C, T, C / G,
-                       stats_ws, gamma, beta, y);
+                       stats_ws, gamma, beta, y, y_f32);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -258,12 +264,12 @@ int sculpt_transpose_add(const float *x_tc, const float *residual_ct, float *out
 }
 
 int sculpt_vit_patchify(const float *image_hwc, int S, int P, const float *mean3_host, const float *std3_host,
-                        uint16_t *patches, sculpt_stream_t stream) {
-    SC_REQUIRE(image_hwc && mean3_host && std3_host && patches, "vit_patchify: null argument");
+                        uint16_t *patches, float *patches_f32, sculpt_stream_t stream) {
+    SC_REQUIRE(image_hwc && mean3_host && std3_host && (patches || patches_f32), "vit_patchify: null argument");
     SC_REQUIRE(P > 0 && S % P == 0, "vit_patchify: S=%d not divisible by P=%d", S, P);
     const long total = (long)(S / P) * (S / P) * 3 * P * P;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), image_hwc, S, P,
-                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], patches);
+                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], patches, patches_f32);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -216,7 +216,9 @@ def layernorm(x, gamma, beta, eps, y=None, y_f32=None, rows=None):
 
 def groupnorm_tokens(x_ct, groups, gamma, beta, eps, y_tc, stats_ws):
     C, T = x_ct.shape
-    check(lib.sculpt_groupnorm_tokens(_ptr(x_ct), C, T, groups, _ptr(gamma), _ptr(beta), float(eps), _ptr(y_tc),
+    yb = y_tc if y_tc.dtype == BF16 else None
+    yf = y_tc if y_tc.dtype == torch.float32 else None
+    check(lib.sculpt_groupnorm_tokens(_ptr(x_ct), C, T, groups, _ptr(gamma), _ptr(beta), float(eps), _ptr(yb), _ptr(yf),
                                       _ptr(stats_ws), _stream()))
 
 
@@ -229,8 +231,10 @@ def vit_patchify(image_hwc, patch, mean, std, patches):
     S = image_hwc.shape[0]
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    pb = patches if patches.dtype == BF16 else None
+    pf = patches if patches.dtype == torch.float32 else None
     check(lib.sculpt_vit_patchify(_ptr(image_hwc), S, patch, ctypes.cast(m, ctypes.c_void_p),
-                                  ctypes.cast(s, ctypes.c_void_p), _ptr(patches), _stream()))
+                                  ctypes.cast(s, ctypes.c_void_p), _ptr(pb), _ptr(pf), _stream()))
 
 
 def vit_assemble(patch_out, cls, pos, tokens):
@@ -316,3 +320,36 @@ def vertex_tangents(v_pos, v_tex, v_nrm, faces):
     check(lib.sculpt_vertex_tangents(_ptr(v), _ptr(t), _ptr(n), v.shape[0], _ptr(f), int(f.dtype == torch.int64), f.shape[0],
                                      _ptr(cnt), _ptr(out), _stream()))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# fp32 parity mode primitives
+# ----------------------------------------------------------------------------------------------
+def gemm_f32(A, W, bias=None, residual=None, out=None, out_t=None, M=None, N=None, epilogue=0, n_split=0, w_rows=0,
+             alpha=1.0):
+    """out[m][n] = epi(alpha * A[m][:] . W[n][:] + bias[n]) (+ residual); fp32 throughout (sculpt_gemm_f32)."""
+    K = A.shape[1]
+    if N is None:
+        N = W.shape[0] // 2 if epilogue == _lib.EPI_GEGLU else W.shape[0]
+    M = A.shape[0] if M is None else M
+    check(lib.sculpt_gemm_f32(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                              residual.stride(0) if residual is not None else 0, _ptr(out),
+                              out.stride(0) if out is not None else 0, _ptr(out_t),
+                              out_t.stride(0) if out_t is not None else 0, int(n_split), int(w_rows), M, N, K,
+                              float(alpha), epilogue, _stream()))
+
+
+def softmax_rows_f32(x, rows, cols, pad_cols):
+    check(lib.sculpt_softmax_rows_f32(_ptr(x), x.stride(0), rows, cols, pad_cols, _stream()))
+
+
+def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores):
+    """softmax(Q K^T scale) V per head in fp32: two GEMMs and a row softmax per head.
+    Q [Tq][*], K [Tk][*] with head h at columns 64h..; Vt [heads*64][>= round_up(Tk,16)] (zero padded);
+    scores: scratch fp32 [Tq][>= round_up(Tk,16)]."""
+    Tkp = ((Tk + 15) // 16) * 16
+    for h in range(heads):
+        q, k = Q[:, 64 * h:64 * h + 64], K[:, 64 * h:64 * h + 64]
+        gemm_f32(q, k, out=scores, M=Tq, N=((Tk + 3) // 4) * 4, w_rows=Tk, alpha=scale)
+        softmax_rows_f32(scores, Tq, Tk, Tkp)
+        gemm_f32(scores[:, :Tkp], Vt[64 * h:64 * h + 64, :Tkp], out=O[:, 64 * h:64 * h + 64], M=Tq, N=64)

@@ -97,9 +97,15 @@ def _f32(x, dev):
 
 
 class TSR:
-    def __init__(self, cfg=None, pos_embed_mode="scale_factor"):
+    def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16"):
+        """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times) or
+        "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
         self.cfg = cfg or DEFAULT_CFG
         self.pos_embed_mode = pos_embed_mode
+        self.precision = precision
+        self.adt = BF16 if precision == "bf16" else torch.float32  # activation / weight storage type
         self._spec = param_spec(self.cfg)
         self._sd = None
         self.device = None
@@ -156,11 +162,12 @@ class TSR:
     # ------------------------------------------------------------------ weight preparation
     def _prepare(self, dev):
         sd, cfg = self._sd, self.cfg
+        wt = _bf if self.precision == "bf16" else _f32  # GEMM weight storage
         v, b = cfg["image_tokenizer"], cfg["backbone"]
         H = v["hidden_size"]
         w = {}
         p = "image_tokenizer.model."
-        w["patch_w"] = _bf(sd[p + "embeddings.patch_embeddings.projection.weight"].reshape(H, -1), dev)
+        w["patch_w"] = wt(sd[p + "embeddings.patch_embeddings.projection.weight"].reshape(H, -1), dev)
         w["patch_b"] = _f32(sd[p + "embeddings.patch_embeddings.projection.bias"], dev)
         w["cls"] = _f32(sd[p + "embeddings.cls_token"].reshape(H), dev)
         w["vit"] = []
@@ -169,11 +176,11 @@ class TSR:
             L = {}
             L["ln1_w"], L["ln1_b"] = _f32(sd[q + "layernorm_before.weight"], dev), _f32(sd[q + "layernorm_before.bias"], dev)
             L["ln2_w"], L["ln2_b"] = _f32(sd[q + "layernorm_after.weight"], dev), _f32(sd[q + "layernorm_after.bias"], dev)
-            L["qkv_w"] = _bf(torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0), dev)
+            L["qkv_w"] = wt(torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0), dev)
             L["qkv_b"] = _f32(torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0), dev)
-            L["o_w"], L["o_b"] = _bf(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
-            L["f1_w"], L["f1_b"] = _bf(sd[q + "intermediate.dense.weight"], dev), _f32(sd[q + "intermediate.dense.bias"], dev)
-            L["f2_w"], L["f2_b"] = _bf(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
+            L["o_w"], L["o_b"] = wt(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
+            L["f1_w"], L["f1_b"] = wt(sd[q + "intermediate.dense.weight"], dev), _f32(sd[q + "intermediate.dense.bias"], dev)
+            L["f2_w"], L["f2_b"] = wt(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
             w["vit"].append(L)
         w["vit_ln_w"], w["vit_ln_b"] = _f32(sd[p + "layernorm.weight"], dev), _f32(sd[p + "layernorm.bias"], dev)
 
@@ -184,25 +191,25 @@ class TSR:
         w["emb_ct"] = _f32(emb_ct, dev)
         w["emb_tc"] = _f32(emb_ct.t().contiguous(), dev)  # residual in token-major layout
         w["gn_w"], w["gn_b"] = _f32(sd["backbone.norm.weight"], dev), _f32(sd["backbone.norm.bias"], dev)
-        w["pin_w"], w["pin_b"] = _bf(sd["backbone.proj_in.weight"], dev), _f32(sd["backbone.proj_in.bias"], dev)
-        w["pout_w"], w["pout_b"] = _bf(sd["backbone.proj_out.weight"], dev), _f32(sd["backbone.proj_out.bias"], dev)
+        w["pin_w"], w["pin_b"] = wt(sd["backbone.proj_in.weight"], dev), _f32(sd["backbone.proj_in.bias"], dev)
+        w["pout_w"], w["pout_b"] = wt(sd["backbone.proj_out.weight"], dev), _f32(sd["backbone.proj_out.bias"], dev)
         w["blocks"] = []
         for i in range(b["num_layers"]):
             q = "backbone.transformer_blocks.%d." % i
             L = {}
             for j, ln in enumerate(("norm1", "norm2", "norm3")):
                 L["n%d_w" % (j + 1)], L["n%d_b" % (j + 1)] = _f32(sd[q + ln + ".weight"], dev), _f32(sd[q + ln + ".bias"], dev)
-            L["sa_qkv"] = _bf(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), dev)
-            L["sa_o"], L["sa_ob"] = _bf(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
-            L["ca_q"] = _bf(sd[q + "attn2.to_q.weight"], dev)
+            L["sa_qkv"] = wt(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), dev)
+            L["sa_o"], L["sa_ob"] = wt(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
+            L["ca_q"] = wt(sd[q + "attn2.to_q.weight"], dev)
             L["_ca_k"], L["_ca_v"] = sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]
-            L["ca_o"], L["ca_ob"] = _bf(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
-            L["ff1"], L["ff1_b"] = _bf(sd[q + "ff.net.0.proj.weight"], dev), _f32(sd[q + "ff.net.0.proj.bias"], dev)
-            L["ff2"], L["ff2_b"] = _bf(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
+            L["ca_o"], L["ca_ob"] = wt(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
+            L["ff1"], L["ff1_b"] = wt(sd[q + "ff.net.0.proj.weight"], dev), _f32(sd[q + "ff.net.0.proj.bias"], dev)
+            L["ff2"], L["ff2_b"] = wt(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
             w["blocks"].append(L)
         # the cross-attention K/V projections of ALL layers depend only on the image tokens: one GEMM
         # [Tc, 768] x [L*2*D, 768]^T per image, rows ordered [K of layer 0..L-1 | V of layer 0..L-1]
-        w["ca_kv_all"] = _bf(torch.cat([L.pop("_ca_k") for L in w["blocks"]] + [L.pop("_ca_v") for L in w["blocks"]], 0), dev)
+        w["ca_kv_all"] = wt(torch.cat([L.pop("_ca_k") for L in w["blocks"]] + [L.pop("_ca_v") for L in w["blocks"]], 0), dev)
         # ConvTranspose2d(k2,s2) as a GEMM: rows (co,dy,dx), K = Cin; rows padded to a multiple of 128
         up = sd["post_processor.upsample.weight"]  # [Cin, Co, 2, 2]
         Co = up.shape[1]
@@ -210,7 +217,7 @@ class TSR:
         npad = ((4 * Co + 127) // 128) * 128
         upw = torch.zeros(npad, up.shape[0])
         upw[: 4 * Co] = rows
-        w["up_w"], w["up_b"] = _bf(upw, dev), _f32(sd["post_processor.upsample.bias"], dev)
+        w["up_w"], w["up_b"] = wt(upw, dev), _f32(sd["post_processor.upsample.bias"], dev)
         self._w = w
         d = cfg["decoder"]
         n = d["n_hidden_layers"] + 1
@@ -233,6 +240,28 @@ class TSR:
             self._buf[key] = t
         return t
 
+    # ------------------------------------------------------------------ precision dispatch
+    def _gemm(self, A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0,
+              n_split=0):
+        """One Linear: bf16 MFMA kernel (out_bf16 = activation buffer) or the fp32 parity kernel (every buffer fp32)."""
+        if self.precision == "bf16":
+            return ops.gemm(A, W, bias=bias, residual=residual, out_f32=out_f32, out_bf16=out_bf16, out_t=out_t, M=M,
+                            epilogue=epilogue, n_split=n_split)
+        out = out_f32 if out_f32 is not None else out_bf16
+        return ops.gemm_f32(A, W, bias=bias, residual=residual, out=out, out_t=out_t, M=M, epilogue=epilogue,
+                            n_split=n_split)
+
+    def _attn(self, Q, K, Vt, O, Tq, Tk, heads, scale):
+        if self.precision == "bf16":
+            return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale)
+        scores = self._b("attn_scores", (Tq, ((Tk + 15) // 16) * 16), torch.float32)
+        return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores)
+
+    def _ln(self, x, gamma, beta, eps, y):
+        if self.precision == "bf16":
+            return ops.layernorm(x, gamma, beta, eps, y=y)
+        return ops.layernorm(x, gamma, beta, eps, y_f32=y)
+
     # ------------------------------------------------------------------ forward
     def image_tokens(self, image_hwc: torch.Tensor):
         """DINOSingleImageTokenizer.forward for one [S,S,3] fp32 image on the device ->
@@ -244,29 +273,33 @@ class TSR:
         npatch = n_side * n_side
         T = npatch + 1
         Tp = ((T + 63) // 64) * 64
-        patches = self._b("patches", (npatch, 3 * P * P), BF16)
+        patches = self._b("patches", (npatch, 3 * P * P), self.adt)
         ops.vit_patchify(image_hwc, P, IMAGE_MEAN, IMAGE_STD, patches)
         pout = self._b("patch_out", (npatch, H), torch.float32)
-        ops.gemm(patches, w["patch_w"], bias=w["patch_b"], out_f32=pout)
+        self._gemm(patches, w["patch_w"], bias=w["patch_b"], out_f32=pout)
         h = self._b("vit_h", (T, H), torch.float32)
         ops.vit_assemble(pout, w["cls"], self._pos(n_side, image_hwc.device), h)
-        xn = self._b("vit_xn", (T, H), BF16)
-        qk = self._b("vit_qk", (T, 2 * H), BF16)
-        vt = self._b("vit_vt", (H, Tp), BF16, zero=True)
-        att = self._b("vit_att", (T, H), BF16)
-        ff = self._b("vit_ff", (T, v["intermediate_size"]), BF16)
+        xn = self._b("vit_xn", (T, H), self.adt)
+        qk = self._b("vit_qk", (T, 2 * H), self.adt)
+        vt = self._b("vit_vt", (H, Tp), self.adt, zero=True)
+        att = self._b("vit_att", (T, H), self.adt)
+        ff = self._b("vit_ff", (T, v["intermediate_size"]), self.adt)
         eps = v["layer_norm_eps"]
         for L in w["vit"]:
-            ops.layernorm(h, L["ln1_w"], L["ln1_b"], eps, y=xn)
-            ops.gemm(xn, L["qkv_w"], bias=L["qkv_b"], out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
-            ops.attention(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
-            ops.gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
-            ops.layernorm(h, L["ln2_w"], L["ln2_b"], eps, y=xn)
-            ops.gemm(xn, L["f1_w"], bias=L["f1_b"], out_bf16=ff, epilogue=_lib.EPI_GELU)
-            ops.gemm(ff, L["f2_w"], bias=L["f2_b"], residual=h, out_f32=h)
-        ctx = self._b("ctx", (T, H), BF16)
+            self._ln(h, L["ln1_w"], L["ln1_b"], eps, xn)
+            self._gemm(xn, L["qkv_w"], bias=L["qkv_b"], out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
+            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
+            self._gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
+            self._ln(h, L["ln2_w"], L["ln2_b"], eps, xn)
+            self._gemm(xn, L["f1_w"], bias=L["f1_b"], out_bf16=ff, epilogue=_lib.EPI_GELU)
+            self._gemm(ff, L["f2_w"], bias=L["f2_b"], residual=h, out_f32=h)
         ctx32 = self._b("ctx32", (T, H), torch.float32)
-        ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y=ctx, y_f32=ctx32)
+        if self.precision == "bf16":
+            ctx = self._b("ctx", (T, H), BF16)
+            ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y=ctx, y_f32=ctx32)
+        else:
+            ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y_f32=ctx32)
+            ctx = ctx32
         return ctx, ctx32
 
     def _run_blocks(self, h: torch.Tensor, ctx: torch.Tensor):
@@ -277,30 +310,30 @@ class TSR:
         T, Tc = h.shape[0], ctx.shape[0]
         Tcp = ((Tc + 63) // 64) * 64
         Tp = ((T + 63) // 64) * 64
-        xn = self._b("bb_xn", (T, D), BF16)
-        qk = self._b("bb_qk", (T, 2 * D), BF16)
-        q = self._b("bb_q", (T, D), BF16)
-        vt = self._b("bb_vt", (D, Tp), BF16, zero=True)
+        xn = self._b("bb_xn", (T, D), self.adt)
+        qk = self._b("bb_qk", (T, 2 * D), self.adt)
+        q = self._b("bb_q", (T, D), self.adt)
+        vt = self._b("bb_vt", (D, Tp), self.adt, zero=True)
         nL = len(w["blocks"])
-        ck_all = self._b("bb_ck", (Tc, nL * D), BF16)
-        cvt_all = self._b("bb_cvt", (nL * D, Tcp), BF16, zero=True)
-        ops.gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Tc)
-        att = self._b("bb_att", (T, D), BF16)
-        ff = self._b("bb_ff", (T, 4 * D), BF16)
+        ck_all = self._b("bb_ck", (Tc, nL * D), self.adt)
+        cvt_all = self._b("bb_cvt", (nL * D, Tcp), self.adt, zero=True)
+        self._gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Tc)
+        att = self._b("bb_att", (T, D), self.adt)
+        ff = self._b("bb_ff", (T, 4 * D), self.adt)
         scale = 1.0 / math.sqrt(hd)
         for li, L in enumerate(w["blocks"]):
             ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
-            ops.layernorm(h, L["n1_w"], L["n1_b"], 1e-5, y=xn)
-            ops.gemm(xn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
-            ops.attention(qk[:, :D], qk[:, D:], vt, att, T, T, nh, scale)
-            ops.gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
-            ops.layernorm(h, L["n2_w"], L["n2_b"], 1e-5, y=xn)
-            ops.gemm(xn, L["ca_q"], out_bf16=q)
-            ops.attention(q, ck, cvt, att, T, Tc, nh, scale)
-            ops.gemm(att, L["ca_o"], bias=L["ca_ob"], residual=h, out_f32=h)
-            ops.layernorm(h, L["n3_w"], L["n3_b"], 1e-5, y=xn)
-            ops.gemm(xn, L["ff1"], bias=L["ff1_b"], out_bf16=ff, epilogue=_lib.EPI_GEGLU)
-            ops.gemm(ff, L["ff2"], bias=L["ff2_b"], residual=h, out_f32=h)
+            self._ln(h, L["n1_w"], L["n1_b"], 1e-5, xn)
+            self._gemm(xn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
+            self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, scale)
+            self._gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
+            self._ln(h, L["n2_w"], L["n2_b"], 1e-5, xn)
+            self._gemm(xn, L["ca_q"], out_bf16=q)
+            self._attn(q, ck, cvt, att, T, Tc, nh, scale)
+            self._gemm(att, L["ca_o"], bias=L["ca_ob"], residual=h, out_f32=h)
+            self._ln(h, L["n3_w"], L["n3_b"], 1e-5, xn)
+            self._gemm(xn, L["ff1"], bias=L["ff1_b"], out_bf16=ff, epilogue=_lib.EPI_GEGLU)
+            self._gemm(ff, L["ff2"], bias=L["ff2_b"], residual=h, out_f32=h)
         return h
 
     def backbone_tokens(self, ctx: torch.Tensor):
@@ -313,17 +346,21 @@ class TSR:
         T = w["emb_ct"].shape[1]
         Tc = ctx.shape[0]
         Tcp = ((Tc + 63) // 64) * 64
-        xn = self._b("bb_xn", (T, D), BF16)
+        xn = self._b("bb_xn", (T, D), self.adt)
         stats = self._b("gn_stats", (2 * b["norm_num_groups"],), torch.float32)
         ops.groupnorm_tokens(w["emb_ct"], b["norm_num_groups"], w["gn_w"], w["gn_b"], 1e-6, xn, stats)
         h = self._b("bb_h", (T, D), torch.float32)
-        ops.gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
+        self._gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
         h = self._run_blocks(h, ctx)
-        hb = self._b("bb_hb", (T, D), BF16)
-        ops.cast_bf16(h, hb)
         out = self._b("bb_out", (T, C), torch.float32)
-        outb = self._b("bb_outb", (T, C), BF16)
-        ops.gemm(hb, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out_f32=out, out_bf16=outb)
+        if self.precision == "bf16":
+            hb = self._b("bb_hb", (T, D), BF16)
+            ops.cast_bf16(h, hb)
+            outb = self._b("bb_outb", (T, C), BF16)
+            ops.gemm(hb, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out_f32=out, out_bf16=outb)
+        else:
+            ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out=out)
+            outb = out
         return out, outb
 
     def scene_code(self, tokens_bf16: torch.Tensor):
@@ -332,7 +369,7 @@ class TSR:
         S = self.cfg["tokenizer"]["plane_size"]
         Co = self.cfg["post_processor"]["out_channels"]
         g = self._b("up_g", (tokens_bf16.shape[0], w["up_w"].shape[0]), torch.float32)
-        ops.gemm(tokens_bf16, w["up_w"], out_f32=g)
+        self._gemm(tokens_bf16, w["up_w"], out_f32=g)
         planes = torch.empty((3, Co, 2 * S, 2 * S), dtype=torch.float32, device=tokens_bf16.device)
         ops.upsample_scatter(g, w["up_b"], planes, S, Co)
         return planes

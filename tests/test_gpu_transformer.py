@@ -329,3 +329,80 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     assert r32 < 3e-2, r32
     ctx, ctx32 = m.image_tokens(torch.from_numpy(img).to(cuda))
     assert _rel(ctx32, col["ctx"])[0] < 2e-2
+    # the fp32 parity mode at full size: fp32 rounding only (28 layers deep)
+    del m
+    torch.cuda.empty_cache()
+    m32 = TSR(pos_embed_mode="scale_factor", precision="fp32")
+    m32.load_state_dict(sd)
+    m32.to(cuda)
+    c32 = m32([img], device=cuda)
+    rel32, _ = _rel(c32[0], ref32)
+    print("full-size scene code: bf16 mode rel %.3e, fp32 mode rel %.3e" % (r32, rel32))
+    assert rel32 < 1e-4, rel32
+    # image -> mesh against the CPU path (north-star: vertices within 1e-4 relative of the CPU reference)
+    from oracle import capi
+
+    R = 64
+    Ws, bs = synth.decoder_lists(sd)
+    dref = capi.density_grid(ref32.numpy(), Ws, bs, R)
+    thr = float(np.quantile(dref, 0.97))
+    mesh = m32.extract_meshes(c32, resolution=R, threshold=thr)[0]
+    rv, rf = capi.reference_isosurface(-(dref - np.float32(thr)), R)
+    rv = rv * np.float32(0.87 - (-0.87)) + np.float32(-0.87)
+    v, f = mesh.vertices.cpu().numpy(), mesh.faces.cpu().numpy()
+    assert abs(len(v) - len(rv)) <= max(4, len(rv) // 500)
+    if f.shape == rf.shape and np.array_equal(f, rf):
+        assert np.abs(v - rv).max() < 1e-4 * 1.74
+
+
+def test_gemm_f32_and_softmax(cuda):
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K) in ((200, 256, 64), (1025, 768, 768), (3072, 1028, 64)):
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = (A.double() @ W.double().t() * 0.5 + b + r).float()
+        out = torch.empty(M, N, device=cuda)
+        ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), residual=r.to(cuda), out=out, alpha=0.5)
+        assert _rel(out, ref)[0] < 5e-7, (M, N, K)
+    A = torch.randn(130, 128, generator=g); W = torch.randn(256, 128, generator=g) / 11; b = torch.randn(256, generator=g)
+    pre = A @ W.t() + b
+    o = torch.empty(130, 128, device=cuda)
+    ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), out=o, epilogue=_lib.EPI_GEGLU)
+    assert _rel(o, pre[:, :128] * torch.nn.functional.gelu(pre[:, 128:]))[1] < 2e-5
+    x = torch.randn(37, 112, generator=g)
+    xs = x.clone().to(cuda)
+    ops.softmax_rows_f32(xs, 37, 100, 112)
+    assert _rel(xs[:, :100], torch.softmax(x[:, :100], -1))[1] < 1e-6 and (xs[:, 100:] == 0).all()
+
+
+def test_fp32_parity_mode_small_and_mesh(cuda):
+    """TSR(precision='fp32'): the whole forward on the exact-fp32 matrix pipe reproduces the fp32 oracle to
+    fp32 rounding, and the mesh extracted from it matches the mesh of the oracle's scene code."""
+    from oracle import capi
+    from sculptmate_amd.tsr import TSR
+
+    sd = synth.tsr_state(31, SMALL_CFG)
+    m = TSR(SMALL_CFG, pos_embed_mode="size", precision="fp32")
+    m.load_state_dict(sd)
+    m.to(cuda)
+    img = synth.composite_rgb(synth.image_rgba(seed=32, size=SMALL_CFG["cond_image_size"]))
+    codes = m([img], device=cuda)
+    ref = tsr_ref.tsr_forward(sd, img, SMALL_CFG, pos_mode="size")
+    rel, mx = _rel(codes[0], ref)
+    assert rel < 2e-5, rel
+    # image -> mesh, end to end, against the CPU path (oracle forward -> oracle density -> oracle marching cubes)
+    R = 40
+    Ws, bs = synth.decoder_lists(sd)
+    dens_ref = capi.density_grid(ref.numpy(), Ws, bs, R)
+    thr = float(np.median(dens_ref))
+    mesh = m.run([img], mc_resolution=R, threshold=thr)[0]
+    rv, rf = capi.reference_isosurface(-(dens_ref - np.float32(thr)), R)
+    rv = rv * np.float32(0.87 - (-0.87)) + np.float32(-0.87)
+    assert abs(len(mesh.vertices) - len(rv)) <= max(4, len(rv) // 500)
+    if mesh.faces.shape == rf.shape and np.array_equal(mesh.faces, rf):
+        # same topology: vertices within the north-star tolerance (1e-4 relative to the scene extent)
+        assert np.abs(mesh.vertices - rv).max() < 1e-4 * 0.87
