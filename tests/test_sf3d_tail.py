@@ -1,6 +1,5 @@
 """StableFast geometry tail: oracle vs the reference's own output (CPU) and HIP vs oracle (GPU)."""
 import os
-import sys
 
 import numpy as np
 import pytest
@@ -9,13 +8,11 @@ import torch
 from conftest import GOLDEN
 from oracle import sf3d_tail as ref
 
-sys.path.insert(0, GOLDEN)
 
 
 def _inputs():
-    import importlib
-
-    g = importlib.import_module("make_reference_goldens") if False else None  # the generator needs /root/reference
+    # same construction as tests/golden/make_reference_goldens.py::sf3d_tail_inputs (the generator itself needs
+    # /root/reference, which does not exist on the GPU box)
     rng = np.random.default_rng(33)
     H = W = 48
     yy, xx = np.mgrid[0:H, 0:W]
