@@ -120,10 +120,10 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
 #define SCULPT_ERR_MC_EMPTY 12
 
 size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2);
-int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsigned flags,
+int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsigned flags,
                     void *workspace, int64_t *n_verts_host, int64_t *n_faces_host,
                     float *minmax_host /* [2] data min,max or NULL */, sculpt_stream_t stream);
-int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsigned flags,
+int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsigned flags,
                    void *workspace, float vert_div, float vert_mul, float vert_add,
                    int axis0_offset /* slab: global index of lattice plane 0 */,
                    float *verts, void *faces, int *top_plane_map /* or NULL */, sculpt_stream_t stream);

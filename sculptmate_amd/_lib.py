@@ -42,8 +42,8 @@ SIGNATURES = {
     "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sculpt_mc_count": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _pi64, _pi64, _vp, _vp]),
-    "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, _f, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
+    "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),

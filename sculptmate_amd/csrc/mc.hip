@@ -20,6 +20,7 @@
 //   faces : re-classify, block scan, every active cell writes its triangles through the map
 // HBM traffic: 3 reads of the volume (4 B/voxel each) + 12 B/vertex + 12|24 B/face + sparse map.
 #include <float.h>
+#include <math.h>
 #include <string.h>
 
 #include "common.h"
@@ -400,7 +401,7 @@ struct CellRec { unsigned w0, w1; };
 // compaction of the active cells of the workgroup into LDS, then the expensive part (Lewiner face /
 // interior tests in fp64, triangle and owned-vertex counts, their prefix) runs on DENSE lanes.
 __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__restrict__ vol, Grid g, float levelf,
-                                                               int classic, CellRec *__restrict__ recs,
+                                                               double level, int classic, CellRec *__restrict__ recs,
                                                                int *__restrict__ block_counts,
                                                                int *__restrict__ block_nact,
                                                                float2 *__restrict__ block_minmax) {
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
         for (int k = 0; k < 8; ++k) {
             mn = fminf(mn, f[k]);
             mx = fmaxf(mx, f[k]);
-            idx |= (f[k] > levelf) ? (1 << k) : 0;  // == ((double)f - level > 0) for a float-valued level
+            idx |= (f[k] > levelf) ? (1 << k) : 0;  // == ((double)f - level > 0): levelf = largest float <= level
         }
         active = idx != 0 && idx != 255;
     }
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
         const int xl = s_list[threadIdx.x];
         const int cx = x - (int)threadIdx.x + xl;  // same row segment
         double v[8];
-        load_cell(vol, g, z, y, cx, (double)levelf, v);
+        load_cell(vol, g, z, y, cx, level, v);
         const Tiling t = classify(v, classic != 0);
         packed = cell_counts(t, cx, y, z, g.halo_low);
         const unsigned ofs = t.ofs < 0 ? (unsigned)(-t.ofs - 1) : (unsigned)t.ofs;
@@ -778,7 +779,7 @@ size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2) {
     return ws_layout(g).total;
 }
 
-int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsigned flags, void *workspace,
+int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
                     int64_t *n_verts_host, int64_t *n_faces_host, float *minmax_host, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     Grid g;
@@ -795,7 +796,10 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsig
     init.max_ord = 0u;
     SC_HIP(hipMemcpyAsync(hdr, &init, sizeof(init), hipMemcpyHostToDevice, st));
     const int classic = (flags & SCULPT_MC_USE_CLASSIC) ? 1 : 0;
-    hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, level, classic,
+    // float f > double level  <=>  f > (largest float <= level): the sign pass needs no fp64
+    float levelf = (float)level;
+    if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
+    hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
                        reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
                        reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax));
     SC_LAUNCH_CHECK();
@@ -828,7 +832,7 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, float level, unsig
     return 0;
 }
 
-int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, float level, unsigned flags, void *workspace,
+int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
                    float vert_div, float vert_mul, float vert_add, int axis0_offset, float *verts, void *faces,
                    int *top_plane_map, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
