@@ -36,6 +36,8 @@ class _Cfg(dict):
 def _wrap(x):
     if isinstance(x, dict):
         return _Cfg({k: _wrap(v) for k, v in x.items()})
+    if isinstance(x, (list, tuple)):
+        return [_wrap(v) for v in x]
     return x
 
 

@@ -1,0 +1,234 @@
+"""Golden vectors for the StableFast-3D networks (BASELINE config 4), produced by IMPORTING the reference.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_sf3d_goldens.py
+Every number in the fixtures comes out of the reference's own classes:
+
+  sf3d_dino.npz      DINOV2SingleImageTokenizer.forward + Dinov2Model + Modulation
+                     (StableFast/sf3d/models/tokenizers/image.py:64-96, dinov2.py, transformers/attention.py:5-31)
+  sf3d_backbone.npz  TwoStreamInterleaveTransformer.forward (models/transformers/backbone.py:398-515)
+  sf3d_post.npz      PixelShuffleUpsampleNetwork.forward (models/network.py:29-75)
+  sf3d_decoder.npz   SF3D.query_triplane (sf3d/system.py:170-199) + MaterialMLP.forward (models/network.py:148-210)
+  sf3d_mtet.npz      MarchingTetrahedraHelper.forward (models/isosurface.py:108-229) on a synthetic tet grid
+                     (the shipped 160_tets.npz is absent from the reference checkout)
+  sf3d_camera.npz    LinearCameraEmbedder + default_cond_c2w + create_intrinsic_from_fov_deg
+                     (models/camera.py:9-32, sf3d/utils.py:24-50)
+
+Tiny widths, seeded weights stored in the fixture, so the oracle (oracle/sf3d_ref.py) is pinned on any machine.
+Stand-ins used (no arithmetic): jaxtyping / gpytoolbox / omegaconf / bpy modules; two never-called
+head-pruning helpers and `get_head_mask` (returns [None]*n for head_mask=None, its transformers-4.x behaviour)
+that transformers 5.x no longer provides; Dinov2Model is built from a small Dinov2Config instead of
+from_pretrained("facebook/dinov2-large") (no network).
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _reference_shims as shims  # noqa: E402
+
+shims.install()
+import make_reference_goldens as mrg  # noqa: E402
+
+mrg._sf3d_shims()
+sys.path.insert(0, "/root/reference/StableFast")
+import transformers.pytorch_utils as _pu  # noqa: E402
+
+for _n in ("find_pruneable_heads_and_indices", "prune_linear_layer"):
+    if not hasattr(_pu, _n):
+        setattr(_pu, _n, lambda *a, **k: None)
+
+torch.set_num_threads(8)
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def randomize(module, seed, scale=None):
+    """Replace default inits by seeded values large enough that every term matters."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.ndim == 1:
+                if name.endswith("weight") or name.endswith("lambda1"):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                fan_in = p[0].numel() if p.ndim > 1 else p.numel()
+                s = scale if scale is not None else 1.0 / np.sqrt(fan_in)
+                p.copy_(s * torch.randn(p.shape, generator=g))
+
+
+def make_dino():
+    from sf3d.models.tokenizers import dinov2
+    from sf3d.models.tokenizers.image import DINOV2SingleImageTokenizer
+    from sf3d.models.transformers.attention import Modulation
+    from transformers.models.dinov2.configuration_dinov2 import Dinov2Config
+
+    if not hasattr(dinov2.Dinov2Model, "get_head_mask"):
+        dinov2.Dinov2Model.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+    cfg = Dinov2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, mlp_ratio=4, image_size=70,
+                       patch_size=14)
+    torch.manual_seed(0)
+    model = dinov2.Dinov2Model(cfg).eval()
+    # DINOV2SingleImageTokenizer.configure (image.py:25-62) minus from_pretrained
+    tok = DINOV2SingleImageTokenizer.__new__(DINOV2SingleImageTokenizer)
+    torch.nn.Module.__init__(tok)
+    tok.model = model
+    mods = []
+    for layer in model.encoder.layer:
+        m1 = Modulation(cfg.hidden_size, 48, zero_init=True, single_layer=True)
+        m2 = Modulation(cfg.hidden_size, 48, zero_init=True, single_layer=True)
+        layer.register_ada_norm_modulation(m1, m2)
+        mods += [m1, m2]
+    tok.modulations = torch.nn.ModuleList(mods)
+    tok.register_buffer("image_mean", torch.as_tensor([0.485, 0.456, 0.406]).reshape(1, 1, 3, 1, 1), persistent=False)
+    tok.register_buffer("image_std", torch.as_tensor([0.229, 0.224, 0.225]).reshape(1, 1, 3, 1, 1), persistent=False)
+    randomize(tok, 1)
+    with torch.no_grad():
+        tok.model.embeddings.position_embeddings.copy_(0.5 * torch.randn(tok.model.embeddings.position_embeddings.shape,
+                                                                         generator=torch.Generator().manual_seed(2)))
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(1, 1, 3, 56, 56, generator=g)
+    cond = torch.randn(1, 1, 48, generator=g)
+    with torch.no_grad():
+        out = tok(images, modulation_cond=cond)  # [B, Nv, Ct, Nt]
+    out = {"out": out.numpy(), "images": images.numpy(), "cond": cond.numpy()}
+    out.update(sd_np(tok, "w."))
+    np.savez_compressed(os.path.join(HERE, "sf3d_dino.npz"), **out)
+    print("sf3d_dino:", out["out"].shape, len(out) - 3, "tensors")
+
+
+def make_backbone():
+    from sf3d.models.transformers.backbone import TwoStreamInterleaveTransformer
+
+    torch.manual_seed(0)
+    bb = TwoStreamInterleaveTransformer(dict(num_attention_heads=2, attention_head_dim=32, raw_triplane_channels=64,
+                                             triplane_channels=64, raw_image_channels=64, num_latents=8, num_blocks=2,
+                                             num_basic_blocks=2, cross_attention_dim=64)).eval()
+    randomize(bb, 5)
+    g = torch.Generator().manual_seed(6)
+    tokens = torch.randn(1, 64, 48, generator=g)
+    img = torch.randn(1, 17, 64, generator=g)
+    with torch.no_grad():
+        y = bb(tokens, encoder_hidden_states=img, modulation_cond=None)
+    out = {"out": y.numpy(), "tokens": tokens.numpy(), "image_tokens": img.numpy()}
+    out.update(sd_np(bb, "w."))
+    np.savez_compressed(os.path.join(HERE, "sf3d_backbone.npz"), **out)
+    print("sf3d_backbone:", y.shape, len(out) - 3, "tensors")
+
+
+def make_post():
+    from sf3d.models.network import PixelShuffleUpsampleNetwork
+
+    torch.manual_seed(0)
+    net = PixelShuffleUpsampleNetwork(dict(in_channels=64, out_channels=40, scale_factor=4, conv_layers=4)).eval()
+    randomize(net, 7)
+    x = torch.randn(1, 3, 64, 4, 4, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        y = net(x)
+    out = {"out": y.numpy(), "x": x.numpy()}
+    out.update(sd_np(net, "w."))
+    np.savez_compressed(os.path.join(HERE, "sf3d_post.npz"), **out)
+    print("sf3d_post:", y.shape)
+
+
+DECODER_CFG = dict(
+    in_channels=120, n_neurons=64, activation="silu",
+    heads=[dict(name="density", out_channels=1, out_bias=-1.0, n_hidden_layers=2, output_activation="trunc_exp"),
+           dict(name="features", out_channels=3, out_bias=0.0, n_hidden_layers=3, output_activation="sigmoid"),
+           dict(name="perturb_normal", out_channels=3, out_bias=0.0, n_hidden_layers=3,
+                output_activation="normalize_channel_last"),
+           # HeadSpec defaults (network.py:139-145) written out: the omegaconf stand-in does not merge nested dataclasses
+           dict(name="vertex_offset", out_channels=3, out_bias=0.0, n_hidden_layers=2, output_activation=None)])
+
+
+def make_decoder():
+    """query_triplane is a method of SF3D that only touches self.cfg.radius; call it unbound on a stub so the
+    system module's heavy constructor (DINOv2 download, tets file, CLIP) is not needed."""
+    sys.modules.setdefault("open_clip", types.ModuleType("open_clip"))
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.transforms.Normalize = object
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tv.transforms)
+    from sf3d.models.network import MaterialMLP
+    from sf3d.system import SF3D
+
+    torch.manual_seed(0)
+    dec = MaterialMLP(DECODER_CFG).eval()
+    randomize(dec, 9, scale=None)
+    g = torch.Generator().manual_seed(10)
+    planes = torch.randn(3, 40, 24, 24, generator=g)
+    pts = (torch.rand(4096, 3, generator=g) * 2 - 1) * 0.87
+    pts[:8] = torch.tensor([[0.87, 0.87, 0.87], [-0.87, -0.87, -0.87], [0.87, -0.87, 0.0], [0.0, 0.0, 0.0],
+                            [0.9, 0.2, -0.95], [-1.2, 0.0, 0.3], [0.435, -0.435, 0.87], [-0.87, 0.5, 0.1]])
+    stub = types.SimpleNamespace(cfg=types.SimpleNamespace(radius=0.87))
+    with torch.no_grad():
+        feats = SF3D.query_triplane(stub, pts, planes)  # [1, N, 120]
+        dec_all = dec(feats)
+    out = {"planes": planes.numpy(), "points": pts.numpy(), "feats": feats[0].numpy()}
+    for k, v in dec_all.items():
+        out["out." + k] = v[0].numpy()
+    out.update(sd_np(dec, "w."))
+    np.savez_compressed(os.path.join(HERE, "sf3d_decoder.npz"), **out)
+    print("sf3d_decoder:", {k: v.shape for k, v in dec_all.items()})
+
+
+def make_mtet():
+    from sf3d.models.isosurface import MarchingTetrahedraHelper
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from sculptmate_amd.sf3d.tets import kuhn_tet_grid  # the stand-in grid (the shipped 160_tets.npz is absent)
+
+    res = 10
+    verts, idx = kuhn_tet_grid(res)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "%d_tets.npz" % res)
+        np.savez(path, vertices=verts, indices=idx)
+        helper = MarchingTetrahedraHelper(res, path)
+    g = torch.Generator().manual_seed(11)
+    p = torch.from_numpy(verts) - 0.5
+    sdf = (0.36 - p.norm(dim=-1) + 0.08 * torch.sin(9 * p[:, 0]) * torch.cos(7 * p[:, 1]))[:, None]
+    sdf = sdf + 0.01 * torch.randn(sdf.shape, generator=g)
+    deform = torch.randn(verts.shape[0], 3, generator=g)
+    with torch.no_grad():
+        mesh = helper(sdf.clone(), deform.clone())
+        mesh_nodef = helper(sdf.clone(), None)
+    out = dict(res=res, vertices=verts, indices=idx, sdf=sdf.numpy(), deform=deform.numpy(),
+               v_pos=mesh.v_pos.numpy(), faces=mesh.t_pos_idx.numpy(),
+               grid_vertices=mesh.extras["grid_vertices"].numpy(), tet_edges=mesh.extras["tet_edges"].numpy(),
+               v_pos_nodef=mesh_nodef.v_pos.numpy(), faces_nodef=mesh_nodef.t_pos_idx.numpy(),
+               center_index=np.int64(helper.center_indices.item()), boundary_indices=helper.boundary_indices.numpy())
+    np.savez_compressed(os.path.join(HERE, "sf3d_mtet.npz"), **out)
+    print("sf3d_mtet:", mesh.v_pos.shape, mesh.t_pos_idx.shape, "all_edges", out["tet_edges"].shape)
+
+
+def make_camera():
+    from sf3d.models.camera import LinearCameraEmbedder
+    from sf3d.utils import create_intrinsic_from_fov_deg, default_cond_c2w
+
+    torch.manual_seed(0)
+    emb = LinearCameraEmbedder(dict(in_channels=25, out_channels=48,
+                                    conditions=["c2w_cond", "intrinsic_normed_cond"])).eval()
+    randomize(emb, 12)
+    c2w = default_cond_c2w(1.6)
+    intr, intr_n = create_intrinsic_from_fov_deg(40.0, 512, 512)
+    with torch.no_grad():
+        e = emb(c2w_cond=c2w.view(1, 1, 4, 4), intrinsic_normed_cond=intr_n.view(1, 1, 3, 3))
+    out = dict(c2w=c2w.numpy(), intrinsic=intr.numpy(), intrinsic_normed=intr_n.numpy(), embedding=e.numpy())
+    out.update(sd_np(emb, "w."))
+    np.savez_compressed(os.path.join(HERE, "sf3d_camera.npz"), **out)
+    print("sf3d_camera:", e.shape)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dino", "backbone", "post", "decoder", "mtet", "camera"]
+    for w in which:
+        globals()["make_" + w]()
