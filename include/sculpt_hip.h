@@ -72,6 +72,17 @@ int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *
                           float *density, float *features, float *density_act, float *color,
                           sculpt_stream_t stream);
 
+/* Same with sampling flags.  SCULPT_QUERY_ALIGN_CORNERS: grid_sample(align_corners=True), as
+ * SF3D.query_triplane does (StableFast/sf3d/system.py:170-199) followed by one MaterialMLP head
+ * (StableFast/sf3d/models/network.py:148-210) packed into the (density | features) 4-row output layer:
+ * a 1-channel head in row 0 (density_act = exp(out + bias) == trunc_exp), a 3-channel head in rows 1..3
+ * (color = sigmoid). */
+#define SCULPT_QUERY_ALIGN_CORNERS 1u
+int sculpt_triplane_query_ex(const float *planes, int C, int H, int W, const void *mlp_packed,
+                             int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,
+                             unsigned flags, float *density, float *features, float *density_act, float *color,
+                             sculpt_stream_t stream);
+
 /* Dense density grid over the lattice slab ix in [x_begin,x_end), flat order ix*R*R + iy*R + iz
  * (isosurface.py:34-37), in two launches:
  *
@@ -134,6 +145,7 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsig
 #define SCULPT_EPI_NONE 0
 #define SCULPT_EPI_GELU 1   /* out = gelu_erf(acc + bias) */
 #define SCULPT_EPI_GEGLU 2  /* W holds [2*N][K]: out[:, n] = (acc_n + b_n) * gelu_erf(acc_{N+n} + b_{N+n}) */
+#define SCULPT_EPI_RELU 3   /* out = max(acc + bias, 0)  (SF3D PixelShuffleUpsampleNetwork convs) */
 
 /* out[M][N] = epi(A[M][K] . W[N][K]^T + bias[N]) (+ residual[M][N], fp32)
  *   A, W bf16 (K contiguous); bias fp32 or NULL; residual fp32 [M][ldr] or NULL;
@@ -186,10 +198,12 @@ int sculpt_transpose_add(const float *x_tc, const float *residual_ct, float *out
 int sculpt_resize_aa_bilinear(const float *in_hwc, int Hin, int Win, int C, float *tmp, float *out_hwc, int Hout,
                               int Wout, sculpt_stream_t stream);
 
-/* ViT front end (tokenizers/image.py:48 + HF ViTEmbeddings): normalise (x-mean)/std and cut
- * [3][S][S] fp32 image into patch rows [S/P * S/P][3*P*P] bf16 (conv16/16 stride 16 as a GEMM) */
+/* ViT front end (tokenizers/image.py:48 + HF ViTEmbeddings; DINOv2: sf3d/models/tokenizers/image.py:86 +
+ * dinov2.py:176-210): normalise (x-mean)/std and cut the [S][S][3] fp32 image into patch rows
+ * [floor(S/P)^2][ld] (the stride-P patch convolution as a GEMM; trailing S - floor(S/P)*P pixels ignored like the
+ * convolution does); columns 3*P*P..ld-1 are written as zero (K padding; ld <= 0 means 3*P*P) */
 int sculpt_vit_patchify(const float *image_hwc, int S, int P, const float *mean3_host, const float *std3_host,
-                        uint16_t *patches, float *patches_f32 /* either may be NULL */, sculpt_stream_t stream);
+                        uint16_t *patches, float *patches_f32 /* either may be NULL */, int ld, sculpt_stream_t stream);
 /* tokens[0] = cls + pos[0]; tokens[1+i] = patch_out[i] + pos[1+i]  (fp32 residual stream) */
 int sculpt_vit_assemble(const float *patch_out, const float *cls, const float *pos, float *tokens,
                         int n_patches, int hidden, sculpt_stream_t stream);
@@ -216,6 +230,40 @@ int sculpt_bake_interpolate(const float *attr, size_t nv, const int *idx, size_t
 void rasterize_cpu(const float *uv, size_t nv, const int *idx, size_t nf, long long res, float *out);
 void interpolate_cpu(const float *attr, size_t nv, const int *idx, size_t nf, const float *rast, long long res,
                      float *out);
+
+/* StableFast-3D networks (BASELINE config 4).
+ *
+ * PixelShuffleUpsampleNetwork (StableFast/sf3d/models/network.py:29-75): each 3x3/pad-1 Conv2d is
+ *   sculpt_im2col3x3 (channel-last activations [n][S*S][C] -> rows [n*S*S][9*C], k = (ky*3+kx)*C + c,
+ *   elements of 2 (bf16) or 4 (f32) bytes) followed by sculpt_gemm_bf16 with W reordered to [Cout][ky][kx][Cin]
+ *   (SCULPT_EPI_RELU for all but the last); sculpt_pixel_shuffle = nn.PixelShuffle(r) of the last GEMM's fp32
+ *   output [n*S*S][ldg] (column co*r*r + dy*r + dx) into planes [n][Co][S*r][S*r]. */
+int sculpt_im2col3x3(const void *in, int n_planes, int S, int C, int elem_bytes, void *out, sculpt_stream_t stream);
+int sculpt_pixel_shuffle(const float *g, int ldg, float *planes, int n_planes, int S, int Co, int r,
+                         sculpt_stream_t stream);
+
+/* F.normalize(x, dim=-1, p=2, eps) on n rows of 3 (the "normalize_channel_last" head activation, network.py:129-130;
+ * may run in place) */
+int sculpt_normalize_rows3(const float *x, int64_t n, float eps, float *y, sculpt_stream_t stream);
+
+/* MarchingTetrahedraHelper (StableFast/sf3d/models/isosurface.py:108-229).
+ *   sculpt_mtet_deform: out = grid_vertices + scale * tanh(offsets), scale = (1-0)/resolution (:108-115, 211-216).
+ *   Static per-grid tables (host, once): tets i32 [Nt][4]; edges i32 [Ne][2] = the lexicographically sorted unique
+ *   undirected edges (a < b) of the grid (== the reference's all_edges, :117-131); tet_edges i32 [Nt][6] = edge
+ *   id of each tet's edges in base_tet_edges order (0-1, 0-2, 0-3, 1-2, 1-3, 2-3; :64-69).
+ *   sculpt_mtet_count: scans -> number of vertices (sign-changing edges, sdf > 0 is "inside", :143) and faces; keeps
+ *   offsets in `workspace` (sculpt_mtet_workspace_bytes).  sculpt_mtet_emit: vertices f32 [Nv][3] =
+ *   (pos_a * (-s_b/(s_a-s_b)) + pos_b * (s_a/(s_a-s_b))) * vert_mul + vert_add in the reference's vertex order
+ *   (crossing edges sorted), faces i64 [Nf][3] in the reference's order (one-triangle tets, then two-triangle tets).
+ *   Bit-identical to the reference given the same pos/sdf. */
+int sculpt_mtet_deform(const float *grid_vertices, const float *offsets, int64_t n_vertices, float scale, float *out,
+                       sculpt_stream_t stream);
+size_t sculpt_mtet_workspace_bytes(int64_t n_edges, int64_t n_tets);
+int sculpt_mtet_count(const float *sdf, const int32_t *tets, int64_t n_tets, const int32_t *edges, int64_t n_edges,
+                      void *workspace, int64_t *n_verts_host, int64_t *n_faces_host, sculpt_stream_t stream);
+int sculpt_mtet_emit(const float *pos, const float *sdf, const int32_t *tets, int64_t n_tets, const int32_t *edges,
+                     int64_t n_edges, const int32_t *tet_edges, void *workspace, float vert_mul, float vert_add,
+                     float *verts, int64_t *faces, sculpt_stream_t stream);
 
 /* StableFast geometry tail:
  *   dilate_fill (sf3d/models/utils.py:96-133): img f32 [3][H][W], mask f32 [H][W]; scratch 8*H*W floats

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sculpt_mlp_packed_bytes": (_sz, [_i, _i]),
     "sculpt_mlp_pack": (_i, [_pp, _pp, _i, _vp, _vp, _sz]),
     "sculpt_triplane_query": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_triplane_query_ex": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _u, _vp, _vp, _vp, _vp, _vp]),
     "sculpt_density_grid_workspace_bytes": (_sz, [_i, _i]),
     "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
@@ -51,7 +52,7 @@ SIGNATURES = {
     "sculpt_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp]),
     "sculpt_groupnorm_tokens": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sculpt_transpose_add": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
-    "sculpt_vit_patchify": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_vit_patchify": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "sculpt_vit_assemble": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sculpt_upsample_scatter": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "sculpt_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
@@ -62,6 +63,13 @@ SIGNATURES = {
     "sculpt_bake_workspace_bytes": (_sz, [_i]),
     "sculpt_bake_rasterize": (_i, [_vp, _sz, _vp, _sz, _i, _vp, _vp, _vp]),
     "sculpt_bake_interpolate": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _vp, _vp]),
+    "sculpt_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "sculpt_pixel_shuffle": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sculpt_normalize_rows3": (_i, [_vp, _i64, _f, _vp, _vp]),
+    "sculpt_mtet_deform": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
+    "sculpt_mtet_workspace_bytes": (_sz, [_i64, _i64]),
+    "sculpt_mtet_count": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _pi64, _pi64, _vp]),
+    "sculpt_mtet_emit": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "rasterize_cpu": (None, [_vp, _sz, _vp, _sz, ctypes.c_longlong, _vp]),
     "interpolate_cpu": (None, [_vp, _sz, _vp, _sz, _vp, ctypes.c_longlong, _vp]),
 }
@@ -78,7 +86,8 @@ MC_SLAB = 8
 MC_SLAB_HALO_LOW = 16
 ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
-EPI_NONE, EPI_GELU, EPI_GEGLU = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_RELU = 0, 1, 2, 3
+QUERY_ALIGN_CORNERS = 1
 
 
 def last_error():

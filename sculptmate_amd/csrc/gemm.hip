@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + (g.bias ? g.bias[n + r] : 0.f);
                     if (EPI == SCULPT_EPI_GELU) v = gelu_erf(v);
+                    if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
                     o[r] = v;
                 }
                 if (g.residual) {
@@ -268,6 +269,9 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
         if (epilogue == SCULPT_EPI_GELU) {
             if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 64>), dim3(N / 64, mt), dim3(256), 0, st, g);
             else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 128>), dim3(N / 128, mt), dim3(256), 0, st, g);
+        } else if (epilogue == SCULPT_EPI_RELU) {
+            if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_RELU, 64>), dim3(N / 64, mt), dim3(256), 0, st, g);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_RELU, 128>), dim3(N / 128, mt), dim3(256), 0, st, g);
         } else if (epilogue == SCULPT_EPI_NONE) {
             if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64>), dim3(N / 64, mt), dim3(256), 0, st, g);
             else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128>), dim3(N / 128, mt), dim3(256), 0, st, g);

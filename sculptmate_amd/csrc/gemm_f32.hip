@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[i][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f);
                         if (EPI == SCULPT_EPI_GELU) v = gelu_erf_exact(v);
+                        if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
                         o[r] = v;
                     }
                     if (g.residual) {
@@ -196,6 +197,8 @@ int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const floa
         hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_GEGLU>, dim3(N / 64, mt), dim3(256), 0, st, g);
     } else if (epilogue == SCULPT_EPI_GELU) {
         hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_GELU>, dim3(cdiv(N, FBW), mt), dim3(256), 0, st, g);
+    } else if (epilogue == SCULPT_EPI_RELU) {
+        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_RELU>, dim3(cdiv(N, FBW), mt), dim3(256), 0, st, g);
     } else {
         SC_REQUIRE(epilogue == SCULPT_EPI_NONE, "gemm_f32: unknown epilogue %d", epilogue);
         hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_NONE>, dim3(cdiv(N, FBW), mt), dim3(256), 0, st, g);

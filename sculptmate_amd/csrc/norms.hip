@@ -164,20 +164,24 @@ __global__ __launch_bounds__(256) void transpose_add_kernel(const float *__restr
     }
 }
 
-// image [S][S][3] fp32 (HWC, 0..1) -> patches [ (S/P)^2 ][3*P*P] bf16, column = c*P*P + py*P + px
-__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, int S, int P, float m0, float m1,
+// image [S][S][3] fp32 (HWC, 0..1) -> patches [ (S/P)^2 ][ld >= 3*P*P], column = c*P*P + py*P + px, columns
+// 3*P*P..ld-1 zero (K padding for the GEMM); pixels beyond (S/P)*P are ignored like a stride-P convolution does
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, int S, int P, int ld, float m0, float m1,
                                                        float m2, float s0, float s1, float s2,
                                                        uint16_t *__restrict__ patches, float *__restrict__ patches_f32) {
     const int np = S / P, cols = 3 * P * P;
-    const long total = (long)np * np * cols;
+    const long total = (long)np * np * ld;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int col = (int)(i % cols);
-        const int patch = (int)(i / cols);
-        const int c = col / (P * P), py = (col / P) % P, px = col % P;
-        const int gy = (patch / np) * P + py, gx = (patch % np) * P + px;
-        const float v = img[((long)gy * S + gx) * 3 + c];
-        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        const float o = (v - mean) / sd;
+        const int col = (int)(i % ld);
+        const int patch = (int)(i / ld);
+        float o = 0.f;
+        if (col < cols) {
+            const int c = col / (P * P), py = (col / P) % P, px = col % P;
+            const int gy = (patch / np) * P + py, gx = (patch % np) * P + px;
+            const float v = img[((long)gy * S + gx) * 3 + c];
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            o = (v - mean) / sd;
+        }
         if (patches) patches[i] = f32_to_bf16(o);
         if (patches_f32) patches_f32[i] = o;
     }
@@ -264,11 +268,13 @@ int sculpt_transpose_add(const float *x_tc, const float *residual_ct, float *out
 }
 
 int sculpt_vit_patchify(const float *image_hwc, int S, int P, const float *mean3_host, const float *std3_host,
-                        uint16_t *patches, float *patches_f32, sculpt_stream_t stream) {
+                        uint16_t *patches, float *patches_f32, int ld, sculpt_stream_t stream) {
     SC_REQUIRE(image_hwc && mean3_host && std3_host && (patches || patches_f32), "vit_patchify: null argument");
-    SC_REQUIRE(P > 0 && S % P == 0, "vit_patchify: S=%d not divisible by P=%d", S, P);
-    const long total = (long)(S / P) * (S / P) * 3 * P * P;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), image_hwc, S, P,
+    SC_REQUIRE(P > 0 && S >= P, "vit_patchify: bad S=%d P=%d", S, P);
+    if (ld <= 0) ld = 3 * P * P;
+    SC_REQUIRE(ld >= 3 * P * P, "vit_patchify: ld=%d < 3*P*P", ld);
+    const long total = (long)(S / P) * (S / P) * ld;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), image_hwc, S, P, ld,
                        mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2], patches, patches_f32);
     SC_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,400 @@
+// StableFast-3D specific kernels for gfx950 (BASELINE config 4).
+//
+// Replaces (reference file:line):
+//   PixelShuffleUpsampleNetwork.forward   StableFast/sf3d/models/network.py:29-75
+//       3x3 convolutions as im2col (this file) + the bf16 MFMA GEMM (gemm.hip, ReLU epilogue) and the
+//       PixelShuffle(4) scatter into the fp32 triplane layout [3][Co][4S][4S].
+//   MarchingTetrahedraHelper.forward/_forward   StableFast/sf3d/models/isosurface.py:108-229
+//       The reference sorts and uniques the edges of the sign-changing tetrahedra on every call
+//       (torch.unique(dim=0), :152-166).  The tet grid is static, so the sorted unique edge list of the
+//       WHOLE grid (== `all_edges`, :117-131) and every tet's six edge ids are tables built once per
+//       grid (sculptmate_amd/sf3d/tets.py); the crossing edges of a call are a subsequence of that list in
+//       the same lexicographic order, so vertex id = exclusive scan of the crossing flags and nothing is
+//       sorted at run time.  Face order = all one-triangle tets in tet order, then all two-triangle tets
+//       (:190-207): two more scans.  Output is bit-identical to the reference given the same sdf / grid.
+//
+// All of this is HBM-bound index work: coalesced int32 streams, ballot/popcount block scans.
+#include <math.h>
+
+#include "common.h"
+
+namespace sculpt {
+
+// ------------------------------------------------------------------------------------------------
+// im2col for a 3x3 / pad 1 convolution over n planes of S x S pixels, channel-last activations.
+// in  [n][S*S][C] (elements of EB bytes), out [n*S*S][9*C], k = (ky*3 + kx)*C + c.  16-byte chunks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, int n,
+                                                        int S, int chunks_per_pixel) {
+    const long total = (long)n * S * S * 9 * chunks_per_pixel;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks_per_pixel);
+        long r = i / chunks_per_pixel;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int x = (int)(r % S);
+        r /= S;
+        const int y = (int)(r % S);
+        const int pl = (int)(r / S);
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (yy >= 0 && yy < S && xx >= 0 && xx < S) v = in[(((long)pl * S + yy) * S + xx) * chunks_per_pixel + c];
+        out[i] = v;
+    }
+}
+
+// g [n*S*S][ldg] fp32, column = co*r*r + dy*r + dx  ->  planes [n][Co][S*r][S*r]   (nn.PixelShuffle)
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float *__restrict__ g, int ldg, float *__restrict__ planes,
+                                                            int n, int S, int Co, int r) {
+    const int SR = S * r;
+    const long total = (long)n * Co * SR * SR;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % SR);
+        long q = i / SR;
+        const int Y = (int)(q % SR);
+        q /= SR;
+        const int co = (int)(q % Co);
+        const int pl = (int)(q / Co);
+        const int y = Y / r, dy = Y - y * r, x = X / r, dx = X - x * r;
+        planes[i] = g[(((long)pl * S + y) * S + x) * ldg + (co * r + dy) * r + dx];
+    }
+}
+
+// F.normalize(x, dim=-1, p=2, eps) on rows of 3  (sf3d/models/utils.py:69-72; network.py:129-130)
+__global__ __launch_bounds__(256) void normalize3_kernel(const float *__restrict__ x, long n, float eps, float *__restrict__ y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+        const float d = fmaxf(sqrtf(a * a + b * b + c * c), eps);
+        y[3 * i] = a / d;
+        y[3 * i + 1] = b / d;
+        y[3 * i + 2] = c / d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// marching tetrahedra
+// ------------------------------------------------------------------------------------------------
+__constant__ signed char MT_TRI[16][6] = {
+    {-1, -1, -1, -1, -1, -1}, {1, 0, 2, -1, -1, -1}, {4, 0, 3, -1, -1, -1}, {1, 4, 2, 1, 3, 4},
+    {3, 1, 5, -1, -1, -1},    {2, 3, 0, 2, 5, 3},    {1, 4, 0, 1, 5, 4},    {4, 2, 5, -1, -1, -1},
+    {4, 5, 2, -1, -1, -1},    {4, 1, 0, 4, 5, 1},    {3, 2, 0, 3, 5, 2},    {1, 3, 5, -1, -1, -1},
+    {4, 1, 2, 4, 3, 1},       {3, 0, 4, -1, -1, -1}, {2, 0, 1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1}};
+__constant__ unsigned char MT_NTRI[16] = {0, 1, 1, 2, 1, 2, 2, 1, 1, 2, 2, 1, 2, 1, 1, 0};
+
+static constexpr int MT_BLOCK = 256;
+static constexpr int MT_ITEMS = 8;                      // items per thread
+static constexpr int MT_TILE = MT_BLOCK * MT_ITEMS;     // items per block
+
+struct MtHeader {
+    long long n_verts, n_ones, n_twos;
+};
+
+// keeps the compiler from contracting a*b+c into an fma across this value (torch CPU rounds each op)
+__device__ __forceinline__ float rounded(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+__global__ __launch_bounds__(256) void mtet_deform_kernel(const float *__restrict__ gv, const float *__restrict__ off,
+                                                          long n3, float scale, float *__restrict__ out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long)gridDim.x * blockDim.x)
+        out[i] = gv[i] + rounded(scale * tanhf(off[i]));
+}
+
+__device__ __forceinline__ int tet_index(const float *__restrict__ sdf, const int4 t) {
+    return (sdf[t.x] > 0.f ? 1 : 0) | (sdf[t.y] > 0.f ? 2 : 0) | (sdf[t.z] > 0.f ? 4 : 0) | (sdf[t.w] > 0.f ? 8 : 0);
+}
+
+// block-wide sum of a per-thread value (256 threads)
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    unsigned long long s = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return s;
+}
+
+// exclusive prefix of a per-thread value over the block (256 threads); returns prefix, *total = block sum
+__device__ __forceinline__ unsigned long long block_excl_u64(unsigned long long v, unsigned long long *sh,
+                                                             unsigned long long *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) base += sh[i];
+        tot += sh[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// pass 1: per block counts.  edges: crossing flags (low word).  tets: ones (low 32) | twos (high 32).
+__global__ __launch_bounds__(MT_BLOCK) void mtet_count_edges_kernel(const float *__restrict__ sdf, const int2 *__restrict__ edges,
+                                                                    long ne, unsigned long long *__restrict__ bsum) {
+    __shared__ unsigned long long sh[4];
+    const long base = (long)blockIdx.x * MT_TILE;
+    unsigned long long c = 0;
+#pragma unroll
+    for (int k = 0; k < MT_ITEMS; ++k) {
+        const long e = base + (long)k * MT_BLOCK + threadIdx.x;
+        if (e < ne) {
+            const int2 ab = edges[e];
+            c += ((sdf[ab.x] > 0.f) != (sdf[ab.y] > 0.f)) ? 1 : 0;
+        }
+    }
+    c = block_sum_u64(c, sh);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(MT_BLOCK) void mtet_count_tets_kernel(const float *__restrict__ sdf, const int4 *__restrict__ tets,
+                                                                   long nt, unsigned long long *__restrict__ bsum) {
+    __shared__ unsigned long long sh[4];
+    const long base = (long)blockIdx.x * MT_TILE;
+    unsigned long long c = 0;
+#pragma unroll
+    for (int k = 0; k < MT_ITEMS; ++k) {
+        const long t = base + (long)k * MT_BLOCK + threadIdx.x;
+        if (t < nt) {
+            const int n = MT_NTRI[tet_index(sdf, tets[t])];
+            c += (n == 1) ? 1ull : (n == 2 ? (1ull << 32) : 0ull);
+        }
+    }
+    c = block_sum_u64(c, sh);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = c;
+}
+
+// pass 2: one block turns the per-block sums of both streams into exclusive offsets and the totals
+__global__ __launch_bounds__(MT_BLOCK) void mtet_scan_blocks_kernel(unsigned long long *__restrict__ ebs, int neb,
+                                                                    unsigned long long *__restrict__ tbs, int ntb,
+                                                                    MtHeader *__restrict__ hd) {
+    __shared__ unsigned long long sh[4];
+    for (int which = 0; which < 2; ++which) {
+        unsigned long long *a = which ? tbs : ebs;
+        const int n = which ? ntb : neb;
+        unsigned long long carry = 0;  // packed halves never overflow: counts < 2^31
+        for (int b0 = 0; b0 < n; b0 += MT_BLOCK) {
+            const int i = b0 + threadIdx.x;
+            const unsigned long long v = i < n ? a[i] : 0ull;
+            unsigned long long tot;
+            const unsigned long long ex = block_excl_u64(v, sh, &tot);
+            if (i < n) a[i] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) {
+            if (which) {
+                hd->n_ones = (long long)(carry & 0xffffffffull);
+                hd->n_twos = (long long)(carry >> 32);
+            } else {
+                hd->n_verts = (long long)carry;
+            }
+        }
+    }
+}
+
+// pass 3a: vertex id of every grid edge (-1 if it does not cross) and the vertex itself.
+// Items are assigned thread-major (thread t owns MT_ITEMS consecutive edges) so ids follow edge order.
+__global__ __launch_bounds__(MT_BLOCK) void mtet_emit_verts_kernel(const float *__restrict__ pos, const float *__restrict__ sdf,
+                                                                   const int2 *__restrict__ edges, long ne,
+                                                                   const unsigned long long *__restrict__ bofs,
+                                                                   float vmul, float vadd, int *__restrict__ edge_vid,
+                                                                   float *__restrict__ verts) {
+    __shared__ unsigned long long sh[4];
+    const long base = (long)blockIdx.x * MT_TILE + (long)threadIdx.x * MT_ITEMS;
+    int2 ab[MT_ITEMS];
+    unsigned flags = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < MT_ITEMS; ++k) {
+        const long e = base + k;
+        if (e < ne) {
+            ab[k] = edges[e];
+            if ((sdf[ab[k].x] > 0.f) != (sdf[ab[k].y] > 0.f)) {
+                flags |= 1u << k;
+                ++cnt;
+            }
+        }
+    }
+    unsigned long long tot;
+    long id = (long)(bofs[blockIdx.x] + block_excl_u64(cnt, sh, &tot));
+#pragma unroll
+    for (int k = 0; k < MT_ITEMS; ++k) {
+        const long e = base + k;
+        if (e >= ne) break;
+        if (!(flags & (1u << k))) {
+            edge_vid[e] = -1;
+            continue;
+        }
+        edge_vid[e] = (int)id;
+        // isosurface.py:168-176: sdf pair (s_a, -s_b); weights = flip / sum; verts = pos_a*w_a + pos_b*w_b
+        const float sa = sdf[ab[k].x], sb = -sdf[ab[k].y];
+        const float den = sa + sb;
+        const float wa = sb / den, wb = sa / den;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float pa = pos[3L * ab[k].x + c], pb = pos[3L * ab[k].y + c];
+            float v = rounded(pa * wa) + rounded(pb * wb);
+            // scale_tensor(v, (0,1), bbox): v * (hi - lo) + lo, each op rounded (sf3d/system.py:161-163)
+            v = rounded(rounded(v) * vmul) + vadd;
+            verts[3 * id + c] = v;
+        }
+        ++id;
+    }
+}
+
+// pass 3b: faces.  One-triangle tets first (tet order), then two-triangle tets.
+__global__ __launch_bounds__(MT_BLOCK) void mtet_emit_faces_kernel(const float *__restrict__ sdf, const int4 *__restrict__ tets,
+                                                                   long nt, const int *__restrict__ tet_edges,
+                                                                   const int *__restrict__ edge_vid,
+                                                                   const unsigned long long *__restrict__ bofs,
+                                                                   const MtHeader *__restrict__ hd, long long *__restrict__ faces) {
+    __shared__ unsigned long long sh[4];
+    const long base = (long)blockIdx.x * MT_TILE + (long)threadIdx.x * MT_ITEMS;
+    unsigned char ti[MT_ITEMS];
+    unsigned long long cnt = 0;
+#pragma unroll
+    for (int k = 0; k < MT_ITEMS; ++k) {
+        const long t = base + k;
+        ti[k] = 0;
+        if (t < nt) {
+            ti[k] = (unsigned char)tet_index(sdf, tets[t]);
+            const int n = MT_NTRI[ti[k]];
+            cnt += (n == 1) ? 1ull : (n == 2 ? (1ull << 32) : 0ull);
+        }
+    }
+    unsigned long long tot;
+    const unsigned long long ex = bofs[blockIdx.x] + block_excl_u64(cnt, sh, &tot);
+    long r1 = (long)(ex & 0xffffffffull), r2 = (long)(ex >> 32);
+    const long n_ones = hd->n_ones;
+#pragma unroll
+    for (int k = 0; k < MT_ITEMS; ++k) {
+        const long t = base + k;
+        if (t >= nt) break;
+        const int n = MT_NTRI[ti[k]];
+        if (n == 0) continue;
+        int vid[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) vid[j] = edge_vid[tet_edges[6 * t + j]];
+        long f = (n == 1) ? r1 : n_ones + 2 * r2;
+        for (int q = 0; q < 3 * n; ++q) faces[3 * f + q] = vid[MT_TRI[ti[k]][q]];
+        if (n == 1) ++r1; else ++r2;
+    }
+}
+
+}  // namespace sculpt
+
+using namespace sculpt;
+
+extern "C" {
+
+int sculpt_im2col3x3(const void *in, int n_planes, int S, int C, int elem_bytes, void *out, sculpt_stream_t stream) {
+    SC_REQUIRE(in && out, "im2col3x3: null argument");
+    SC_REQUIRE(elem_bytes == 2 || elem_bytes == 4, "im2col3x3: elem_bytes must be 2 (bf16) or 4 (f32)");
+    SC_REQUIRE(n_planes >= 1 && S >= 1 && C >= 1 && (C * elem_bytes) % 16 == 0, "im2col3x3: bad shape n=%d S=%d C=%d", n_planes, S, C);
+    const int cpp = C * elem_bytes / 16;
+    const long total = (long)n_planes * S * S * 9 * cpp;
+    const int grid = (int)std::min<long>(cdiv(total, 256), (long)num_cus() * 32);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const uint4 *>(in),
+                       reinterpret_cast<uint4 *>(out), n_planes, S, cpp);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_pixel_shuffle(const float *g, int ldg, float *planes, int n_planes, int S, int Co, int r, sculpt_stream_t stream) {
+    SC_REQUIRE(g && planes, "pixel_shuffle: null argument");
+    SC_REQUIRE(n_planes >= 1 && S >= 1 && Co >= 1 && r >= 1 && ldg >= Co * r * r, "pixel_shuffle: bad shape");
+    const long total = (long)n_planes * Co * S * r * S * r;
+    const int grid = (int)std::min<long>(cdiv(total, 256), (long)num_cus() * 32);
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid), dim3(256), 0, as_stream(stream), g, ldg, planes, n_planes, S, Co, r);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_normalize_rows3(const float *x, int64_t n, float eps, float *y, sculpt_stream_t stream) {
+    SC_REQUIRE(x && y, "normalize_rows3: null argument");
+    if (n <= 0) return 0;
+    const int grid = (int)std::min<long>(cdiv(n, 256), (long)num_cus() * 32);
+    hipLaunchKernelGGL(normalize3_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, (long)n, eps, y);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_mtet_deform(const float *grid_vertices, const float *offsets, int64_t n_vertices, float scale, float *out,
+                       sculpt_stream_t stream) {
+    SC_REQUIRE(grid_vertices && offsets && out, "mtet_deform: null argument");
+    if (n_vertices <= 0) return 0;
+    const long n3 = 3L * n_vertices;
+    const int grid = (int)std::min<long>(cdiv(n3, 256), (long)num_cus() * 32);
+    hipLaunchKernelGGL(mtet_deform_kernel, dim3(grid), dim3(256), 0, as_stream(stream), grid_vertices, offsets, n3, scale, out);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline size_t mt_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t sculpt_mtet_workspace_bytes(int64_t n_edges, int64_t n_tets) {
+    const size_t neb = (size_t)cdiv(n_edges, MT_TILE), ntb = (size_t)cdiv(n_tets, MT_TILE);
+    return mt_align(sizeof(MtHeader)) + mt_align(neb * 8) + mt_align(ntb * 8) + mt_align((size_t)n_edges * 4);
+}
+
+struct MtWs {
+    MtHeader *hd;
+    unsigned long long *ebs, *tbs;
+    int *edge_vid;
+    int neb, ntb;
+};
+static MtWs mt_ws(void *ws, int64_t ne, int64_t nt) {
+    MtWs w;
+    w.neb = cdiv(ne, MT_TILE);
+    w.ntb = cdiv(nt, MT_TILE);
+    unsigned char *p = reinterpret_cast<unsigned char *>(ws);
+    w.hd = reinterpret_cast<MtHeader *>(p); p += mt_align(sizeof(MtHeader));
+    w.ebs = reinterpret_cast<unsigned long long *>(p); p += mt_align((size_t)w.neb * 8);
+    w.tbs = reinterpret_cast<unsigned long long *>(p); p += mt_align((size_t)w.ntb * 8);
+    w.edge_vid = reinterpret_cast<int *>(p);
+    return w;
+}
+
+int sculpt_mtet_count(const float *sdf, const int32_t *tets, int64_t n_tets, const int32_t *edges, int64_t n_edges,
+                      void *workspace, int64_t *n_verts_host, int64_t *n_faces_host, sculpt_stream_t stream) {
+    SC_REQUIRE(sdf && tets && edges && workspace && n_verts_host && n_faces_host, "mtet_count: null argument");
+    SC_REQUIRE(n_tets >= 1 && n_edges >= 1 && n_tets < (1LL << 31) && n_edges < (1LL << 31), "mtet_count: bad sizes");
+    hipStream_t st = as_stream(stream);
+    MtWs w = mt_ws(workspace, n_edges, n_tets);
+    hipLaunchKernelGGL(mtet_count_edges_kernel, dim3(w.neb), dim3(MT_BLOCK), 0, st, sdf, reinterpret_cast<const int2 *>(edges),
+                       (long)n_edges, w.ebs);
+    hipLaunchKernelGGL(mtet_count_tets_kernel, dim3(w.ntb), dim3(MT_BLOCK), 0, st, sdf, reinterpret_cast<const int4 *>(tets),
+                       (long)n_tets, w.tbs);
+    hipLaunchKernelGGL(mtet_scan_blocks_kernel, dim3(1), dim3(MT_BLOCK), 0, st, w.ebs, w.neb, w.tbs, w.ntb, w.hd);
+    SC_LAUNCH_CHECK();
+    MtHeader h;
+    SC_HIP(hipMemcpyAsync(&h, w.hd, sizeof(h), hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    *n_verts_host = h.n_verts;
+    *n_faces_host = h.n_ones + 2 * h.n_twos;
+    return 0;
+}
+
+int sculpt_mtet_emit(const float *pos, const float *sdf, const int32_t *tets, int64_t n_tets, const int32_t *edges,
+                     int64_t n_edges, const int32_t *tet_edges, void *workspace, float vert_mul, float vert_add,
+                     float *verts, int64_t *faces, sculpt_stream_t stream) {
+    SC_REQUIRE(pos && sdf && tets && edges && tet_edges && workspace, "mtet_emit: null argument");
+    SC_REQUIRE(verts && faces, "mtet_emit: null output");
+    hipStream_t st = as_stream(stream);
+    MtWs w = mt_ws(workspace, n_edges, n_tets);
+    hipLaunchKernelGGL(mtet_emit_verts_kernel, dim3(w.neb), dim3(MT_BLOCK), 0, st, pos, sdf,
+                       reinterpret_cast<const int2 *>(edges), (long)n_edges, w.ebs, vert_mul, vert_add, w.edge_vid, verts);
+    hipLaunchKernelGGL(mtet_emit_faces_kernel, dim3(w.ntb), dim3(MT_BLOCK), 0, st, sdf, reinterpret_cast<const int4 *>(tets),
+                       (long)n_tets, tet_edges, w.edge_vid, w.tbs, w.hd, reinterpret_cast<long long *>(faces));
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

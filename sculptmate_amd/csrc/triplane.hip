@@ -161,8 +161,10 @@ struct Tap1 {
     int i0;       // floor index (may be -1 .. size-1)
     float w1;     // weight of i0+1 (fraction), weight of i0 is 1-w1
 };
+template <bool AC = false>
 __device__ __forceinline__ Tap1 tap_of(float g, int size) {
-    float f = ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+    // torch grid_sampler_unnormalize: align_corners ? (g+1)/2*(size-1) : ((g+1)*size-1)/2
+    float f = AC ? ((g + 1.0f) / 2.0f) * (float)(size - 1) : ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
     float fl = floorf(f);
     Tap1 t;
     t.i0 = (int)fl;
@@ -179,7 +181,7 @@ __device__ __forceinline__ float to_unit(float p, float radius, float span) {
 // General query at arbitrary points (C = 40 channels per plane).
 // lane (p = lane&31, h = lane>>5) samples features k = h*60 + s, s = 0..59, of point p.
 // ---------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool AC>
 __global__ __launch_bounds__(512) void query_points_kernel(
     const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
     const float *__restrict__ pts, long N, float radius, float span, float density_bias,
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(512) void query_points_kernel(
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const float gx = q[pl == 2 ? 1 : 0], gy = q[pl == 0 ? 1 : 2];
-            Tap1 tx = tap_of(gx, W), ty = tap_of(gy, H);
+            Tap1 tx = tap_of<AC>(gx, W), ty = tap_of<AC>(gy, H);
             const float wx = tx.w1, ex = 1.0f - wx, wy = ty.w1, ey = 1.0f - wy;
             const int x0 = tx.i0, x1 = x0 + 1, y0 = ty.i0, y1 = y0 + 1;
             const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
@@ -451,6 +453,14 @@ int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *
                           int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,
                           float *density, float *features, float *density_act, float *color,
                           sculpt_stream_t stream) {
+    return sculpt_triplane_query_ex(planes, C, H, W, mlp_packed, n_hidden_64, points, N, radius, density_bias, 0u,
+                                    density, features, density_act, color, stream);
+}
+
+int sculpt_triplane_query_ex(const float *planes, int C, int H, int W, const void *mlp_packed,
+                             int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,
+                             unsigned flags, float *density, float *features, float *density_act, float *color,
+                             sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     SC_REQUIRE(C == 40, "triplane_query: built for C=40 channels per plane (got %d)", C);
     SC_REQUIRE(planes && mlp_packed, "triplane_query: null input");
@@ -459,7 +469,7 @@ int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *
     SC_REQUIRE(n_hidden_64 >= 0, "triplane_query: bad n_hidden_64");
     const size_t lds = lds_bytes_for(n_hidden_64);
     SC_REQUIRE(lds <= 160 * 1024, "triplane_query: %d hidden layers do not fit LDS", n_hidden_64);
-    auto kern = query_points_kernel<40>;
+    auto kern = (flags & SCULPT_QUERY_ALIGN_CORNERS) ? query_points_kernel<40, true> : query_points_kernel<40, false>;
     SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long ntiles = (N + 31) / 32;
     const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());

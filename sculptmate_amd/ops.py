@@ -54,8 +54,9 @@ class PackedMLP:
 
 
 def triplane_query(planes, mlp, points, radius=0.87, density_bias=-1.0,
-                   want=("density", "features", "density_act", "color")):
-    """query_triplane (nerf_renderer.py:41-91) at arbitrary points -> dict of [N,1]/[N,3] tensors."""
+                   want=("density", "features", "density_act", "color"), align_corners=False):
+    """query_triplane (nerf_renderer.py:41-91) at arbitrary points -> dict of [N,1]/[N,3] tensors.
+    align_corners=True is SF3D.query_triplane's sampling (StableFast/sf3d/system.py:170-199)."""
     planes = _req(planes, torch.float32, "planes")
     shape = points.shape[:-1]
     pts = _req(points.reshape(-1, 3).contiguous(), torch.float32, "points")
@@ -64,10 +65,11 @@ def triplane_query(planes, mlp, points, radius=0.87, density_bias=-1.0,
     out = {}
     for k, w in (("density", 1), ("features", 3), ("density_act", 1), ("color", 3)):
         out[k] = torch.empty((N, w), dtype=torch.float32, device=planes.device) if k in want else None
-    check(lib.sculpt_triplane_query(_ptr(planes), C, H, W, _ptr(mlp.blob), mlp.n_hidden, _ptr(pts), N,
-                                    float(radius), float(density_bias), _ptr(out["density"]),
-                                    _ptr(out["features"]), _ptr(out["density_act"]), _ptr(out["color"]),
-                                    _stream()))
+    check(lib.sculpt_triplane_query_ex(_ptr(planes), C, H, W, _ptr(mlp.blob), mlp.n_hidden, _ptr(pts), N,
+                                       float(radius), float(density_bias),
+                                       _lib.QUERY_ALIGN_CORNERS if align_corners else 0, _ptr(out["density"]),
+                                       _ptr(out["features"]), _ptr(out["density_act"]), _ptr(out["color"]),
+                                       _stream()))
     return {k: v.view(*shape, v.shape[-1]) for k, v in out.items() if v is not None}
 
 
@@ -234,7 +236,7 @@ def vit_patchify(image_hwc, patch, mean, std, patches):
     pb = patches if patches.dtype == BF16 else None
     pf = patches if patches.dtype == torch.float32 else None
     check(lib.sculpt_vit_patchify(_ptr(image_hwc), S, patch, ctypes.cast(m, ctypes.c_void_p),
-                                  ctypes.cast(s, ctypes.c_void_p), _ptr(pb), _ptr(pf), _stream()))
+                                  ctypes.cast(s, ctypes.c_void_p), _ptr(pb), _ptr(pf), patches.stride(0), _stream()))
 
 
 def vit_assemble(patch_out, cls, pos, tokens):
@@ -320,6 +322,74 @@ def vertex_tangents(v_pos, v_tex, v_nrm, faces):
     check(lib.sculpt_vertex_tangents(_ptr(v), _ptr(t), _ptr(n), v.shape[0], _ptr(f), int(f.dtype == torch.int64), f.shape[0],
                                      _ptr(cnt), _ptr(out), _stream()))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# StableFast-3D networks: 3x3 conv as im2col + GEMM, pixel shuffle, marching tetrahedra
+# ----------------------------------------------------------------------------------------------
+def im2col3x3(act, n_planes, S, out):
+    """act [n_planes*S*S][C] channel-last (bf16 or f32) -> out [n_planes*S*S][9*C], k = (ky*3+kx)*C + c."""
+    C = act.shape[1]
+    assert act.is_contiguous() and out.is_contiguous() and out.shape == (n_planes * S * S, 9 * C) and out.dtype == act.dtype
+    check(lib.sculpt_im2col3x3(_ptr(act), n_planes, S, C, act.element_size(), _ptr(out), _stream()))
+
+
+def pixel_shuffle(g, planes, n_planes, S, Co, r):
+    """nn.PixelShuffle(r) of g f32 [n_planes*S*S][>= Co*r*r] into planes f32 [n_planes][Co][S*r][S*r]."""
+    g = _req(g, torch.float32, "g")
+    check(lib.sculpt_pixel_shuffle(_ptr(g), g.stride(0), _ptr(planes), n_planes, S, Co, r, _stream()))
+
+
+def normalize_rows3(x, eps=1e-7):
+    """F.normalize(x, dim=-1, eps=eps) for [N,3] fp32."""
+    x = _req(x.contiguous(), torch.float32, "x")
+    y = torch.empty_like(x)
+    check(lib.sculpt_normalize_rows3(_ptr(x), x.shape[0], float(eps), _ptr(y), _stream()))
+    return y
+
+
+class TetGrid:
+    """Static tetrahedral grid tables resident in HBM (see sculptmate_amd/sf3d/tets.py)."""
+
+    def __init__(self, vertices, indices, device, edges=None, tet_edges=None):
+        from .sf3d.tets import edge_tables
+
+        v = np.ascontiguousarray(vertices, np.float32)
+        t = np.ascontiguousarray(indices, np.int64)
+        if edges is None or tet_edges is None:
+            edges, tet_edges = edge_tables(t, v.shape[0])
+        self.n_vertices, self.n_tets, self.n_edges = v.shape[0], t.shape[0], edges.shape[0]
+        self.vertices = torch.from_numpy(v).to(device)
+        self.tets = torch.from_numpy(t.astype(np.int32)).to(device)
+        self.edges = torch.from_numpy(np.ascontiguousarray(edges, np.int32)).to(device)
+        self.tet_edges = torch.from_numpy(np.ascontiguousarray(tet_edges, np.int32)).to(device)
+        self.ws = torch.empty(lib.sculpt_mtet_workspace_bytes(self.n_edges, self.n_tets), dtype=torch.uint8, device=device)
+
+
+def mtet_deform(grid: TetGrid, offsets, resolution):
+    """grid_vertices + (1/resolution) * tanh(offsets)  (isosurface.py:108-115)."""
+    off = _req(offsets.reshape(-1, 3).contiguous(), torch.float32, "offsets")
+    out = torch.empty_like(grid.vertices)
+    check(lib.sculpt_mtet_deform(_ptr(grid.vertices), _ptr(off), grid.n_vertices, float((1 - 0) / resolution), _ptr(out),
+                                 _stream()))
+    return out
+
+
+def marching_tets(grid: TetGrid, pos, sdf, vert_mul=1.0, vert_add=0.0):
+    """MarchingTetrahedraHelper._forward (isosurface.py:142-209) -> (verts f32 [Nv,3] * vert_mul + vert_add, faces i64)."""
+    pos = _req(pos.contiguous(), torch.float32, "pos")
+    sdf = _req(sdf.reshape(-1).contiguous(), torch.float32, "sdf")
+    assert pos.shape == (grid.n_vertices, 3) and sdf.shape[0] == grid.n_vertices
+    nv, nf = ctypes.c_int64(), ctypes.c_int64()
+    check(lib.sculpt_mtet_count(_ptr(sdf), _ptr(grid.tets), grid.n_tets, _ptr(grid.edges), grid.n_edges, _ptr(grid.ws),
+                                ctypes.byref(nv), ctypes.byref(nf), _stream()))
+    verts = torch.empty((nv.value, 3), dtype=torch.float32, device=pos.device)
+    faces = torch.empty((nf.value, 3), dtype=torch.int64, device=pos.device)
+    if nv.value and nf.value:
+        check(lib.sculpt_mtet_emit(_ptr(pos), _ptr(sdf), _ptr(grid.tets), grid.n_tets, _ptr(grid.edges), grid.n_edges,
+                                   _ptr(grid.tet_edges), _ptr(grid.ws), float(vert_mul), float(vert_add), _ptr(verts),
+                                   _ptr(faces), _stream()))
+    return verts, faces
 
 
 # ----------------------------------------------------------------------------------------------

@@ -125,3 +125,37 @@ def calibrate_density_bias(pre_activation, inside_fraction=0.015, threshold=25.0
     exceed the iso threshold: exp(d + b* + density_bias) = threshold at the (1-f) quantile."""
     qv = np.quantile(np.asarray(pre_activation, np.float64), 1.0 - inside_fraction)
     return float(math.log(threshold) - density_bias - qv)
+
+
+def sf3d_state(seed=0, cfg=None):
+    """Full SF3D state dict (NumPy float32) for the geometry/texture path (sculptmate_amd.sf3d.spec.param_spec):
+    DINOv2 trunc-normal(0.02), LayerScale 1.0 +- 0.1, adaLN modulations small but non-zero (the shipped model trains
+    them away from their zero init), nn.Linear / Conv2d default kaiming-uniform(a=sqrt(5)), latents N(0, 0.02),
+    triplane tokens randn/sqrt(C), MaterialMLP heads nn.Linear default."""
+    from .sf3d.spec import DEFAULT_CFG, param_spec
+
+    cfg = cfg or DEFAULT_CFG
+    rng = np.random.default_rng([seed, 16])
+    sd = {}
+    for name, shape in param_spec(cfg).items():
+        is_bias = name.endswith(".bias")
+        if "_modulation." in name:
+            sd[name] = _uniform(rng, shape, 0.02)
+        elif name.endswith("lambda1"):
+            sd[name] = (1.0 + _uniform(rng, shape, 0.1)).astype(np.float32)
+        elif any(t in name for t in (".norm", "layernorm", "norm_")) and len(shape) == 1:
+            sd[name] = _uniform(rng, shape, 0.05) if is_bias else (1.0 + _uniform(rng, shape, 0.1)).astype(np.float32)
+        elif name.startswith("image_tokenizer."):
+            sd[name] = _uniform(rng, shape, 0.02) if is_bias else _trunc_normal(rng, shape)
+        elif name == "tokenizer.embeddings":
+            sd[name] = (rng.standard_normal(shape, dtype=np.float32) / np.float32(math.sqrt(shape[1]))).astype(np.float32)
+        elif name == "backbone.latent_init":
+            sd[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)).astype(np.float32)
+        else:
+            if is_bias:
+                wshape = sd[name[:-4] + "weight"].shape
+                fan_in = int(np.prod(wshape[1:]))
+            else:
+                fan_in = int(np.prod(shape[1:]))
+            sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(fan_in))
+    return sd

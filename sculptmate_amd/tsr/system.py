@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
+from ..engine import KernelEngine
 from .posemb import interpolate_pos_embedding
 from .utils import ImagePreprocessor, scale_tensor
 
@@ -96,7 +97,7 @@ def _f32(x, dev):
     return torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()
 
 
-class TSR:
+class TSR(KernelEngine):
     def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16"):
         """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times) or
         "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference)."""
@@ -231,36 +232,6 @@ class TSR:
             pe = self._sd["image_tokenizer.model.embeddings.position_embeddings"].numpy()
             self._pos_cache[n_side] = _f32(interpolate_pos_embedding(pe, n_side, self.pos_embed_mode), dev)
         return self._pos_cache[n_side]
-
-    def _b(self, name, shape, dtype, zero=False):
-        key = (name, tuple(shape), dtype)
-        t = self._buf.get(key)
-        if t is None:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self._buf[key] = t
-        return t
-
-    # ------------------------------------------------------------------ precision dispatch
-    def _gemm(self, A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0,
-              n_split=0):
-        """One Linear: bf16 MFMA kernel (out_bf16 = activation buffer) or the fp32 parity kernel (every buffer fp32)."""
-        if self.precision == "bf16":
-            return ops.gemm(A, W, bias=bias, residual=residual, out_f32=out_f32, out_bf16=out_bf16, out_t=out_t, M=M,
-                            epilogue=epilogue, n_split=n_split)
-        out = out_f32 if out_f32 is not None else out_bf16
-        return ops.gemm_f32(A, W, bias=bias, residual=residual, out=out, out_t=out_t, M=M, epilogue=epilogue,
-                            n_split=n_split)
-
-    def _attn(self, Q, K, Vt, O, Tq, Tk, heads, scale):
-        if self.precision == "bf16":
-            return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale)
-        scores = self._b("attn_scores", (Tq, ((Tk + 15) // 16) * 16), torch.float32)
-        return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores)
-
-    def _ln(self, x, gamma, beta, eps, y):
-        if self.precision == "bf16":
-            return ops.layernorm(x, gamma, beta, eps, y=y)
-        return ops.layernorm(x, gamma, beta, eps, y_f32=y)
 
     # ------------------------------------------------------------------ forward
     def image_tokens(self, image_hwc: torch.Tensor):
