@@ -222,3 +222,30 @@ def test_sf3d_rejects_cpu_and_bad_state(cuda):
     extra = dict(sd)
     extra["image_estimator.head.weight"] = np.zeros(3, np.float32)  # estimator weights are tolerated (not built)
     m.load_state_dict(extra)
+
+
+def test_full_size_sf3d_scene_code_vs_oracle(cuda):
+    """The shipped architecture (DINOv2-L, 27 648 triplane tokens, 3 089 latents, 384^2 planes): bf16 pipeline and the
+    fp32 parity mode against the fp32 oracle on the host cores (about a minute of CPU time)."""
+    from sculptmate_amd.sf3d.spec import DEFAULT_CFG
+    from sculptmate_amd.sf3d.system import SF3D
+
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = dict(DEFAULT_CFG, isosurface_resolution=16)  # the tet grid is not under test here
+    sd = synth.sf3d_state(0, cfg)
+    img = synth.composite_rgb(synth.image_rgba(0, 512))
+    ref, _ = R.get_scene_codes(sd, img, cfg)
+    assert ref.shape == (3, 40, 384, 384)
+    out = {}
+    for prec in ("bf16", "fp32"):
+        m = SF3D(cfg, precision=prec)
+        m.load_state_dict(sd)
+        m.to(cuda)
+        out[prec] = m.scene_code(torch.from_numpy(img).to(cuda)).cpu()
+        del m
+        torch.cuda.empty_cache()
+    r32 = _rel(out["fp32"], ref)
+    rbf = _rel(out["bf16"], ref)
+    print("full-size SF3D scene code: fp32 mode rel %.2e max %.2e | bf16 rel %.2e max %.2e" % (r32 + rbf))
+    assert r32[0] < 3e-5, r32
+    assert rbf[0] < 3e-2, rbf

@@ -1,0 +1,64 @@
+"""Stage timing of the StableFast-3D path (BASELINE config 4) at full size on one MI355X (HIP events)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sculptmate_amd import synth  # noqa: E402
+from sculptmate_amd.sf3d.spec import DEFAULT_CFG  # noqa: E402
+from sculptmate_amd.sf3d.system import SF3D  # noqa: E402
+
+dev = torch.device("cuda:0")
+res = int(sys.argv[1]) if len(sys.argv) > 1 else DEFAULT_CFG["isosurface_resolution"]
+cfg = dict(DEFAULT_CFG, isosurface_resolution=res)
+t0 = time.time()
+sd = synth.sf3d_state(0, cfg)
+print("synthetic weights: %.1f s, %.1f M params" % (time.time() - t0, sum(v.size for v in sd.values()) / 1e6))
+m = SF3D(cfg)
+m.load_state_dict(sd)
+t0 = time.time()
+m.to(dev)
+torch.cuda.synchronize()
+g = m.isosurface_helper.grid
+print("prepare: %.1f s; tet grid %s: %d vertices, %d tets, %d edges" % (time.time() - t0, m.isosurface_helper.source,
+                                                                    g.n_vertices, g.n_tets, g.n_edges))
+img = torch.from_numpy(synth.composite_rgb(synth.image_rgba(0, 512))).to(dev)
+codes = m.scene_code(img)
+torch.cuda.synchronize()
+# calibrate the density head so ~10 % of the grid is inside
+q = m.query_triplane(m._grid_world, codes)
+pre = m.decoder(q, include=["density"])["density"].reshape(-1).log().cpu().numpy()
+shift = np.log(cfg["isosurface_threshold"]) - np.quantile(pre.astype(np.float64), 0.9)
+sd["decoder.heads.density.4.bias"] = (sd["decoder.heads.density.4.bias"] + np.float32(shift)).astype(np.float32)
+m.load_state_dict(sd)
+
+
+def ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def stage_times(n=5):
+    rows = []
+    for _ in range(n):
+        e = [ev()]
+        tok = m.image_tokens(img); e.append(ev())
+        direct = m.backbone_tokens(tok); e.append(ev())
+        planes = m.post_process(direct); e.append(ev())
+        mesh = m.triplane_to_meshes(planes[None])[0]; e.append(ev())
+        torch.cuda.synchronize()
+        rows.append([e[i].elapsed_time(e[i + 1]) for i in range(4)])
+    return np.median(np.array(rows), 0), mesh
+
+
+stage_times(2)
+t, mesh = stage_times(7)
+print("dinov2 %.2f ms | backbone %.2f ms | upsampler %.2f ms | query+mtet %.2f ms | total %.2f ms -> %.1f meshes/s"
+      % (t[0], t[1], t[2], t[3], t.sum(), 1e3 / t.sum()))
+print("mesh: %d vertices, %d faces" % (mesh.v_pos.shape[0], mesh.t_pos_idx.shape[0]))
+fl = dict(dino=0.95e12, backbone=8.5e12, post=1.9e12)
+print("approx TFLOP/s: dino %.0f backbone %.0f upsampler %.0f" % (fl["dino"] / t[0] / 1e9, fl["backbone"] / t[1] / 1e9, fl["post"] / t[2] / 1e9))
