@@ -246,6 +246,19 @@ int sculpt_pixel_shuffle(const float *g, int ldg, float *planes, int n_planes, i
  * may run in place) */
 int sculpt_normalize_rows3(const float *x, int64_t n, float eps, float *y, sculpt_stream_t stream);
 
+/* Texture bake, material composition per texel (StableFast/sf3d/system.py:375-440): all inputs are [res*res][3]
+ * texel images except rast [res*res][4] (texels with rast[..][3] < 0 are outside every chart and stay 0):
+ * albedo = color; bump = clamp(0.5*(pn.t, pn.b, clip(pn.n, 0.3, 1)) + 0.5, 0, 1) with n, t the normalised interpolated
+ * normal / tangent, b = normalize(cross(t, n)), pn = normalize(perturb_normal).  bump may be NULL (albedo only). */
+int sculpt_bake_material(const float *rast, int res, const float *color, const float *perturb_normal, const float *nrm,
+                         const float *tng, float *albedo, float *bump, sculpt_stream_t stream);
+
+/* Stand-in UV layout (NOT the reference's box-projection atlas, which ends in uv_unwrapper.dll): triangle f is drawn
+ * isometrically inside cell (f % cols, f / cols) of a cols x rows grid with relative padding; uv f32 [3*nf][2] in
+ * face-corner order (what Mesh.unwrap_uv's `uv[indices]` produces, mesh.py:236-262). */
+int sculpt_uv_cell_atlas(const float *v_pos, const void *faces, int faces_i64, int64_t nf, int cols, int rows, float padding,
+                         float *uv, sculpt_stream_t stream);
+
 /* MarchingTetrahedraHelper (StableFast/sf3d/models/isosurface.py:108-229).
  *   sculpt_mtet_deform: out = grid_vertices + scale * tanh(offsets), scale = (1-0)/resolution (:108-115, 211-216).
  *   Static per-grid tables (host, once): tets i32 [Nt][4]; edges i32 [Ne][2] = the lexicographically sorted unique

@@ -309,6 +309,29 @@ def marching_tets(pos, sdf, tets):
     return verts, np.concatenate([f1, f2], 0)
 
 
+# ----------------------------------------------------------------------------- texture bake composition
+def bake_material(rast, color, perturb_normal, nrm, tng):
+    """sf3d/system.py:375-440 on full texel images ([res,res,3]; rast [res,res,4], covered where rast[...,-1] >= 0):
+    the reference gathers the covered texels, computes, and scatters into zero images -- same values.
+    (Inline code of generate_mesh, no callable to run under the reference: restated, not pinned by a golden.)"""
+    rast, color = _t(rast).float(), _t(color).float()
+    mask = rast[..., -1] >= 0
+    albedo = torch.zeros_like(color)
+    albedo[mask] = color[mask]
+    if perturb_normal is None:
+        return albedo.numpy(), None
+    gb_nrm = F.normalize(_t(nrm).float()[mask], dim=-1)
+    gb_tng = F.normalize(_t(tng).float()[mask], dim=-1)
+    gb_btng = F.normalize(torch.cross(gb_tng, gb_nrm, dim=-1), dim=-1)
+    normal = F.normalize(F.normalize(_t(perturb_normal).float()[mask], dim=-1, eps=1e-7), dim=-1)
+    dot = lambda a, b: (a * b).sum(-1, keepdim=True)  # noqa: E731
+    bump = torch.cat((dot(normal, gb_tng), dot(normal, gb_btng), dot(normal, gb_nrm).clip(0.3, 1)), -1)
+    bump = (bump * 0.5 + 0.5).clamp(0, 1)
+    out = torch.zeros_like(color)
+    out[mask] = bump
+    return albedo.numpy(), out.numpy()
+
+
 # ----------------------------------------------------------------------------- glue
 def get_scene_codes(sd, image_hwc, cfg, bf16=False):
     """SF3D.get_scene_codes for one image -> (scene_codes [3,Co,S*r,S*r], direct_codes [3,C,S,S])."""

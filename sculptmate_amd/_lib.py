@@ -66,6 +66,8 @@ SIGNATURES = {
     "sculpt_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_pixel_shuffle": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "sculpt_normalize_rows3": (_i, [_vp, _i64, _f, _vp, _vp]),
+    "sculpt_bake_material": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_uv_cell_atlas": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp]),
     "sculpt_mtet_deform": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     "sculpt_mtet_workspace_bytes": (_sz, [_i64, _i64]),
     "sculpt_mtet_count": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _pi64, _pi64, _vp]),

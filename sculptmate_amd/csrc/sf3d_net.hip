@@ -72,6 +72,80 @@ __global__ __launch_bounds__(256) void normalize3_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// texture bake: per texel material composition (StableFast/sf3d/system.py:375-440, one launch instead of ~25
+// masked gather / normalize / cross / dot / scatter tensor ops).  Texels with rast[...,3] < 0 (baker.py:58-68)
+// stay zero.  albedo = sigmoid features; bump = tangent-space encoding of the perturbed normal:
+//   n  = normalize(interp normal), t = normalize(interp tangent), b = normalize(cross(t, n))
+//   pn = normalize(perturb_normal);  bump = clamp(0.5 * (pn.t, pn.b, clip(pn.n, 0.3, 1)) + 0.5, 0, 1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nrm3(float &a, float &b, float &c, float eps) {
+    const float d = fmaxf(sqrtf(a * a + b * b + c * c), eps);
+    a /= d; b /= d; c /= d;
+}
+
+__global__ __launch_bounds__(256) void bake_material_kernel(const float *__restrict__ rast, long n, const float *__restrict__ color,
+                                                            const float *__restrict__ pnrm, const float *__restrict__ nrm,
+                                                            const float *__restrict__ tng, float *__restrict__ albedo,
+                                                            float *__restrict__ bump) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const bool on = rast[4 * i + 3] >= 0.f;
+        float al[3] = {0.f, 0.f, 0.f}, bu[3] = {0.f, 0.f, 0.f};
+        if (on) {
+            al[0] = color[3 * i]; al[1] = color[3 * i + 1]; al[2] = color[3 * i + 2];
+            if (bump) {
+                float nx = nrm[3 * i], ny = nrm[3 * i + 1], nz = nrm[3 * i + 2];
+                float tx = tng[3 * i], ty = tng[3 * i + 1], tz = tng[3 * i + 2];
+                float px = pnrm[3 * i], py = pnrm[3 * i + 1], pz = pnrm[3 * i + 2];
+                nrm3(nx, ny, nz, 1e-12f);
+                nrm3(tx, ty, tz, 1e-12f);
+                float bx = ty * nz - tz * ny, by = tz * nx - tx * nz, bz = tx * ny - ty * nx;
+                nrm3(bx, by, bz, 1e-12f);
+                nrm3(px, py, pz, 1e-7f);   // models/utils.py:69-72 (EPS_DTYPE[float32])
+                nrm3(px, py, pz, 1e-12f);  // F.normalize (system.py:418)
+                const float dt = px * tx + py * ty + pz * tz, db = px * bx + py * by + pz * bz;
+                const float dn = fminf(fmaxf(px * nx + py * ny + pz * nz, 0.3f), 1.0f);
+                bu[0] = fminf(fmaxf(dt * 0.5f + 0.5f, 0.f), 1.f);
+                bu[1] = fminf(fmaxf(db * 0.5f + 0.5f, 0.f), 1.f);
+                bu[2] = fminf(fmaxf(dn * 0.5f + 0.5f, 0.f), 1.f);
+            }
+        }
+        albedo[3 * i] = al[0]; albedo[3 * i + 1] = al[1]; albedo[3 * i + 2] = al[2];
+        if (bump) { bump[3 * i] = bu[0]; bump[3 * i + 1] = bu[1]; bump[3 * i + 2] = bu[2]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-in UV layout when no unwrapper is supplied: every triangle gets its own cell of a cols x rows grid,
+// drawn isometrically (a at the origin, b on the u axis) and scaled to fit the padded cell.  uv [3*nf][2].
+// NOT the reference's box-projection atlas (uv_unwrapper/unwrap.py + uv_unwrapper.dll).
+// ------------------------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(256) void uv_cell_atlas_kernel(const float *__restrict__ v, const IdxT *__restrict__ faces, long nf,
+                                                            int cols, int rows, float pad, float *__restrict__ uv) {
+    for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += (long)gridDim.x * blockDim.x) {
+        const long ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+        const float ax = v[3 * ia], ay = v[3 * ia + 1], az = v[3 * ia + 2];
+        const float e1x = v[3 * ib] - ax, e1y = v[3 * ib + 1] - ay, e1z = v[3 * ib + 2] - az;
+        const float e2x = v[3 * ic] - ax, e2y = v[3 * ic + 1] - ay, e2z = v[3 * ic + 2] - az;
+        const float l1 = sqrtf(e1x * e1x + e1y * e1y + e1z * e1z);
+        const float inv = l1 > 0.f ? 1.0f / l1 : 0.f;
+        float cx = (e2x * e1x + e2y * e1y + e2z * e1z) * inv;                      // c along ab
+        const float c2 = e2x * e2x + e2y * e2y + e2z * e2z;
+        float cy = sqrtf(fmaxf(c2 - cx * cx, 0.f));                                 // c perpendicular
+        // bounding box of (0,0), (l1,0), (cx,cy)
+        const float minx = fminf(0.f, cx), maxx = fmaxf(l1, cx);
+        const float ext = fmaxf(fmaxf(maxx - minx, cy), 1e-20f);
+        const float cw = 1.0f / cols, ch = 1.0f / rows;
+        const float sx = cw * (1.0f - 2.0f * pad) / ext, sy = ch * (1.0f - 2.0f * pad) / ext;
+        const float ox = (float)(f % cols) * cw + pad * cw, oy = (float)(f / cols) * ch + pad * ch;
+        float *o = uv + 6 * f;
+        o[0] = ox + (0.f - minx) * sx; o[1] = oy;
+        o[2] = ox + (l1 - minx) * sx;  o[3] = oy;
+        o[4] = ox + (cx - minx) * sx;  o[5] = oy + cy * sy;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // marching tetrahedra
 // ------------------------------------------------------------------------------------------------
 __constant__ signed char MT_TRI[16][6] = {
@@ -322,6 +396,36 @@ int sculpt_normalize_rows3(const float *x, int64_t n, float eps, float *y, sculp
     if (n <= 0) return 0;
     const int grid = (int)std::min<long>(cdiv(n, 256), (long)num_cus() * 32);
     hipLaunchKernelGGL(normalize3_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, (long)n, eps, y);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_bake_material(const float *rast, int res, const float *color, const float *perturb_normal, const float *nrm,
+                         const float *tng, float *albedo, float *bump, sculpt_stream_t stream) {
+    SC_REQUIRE(rast && color && albedo && res >= 1, "bake_material: null argument");
+    SC_REQUIRE(!bump || (perturb_normal && nrm && tng), "bake_material: the bump map needs perturb_normal, nrm and tng");
+    const long n = (long)res * res;
+    const int grid = (int)std::min<long>(cdiv(n, 256), (long)num_cus() * 32);
+    hipLaunchKernelGGL(bake_material_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rast, n, color, perturb_normal, nrm,
+                       tng, albedo, bump);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_uv_cell_atlas(const float *v_pos, const void *faces, int faces_i64, int64_t nf, int cols, int rows, float padding,
+                         float *uv, sculpt_stream_t stream) {
+    SC_REQUIRE(v_pos && faces && uv, "uv_cell_atlas: null argument");
+    if (nf <= 0) return 0;
+    SC_REQUIRE(cols >= 1 && rows >= 1 && (int64_t)cols * rows >= nf, "uv_cell_atlas: %d x %d cells for %lld faces", cols, rows,
+               (long long)nf);
+    SC_REQUIRE(padding >= 0.f && padding < 0.5f, "uv_cell_atlas: bad padding");
+    const int grid = (int)std::min<long>(cdiv(nf, 256), (long)num_cus() * 32);
+    if (faces_i64)
+        hipLaunchKernelGGL(uv_cell_atlas_kernel<long long>, dim3(grid), dim3(256), 0, as_stream(stream), v_pos,
+                           reinterpret_cast<const long long *>(faces), (long)nf, cols, rows, padding, uv);
+    else
+        hipLaunchKernelGGL(uv_cell_atlas_kernel<int>, dim3(grid), dim3(256), 0, as_stream(stream), v_pos,
+                           reinterpret_cast<const int *>(faces), (long)nf, cols, rows, padding, uv);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -348,6 +348,32 @@ def normalize_rows3(x, eps=1e-7):
     return y
 
 
+def bake_material(rast, color, perturb_normal=None, nrm=None, tng=None):
+    """system.py:375-440 per texel -> (albedo [res,res,3], bump [res,res,3] or None)."""
+    res = rast.shape[0]
+    rast = _req(rast.contiguous(), torch.float32, "rast")
+    albedo = torch.empty((res, res, 3), dtype=torch.float32, device=rast.device)
+    bump = torch.empty_like(albedo) if perturb_normal is not None else None
+    args = [None if t is None else _req(t.reshape(-1, 3).contiguous(), torch.float32, "texel image")
+            for t in (color, perturb_normal, nrm, tng)]
+    check(lib.sculpt_bake_material(_ptr(rast), res, _ptr(args[0]), _ptr(args[1]), _ptr(args[2]), _ptr(args[3]),
+                                   _ptr(albedo), _ptr(bump), _stream()))
+    return albedo, bump
+
+
+def uv_cell_atlas(v_pos, faces, padding=0.05):
+    """One grid cell per triangle (stand-in unwrapper) -> (uv f32 [3*Nf, 2], indices i64 [Nf, 3] = arange)."""
+    v = _req(v_pos.contiguous(), torch.float32, "v_pos")
+    f = faces.contiguous()
+    nf = f.shape[0]
+    cols = max(1, int(np.ceil(np.sqrt(nf))))
+    rows = max(1, -(-nf // cols))
+    uv = torch.empty((3 * nf, 2), dtype=torch.float32, device=v.device)
+    check(lib.sculpt_uv_cell_atlas(_ptr(v), _ptr(f), int(f.dtype == torch.int64), nf, cols, rows, float(padding), _ptr(uv),
+                                   _stream()))
+    return uv, torch.arange(3 * nf, device=v.device, dtype=torch.int64).reshape(-1, 3)
+
+
 class TetGrid:
     """Static tetrahedral grid tables resident in HBM (see sculptmate_amd/sf3d/tets.py)."""
 
