@@ -78,6 +78,11 @@ int sculpt_triplane_query(const float *planes, int C, int H, int W, const void *
  * a 1-channel head in row 0 (density_act = exp(out + bias) == trunc_exp), a 3-channel head in rows 1..3
  * (color = sigmoid). */
 #define SCULPT_QUERY_ALIGN_CORNERS 1u
+/* SCULPT_QUERY_CHANNEL_LAST: `planes` is [3][H][W][C] (sculpt_planes_channel_last of the reference layout): one tap
+ * is C contiguous floats, ~20x fewer cache lines per point than gathering from C separate channel planes. */
+#define SCULPT_QUERY_CHANNEL_LAST 2u
+int sculpt_planes_channel_last(const float *planes /* [3][C][H][W] */, int C, int H, int W, float *out /* [3][H][W][C] */,
+                               sculpt_stream_t stream);
 int sculpt_triplane_query_ex(const float *planes, int C, int H, int W, const void *mlp_packed,
                              int n_hidden_64, const float *points, int64_t N, float radius, float density_bias,
                              unsigned flags, float *density, float *features, float *density_act, float *color,

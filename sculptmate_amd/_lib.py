@@ -39,6 +39,7 @@ SIGNATURES = {
     "sculpt_mlp_pack": (_i, [_pp, _pp, _i, _vp, _vp, _sz]),
     "sculpt_triplane_query": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "sculpt_triplane_query_ex": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _u, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_planes_channel_last": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sculpt_density_grid_workspace_bytes": (_sz, [_i, _i]),
     "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
@@ -90,6 +91,7 @@ ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
 EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_RELU = 0, 1, 2, 3
 QUERY_ALIGN_CORNERS = 1
+QUERY_CHANNEL_LAST = 2
 
 
 def last_error():

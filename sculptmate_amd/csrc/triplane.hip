@@ -181,7 +181,10 @@ __device__ __forceinline__ float to_unit(float p, float radius, float span) {
 // General query at arbitrary points (C = 40 channels per plane).
 // lane (p = lane&31, h = lane>>5) samples features k = h*60 + s, s = 0..59, of point p.
 // ---------------------------------------------------------------------------------------------
-template <int C, bool AC>
+// CL = planes are channel-last [3][H][W][C]: a tap is C contiguous floats (160 B), read as float4 groups of four
+// channels -- 60 vector loads per lane instead of 240 scalar gathers from 40 channel planes 4*H*W bytes apart
+// (the reference layout [3][C][H][W] touches ~480 cache lines per point, channel-last ~24).
+template <int C, bool AC, bool CL>
 __global__ __launch_bounds__(512) void query_points_kernel(
     const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
     const float *__restrict__ pts, long N, float radius, float span, float density_bias,
@@ -228,6 +231,38 @@ __global__ __launch_bounds__(512) void query_points_kernel(
         // layer 0 on MFMA: step s consumes feature k = h*S0 + s of point p
         f32x16 acc0 = lds_bias16(L.bacc, 0, h, 0);
         f32x16 acc1 = lds_bias16(L.bacc, 0, h, 1);
+        if (CL) {
+            static_assert(C % 4 == 0 && (3 * C / 2) % 4 == 0, "channel-last path reads groups of four channels");
+            constexpr int C4 = C / 4;
+            const f32x4 *P4 = reinterpret_cast<const f32x4 *>(planes);
+#pragma unroll 3
+            for (int gq = 0; gq < S0 / 4; ++gq) {
+                const int f = h * S0 + 4 * gq;
+                const int pl = f / C, ch4 = (f - pl * C) >> 2;
+                const f32x4 *B = P4 + (long)pl * HW * C4 + ch4;
+                const int o0 = pl == 0 ? off[0][0] : (pl == 1 ? off[1][0] : off[2][0]);
+                const int o1 = pl == 0 ? off[0][1] : (pl == 1 ? off[1][1] : off[2][1]);
+                const int o2 = pl == 0 ? off[0][2] : (pl == 1 ? off[1][2] : off[2][2]);
+                const int o3 = pl == 0 ? off[0][3] : (pl == 1 ? off[1][3] : off[2][3]);
+                const float w0 = pl == 0 ? wt[0][0] : (pl == 1 ? wt[1][0] : wt[2][0]);
+                const float w1 = pl == 0 ? wt[0][1] : (pl == 1 ? wt[1][1] : wt[2][1]);
+                const float w2 = pl == 0 ? wt[0][2] : (pl == 1 ? wt[1][2] : wt[2][2]);
+                const float w3 = pl == 0 ? wt[0][3] : (pl == 1 ? wt[1][3] : wt[2][3]);
+                const f32x4 t0 = B[(long)o0 * C4], t1 = B[(long)o1 * C4], t2 = B[(long)o2 * C4], t3 = B[(long)o3 * C4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = t0[j] * w0;  // same tap order as torch: nw + ne + sw + se
+                    v += t1[j] * w1;
+                    v += t2[j] * w2;
+                    v += t3[j] * w3;
+                    const int s = 4 * gq + j;
+                    const float a0 = A0g[(0 * S0 + s) * 64 + lane];
+                    const float a1 = A0g[(1 * S0 + s) * 64 + lane];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll 4
         for (int s = 0; s < S0; ++s) {
             const int f = h * S0 + s;
@@ -250,6 +285,7 @@ __global__ __launch_bounds__(512) void query_points_kernel(
             const float a1 = A0g[(1 * S0 + s) * 64 + lane];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+        }
         }
         f32x16 x0 = silu16(acc0), x1 = silu16(acc1);
         hidden_layers(L, NH, lane, h, x0, x1);
@@ -394,9 +430,41 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
 
 }  // namespace sculpt
 
+namespace sculpt {
+// planes [3][C][H][W] -> [3][H][W][C] through an LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void planes_channel_last_kernel(const float *__restrict__ in, float *__restrict__ out, int C,
+                                                                  long HW) {
+    __shared__ float tile[64][65];
+    const int pl = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r;
+        const long p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? in[((long)pl * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const long p = p0 + r;
+        const int c = c0 + tx;
+        if (c < C && p < HW) out[((long)pl * HW + p) * C + c] = tile[tx][r];
+    }
+}
+}  // namespace sculpt
+
 using namespace sculpt;
 
 extern "C" {
+
+int sculpt_planes_channel_last(const float *planes, int C, int H, int W, float *out, sculpt_stream_t stream) {
+    SC_REQUIRE(planes && out && C >= 1 && H >= 1 && W >= 1, "planes_channel_last: bad argument");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(planes_channel_last_kernel, dim3(cdiv(HW, 64), cdiv(C, 64), 3), dim3(256), 0, as_stream(stream), planes,
+                       out, C, HW);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 size_t sculpt_mlp_packed_bytes(int in_channels, int n_hidden_64) {
     MlpPackHeader hd;
@@ -469,7 +537,9 @@ int sculpt_triplane_query_ex(const float *planes, int C, int H, int W, const voi
     SC_REQUIRE(n_hidden_64 >= 0, "triplane_query: bad n_hidden_64");
     const size_t lds = lds_bytes_for(n_hidden_64);
     SC_REQUIRE(lds <= 160 * 1024, "triplane_query: %d hidden layers do not fit LDS", n_hidden_64);
-    auto kern = (flags & SCULPT_QUERY_ALIGN_CORNERS) ? query_points_kernel<40, true> : query_points_kernel<40, false>;
+    const bool ac = flags & SCULPT_QUERY_ALIGN_CORNERS, cl = flags & SCULPT_QUERY_CHANNEL_LAST;
+    auto kern = cl ? (ac ? query_points_kernel<40, true, true> : query_points_kernel<40, false, true>)
+                   : (ac ? query_points_kernel<40, true, false> : query_points_kernel<40, false, false>);
     SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long ntiles = (N + 31) / 32;
     const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());

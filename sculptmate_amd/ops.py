@@ -53,21 +53,37 @@ class PackedMLP:
         self.blob = torch.from_numpy(host).to(device)
 
 
+class ChannelLastPlanes:
+    """A scene code re-laid as [3][H][W][C] for the point-query kernel (sculpt_planes_channel_last)."""
+
+    def __init__(self, planes):
+        planes = _req(planes.contiguous(), torch.float32, "planes")
+        _, self.C, self.H, self.W = planes.shape
+        self.data = torch.empty((3, self.H, self.W, self.C), dtype=torch.float32, device=planes.device)
+        check(lib.sculpt_planes_channel_last(_ptr(planes), self.C, self.H, self.W, _ptr(self.data), _stream()))
+
+
 def triplane_query(planes, mlp, points, radius=0.87, density_bias=-1.0,
                    want=("density", "features", "density_act", "color"), align_corners=False):
     """query_triplane (nerf_renderer.py:41-91) at arbitrary points -> dict of [N,1]/[N,3] tensors.
-    align_corners=True is SF3D.query_triplane's sampling (StableFast/sf3d/system.py:170-199)."""
-    planes = _req(planes, torch.float32, "planes")
+    align_corners=True is SF3D.query_triplane's sampling (StableFast/sf3d/system.py:170-199).
+    planes: [3,C,H,W] (reference layout) or a ChannelLastPlanes (much faster for many points)."""
     shape = points.shape[:-1]
     pts = _req(points.reshape(-1, 3).contiguous(), torch.float32, "points")
     N = pts.shape[0]
-    _, C, H, W = planes.shape
+    flags = _lib.QUERY_ALIGN_CORNERS if align_corners else 0
+    if isinstance(planes, ChannelLastPlanes):
+        C, H, W = planes.C, planes.H, planes.W
+        planes = planes.data
+        flags |= _lib.QUERY_CHANNEL_LAST
+    else:
+        planes = _req(planes, torch.float32, "planes")
+        _, C, H, W = planes.shape
     out = {}
     for k, w in (("density", 1), ("features", 3), ("density_act", 1), ("color", 3)):
-        out[k] = torch.empty((N, w), dtype=torch.float32, device=planes.device) if k in want else None
+        out[k] = torch.empty((N, w), dtype=torch.float32, device=pts.device) if k in want else None
     check(lib.sculpt_triplane_query_ex(_ptr(planes), C, H, W, _ptr(mlp.blob), mlp.n_hidden, _ptr(pts), N,
-                                       float(radius), float(density_bias),
-                                       _lib.QUERY_ALIGN_CORNERS if align_corners else 0, _ptr(out["density"]),
+                                       float(radius), float(density_bias), flags, _ptr(out["density"]),
                                        _ptr(out["features"]), _ptr(out["density_act"]), _ptr(out["color"]),
                                        _stream()))
     return {k: v.view(*shape, v.shape[-1]) for k, v in out.items() if v is not None}

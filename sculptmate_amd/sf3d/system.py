@@ -627,7 +627,19 @@ class SF3D(KernelEngine):
     # ------------------------------------------------------------------ geometry
     def query_triplane(self, positions, triplanes) -> TriplaneQuery:
         """system.py:170-199 -- returns the deferred query the decoder launches fused (see TriplaneQuery)."""
-        return TriplaneQuery(positions, triplanes.contiguous(), self.cfg["radius"])
+        if isinstance(triplanes, torch.Tensor) and positions.numel() >= 3 * 4096:
+            triplanes = self.channel_last(triplanes)
+        elif isinstance(triplanes, torch.Tensor):
+            triplanes = triplanes.contiguous()
+        return TriplaneQuery(positions, triplanes, self.cfg["radius"])
+
+    def channel_last(self, triplanes: torch.Tensor) -> ops.ChannelLastPlanes:
+        """[3,C,H,W] -> the [3,H,W,C] copy the point-query kernel reads fastest; the last conversion is kept."""
+        key = (triplanes.data_ptr(), triplanes._version, tuple(triplanes.shape))
+        if getattr(self, "_cl_key", None) != key:
+            self._cl = ops.ChannelLastPlanes(triplanes)
+            self._cl_key = key
+        return self._cl
 
     def triplane_to_meshes(self, triplanes) -> List[Mesh]:
         """system.py:140-168"""

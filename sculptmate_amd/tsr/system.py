@@ -85,7 +85,10 @@ class TriplaneNeRFRenderer:
         self.chunk_size = chunk_size  # kept for API parity; the fused kernel needs no chunking
 
     def query_triplane(self, decoder, positions, triplane):
-        return ops.triplane_query(triplane.contiguous(), decoder, positions, radius=self.cfg.radius,
+        triplane = triplane.contiguous()
+        if positions.numel() >= 3 * 4096:  # many points (vertex colours): channel-last taps, ~20x fewer cache lines
+            triplane = ops.ChannelLastPlanes(triplane)
+        return ops.triplane_query(triplane, decoder, positions, radius=self.cfg.radius,
                                   density_bias=self.cfg.density_bias)
 
 

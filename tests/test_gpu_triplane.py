@@ -118,3 +118,24 @@ def test_density_grid_full_size_properties(cuda):
     ref = capi.query_triplane(tri_np, pts, Ws, bs)["density_act"][:, 0]
     got = a.cpu().numpy()[idx]
     np.testing.assert_allclose(np.log(got), np.log(ref), rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_channel_last_query_is_bit_identical_to_reference_layout(cuda, align):
+    """SCULPT_QUERY_CHANNEL_LAST only changes where the taps are read from: same values, same order of operations."""
+    import torch
+
+    from sculptmate_amd import ops, synth
+
+    sd = synth.decoder_state(3)
+    Ws, bs = synth.decoder_lists(sd)
+    mlp = ops.PackedMLP(Ws, bs, cuda)
+    planes = torch.from_numpy(synth.triplane(4, size=48)).to(cuda)
+    g = torch.Generator().manual_seed(1)
+    pts = ((torch.rand(20001, 3, generator=g) * 2 - 1) * 0.95).to(cuda)  # some outside the box
+    a = ops.triplane_query(planes, mlp, pts, align_corners=align)
+    cl = ops.ChannelLastPlanes(planes)
+    assert torch.equal(cl.data, planes.permute(0, 2, 3, 1).contiguous())
+    b = ops.triplane_query(cl, mlp, pts, align_corners=align)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
