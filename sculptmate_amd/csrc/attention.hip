@@ -27,25 +27,41 @@ typedef const __attribute__((address_space(1))) void *agbl_ptr_t;
 
 __device__ __forceinline__ int a_lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
-// One workgroup = 8 waves = 128 queries of one head.  Wave w: query block qi = w & 3 (32 queries),
-// key half kh = w >> 2.  Each iteration stages a PAIR of 64-key tiles; the kh = 0 waves consume the
-// first, the kh = 1 waves the second (flash-decoding style split of the key range inside the
-// workgroup): 2x the waves per SIMD of a 4-wave layout at these small shapes (1.5 workgroups per CU),
-// which is what hides the LDS / LDS-DMA latency.  The two partial (max, sum, O) states of a query
-// block are merged through LDS at the end.
-__global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t *__restrict__ Q, int ldq,
-                                                        const uint16_t *__restrict__ K, int ldk,
-                                                        const uint16_t *__restrict__ Vt, int ldvt,
-                                                        uint16_t *__restrict__ O, int ldo, int Tq, int Tk,
-                                                        float scale_log2e) {
+// One workgroup = 2*NQB waves = NQB*32 queries of one head.  Wave w: query block qi = w % NQB (32 queries),
+// key half kh = w / NQB.  Each iteration stages a PAIR of 64-key tiles; the kh = 0 waves consume the first, the
+// kh = 1 waves the second (flash-decoding style split of the key range inside the workgroup): twice the waves per
+// SIMD of a one-wave-per-query-block layout at these small shapes.  The two partial (max, sum, O) states of a
+// query block are merged through LDS at the end.  NQB = 4 (128 queries) is what the launcher uses: 96-query
+// workgroups would fill the 2 x 256 workgroup slots evenly at 3072 queries x 16 heads (512 blocks instead of 384)
+// but measured 20 % SLOWER -- every workgroup re-stages the head's whole K/V, and that L2 -> LDS traffic (already
+// ~10 TB/s at 128 queries) grows with the block count.
+//
+// Register budget is 128 VGPRs (4 waves per SIMD): everything address-like that is wave-uniform lives in SGPRs
+// (the staging source is a scalar base plus one of four per-lane 32-bit offsets), because a single spill puts a
+// scratch load -- and with it an s_waitcnt vmcnt(0) that also waits for the LDS-DMA prefetch -- into the loop.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;  // v_max3_f32 without the canonicalising v_max(x, x) the compiler adds around fmaxf of MFMA results
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+
+template <int NQB>
+__global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t *__restrict__ Q, int ldq,
+                                                                  const uint16_t *__restrict__ K, int ldk,
+                                                                  const uint16_t *__restrict__ Vt, int ldvt,
+                                                                  uint16_t *__restrict__ O, int ldo, int Tq, int Tk,
+                                                                  float scale_log2e) {
+    constexpr int NW = 2 * NQB;  // waves
     // [stage][K0 | K1 | V0 | V1] sub-tiles of 8 KiB (64 rows x 128 B); reused as merge scratch at the end
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * 8192];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qi = wave & 3, kh = wave >> 2;
+    const int qi = wave % NQB, kh = wave / NQB;
     const int qc = lane & 31, h = lane >> 5;
     const int head = blockIdx.y;
-    const int q = blockIdx.x * 128 + qi * 32 + qc;
+    const int q = blockIdx.x * (NQB * 32) + qi * 32 + qc;
     const int qld = min(q, Tq - 1);
 
     // Q fragments (B operand): Q[q][16*ks + 8h + j]
@@ -54,44 +70,59 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t *__res
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const abf16x8 *>(Q + (long)qld * ldq + head * 64 + ks * 16 + h * 8);
 
-    // staging by LDS-DMA: wave w fills rows 32*(w&1) .. +31 of sub-tile (w>>1): 4 instructions of 8 rows.
-    // The chunk XOR is applied to the per-lane source address (the LDS image is lane-linear).
+    // ---- staging by LDS-DMA.  A tile pair is 32 wave-instructions of 8 rows (1 KiB): instruction j fills rows
+    // 8*(j&7).. of sub-tile j>>3 (0: K0, 1: K1, 2: V0, 3: V1); wave w issues j = w, w+NW, ...  The LDS image is
+    // lane-linear, so the (row>>1)&7 chunk swizzle is applied to the per-lane SOURCE offset:
+    //   row = 8*rg + srow  ->  swizzle = (srow>>1) ^ ((rg&1)<<2): two per-lane variants (rg even / odd).
     const int ntp = (Tk + 127) / 128;
-    const int sub = wave >> 1;              // 0: K0, 1: K1, 2: V0, 3: V1
     const int srow = lane >> 3, sslot = lane & 7;
-    const int rbase = 32 * (wave & 1) + srow;  // + 8*i
-    const int sdst = sub * 8192 + 32 * (wave & 1) * 128;
-    const bool is_k = sub < 2;
-    const int half = sub & 1;
+    const int cs0 = ((sslot ^ (srow >> 1)) << 3), cs1 = cs0 ^ 32;  // element offsets of the lane's chunk
+    const unsigned klane0 = (unsigned)(srow * ldk + cs0) * 2u, klane1 = (unsigned)(srow * ldk + cs1) * 2u;
+    const unsigned vlane0 = (unsigned)(srow * ldvt + cs0) * 2u, vlane1 = (unsigned)(srow * ldvt + cs1) * 2u;
+    const char *Kh = reinterpret_cast<const char *>(K + head * 64);
+    const char *Vh = reinterpret_cast<const char *>(Vt + (long)head * 64 * ldvt);
 
-#define STAGE(buf, tp)                                                                                         \
-    do {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
-            const int r = rbase + 8 * i;                                                                       \
-            const int cs = (sslot ^ ((r >> 1) & 7)) << 3;                                                      \
-            const uint16_t *src;                                                                               \
-            if (is_k) {                                                                                        \
-                const int key = min((tp) * 128 + half * 64 + r, Tk - 1);                                       \
-                src = K + (long)key * ldk + head * 64 + cs;                                                    \
-            } else {                                                                                           \
-                const int col = min((tp) * 128 + half * 64, ldvt - 64);                                        \
-                src = Vt + (long)(head * 64 + r) * ldvt + col + cs;                                            \
-            }                                                                                                  \
-            __builtin_amdgcn_global_load_lds((agbl_ptr_t)src, (alds_ptr_t)(smem + (buf) * 32768 + sdst + i * 1024), 16, 0, 0); \
-        }                                                                                                      \
-    } while (0)
+    auto stage = [&](int buf, int tp) {
+        const bool last = (tp * 128 + 128 > Tk);  // wave-uniform: only the final pair can run past the arrays
+#pragma unroll
+        for (int i = 0; i < (32 + NW - 1) / NW; ++i) {
+            const int j = wave + NW * i;  // scalar
+            if (j < 32) {
+                const int sub = j >> 3, rg = j & 7, half = sub & 1;
+                unsigned char *dst = smem + buf * 32768 + sub * 8192 + rg * 1024;
+                const char *src;
+                if (sub < 2) {
+                    const int row0 = tp * 128 + half * 64 + 8 * rg;
+                    if (!last) {
+                        src = Kh + (long)row0 * ldk * 2 + ((rg & 1) ? klane1 : klane0);
+                    } else {
+                        const int key = min(row0 + srow, Tk - 1);
+                        src = Kh + ((long)key * ldk + ((rg & 1) ? cs1 : cs0)) * 2;
+                    }
+                } else {
+                    const int col = last ? min(tp * 128 + half * 64, ldvt - 64) : tp * 128 + half * 64;
+                    src = Vh + ((long)(8 * rg) * ldvt + col) * 2 + ((rg & 1) ? vlane1 : vlane0);
+                }
+                __builtin_amdgcn_global_load_lds((agbl_ptr_t)src, (alds_ptr_t)dst, 16, 0, 0);
+            }
+        }
+    };
 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;  // m_run in raw score units (before the softmax scale)
 
-    STAGE(0, 0);
+    // fragment read offsets: K rows qc / 32+qc, chunk 2*ks + h  ->  base ^ (ks << 5)
+    const int kbase = a_lds_off(qc, h);
+    const int vbase = a_lds_off(qc, 0) + 8 * h;  // V^T rows qc / 32+qc, chunk c -> base ^ (c << 4)
+
+    stage(0, 0);
     for (int tp = 0; tp < ntp; ++tp) {
         const int buf = tp & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tp + 1 < ntp) STAGE(buf ^ 1, tp + 1);
+        if (tp + 1 < ntp) stage(buf ^ 1, tp + 1);
         const int key_start = tp * 128 + kh * 64;
         if (key_start < Tk) {  // wave-uniform: a wholly out-of-range tile is skipped
             const unsigned char *Kt = smem + buf * 32768 + kh * 8192;
@@ -102,8 +133,8 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t *__res
             for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const abf16x8 k0 = *reinterpret_cast<const abf16x8 *>(Kt + a_lds_off(qc, 2 * ks + h));
-                const abf16x8 k1 = *reinterpret_cast<const abf16x8 *>(Kt + a_lds_off(32 + qc, 2 * ks + h));
+                const abf16x8 k0 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)));
+                const abf16x8 k1 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)) + 4096);
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
             }
@@ -117,24 +148,37 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t *__res
                     if (key0 + 32 >= Tk) s1[r] = -INFINITY;
                 }
             }
-            float mx = fmaxf(s0[0], s1[0]);
+            float mx = max3f(s0[0], s1[0], s0[1]);
+            mx = max3f(mx, s1[1], s0[2]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 2; r < 15; ++r) mx = max3f(mx, s1[r], s0[r + 1]);
+            mx = max3f(mx, s1[15], __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both halves now hold the row maximum
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-            const float mc = -m_new * scale_log2e;
-            m_run = m_new;
-            float psum = 0.f;
+            // rescale the running state only when some query of the wave saw a new maximum (wave-uniform branch)
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, mc));
-                s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, mc));
-                psum += s0[r] + s1[r];
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                m_run = m_new;
             }
-            l_run = l_run * alpha + psum;
+            const float mc = -m_run * scale_log2e;
+            const af32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
+            af32x2 ps = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int r = 0; r < 16; r += 2) {
+                af32x2 a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
+                a = a * sc2 + mc2;  // v_pk_fma_f32
+                b = b * sc2 + mc2;
+                a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+                b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
+                s0[r] = a[0]; s0[r + 1] = a[1];
+                s1[r] = b[0]; s1[r + 1] = b[1];
+                ps += a;
+                ps += b;
+            }
+            l_run += ps[0] + ps[1];
             // ---- O^T += V^T . P^T   (4 k-steps of 16 keys)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -146,18 +190,17 @@ __global__ __launch_bounds__(512, 4) void attention_kernel(const uint16_t *__res
                 }
                 // keys of element j: 16*kk + 8*(j>>2) + 4h + (j&3)  -> two 8-byte reads per d row
                 const int c0 = 2 * kk, c1 = 2 * kk + 1;
-                const abf16x4 a = *reinterpret_cast<const abf16x4 *>(Vtl + a_lds_off(qc, c0) + 8 * h);
-                const abf16x4 b = *reinterpret_cast<const abf16x4 *>(Vtl + a_lds_off(qc, c1) + 8 * h);
+                const abf16x4 a = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c0 << 4)));
+                const abf16x4 b = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c1 << 4)));
                 const abf16x8 v0 = abf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                const abf16x4 c = *reinterpret_cast<const abf16x4 *>(Vtl + a_lds_off(32 + qc, c0) + 8 * h);
-                const abf16x4 d = *reinterpret_cast<const abf16x4 *>(Vtl + a_lds_off(32 + qc, c1) + 8 * h);
+                const abf16x4 c = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c0 << 4)) + 4096);
+                const abf16x4 d = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c1 << 4)) + 4096);
                 const abf16x8 v1 = abf16x8{c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
             }
         }
     }
-#undef STAGE
     // ---- merge the two key halves of each query block through LDS: layout [qi][r (0..33)][lane]
     float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     __syncthreads();  // all tile reads done; staging memory becomes scratch
@@ -204,7 +247,7 @@ extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t 
     SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
     SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
-    hipLaunchKernelGGL(attention_kernel, dim3(cdiv(Tq, 128), heads), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk,
+    hipLaunchKernelGGL(attention_kernel<4>, dim3(cdiv(Tq, 128), heads), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk,
                        Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
     SC_LAUNCH_CHECK();
     return 0;
