@@ -75,6 +75,33 @@ def one_step(model, img_dev, events=None):
     return v, f
 
 
+def stage_split(model, img_dev, n=5):
+    """ms per stage (HIP events on torch's stream, median of n untimed extra steps): SURVEY 8d's stage split."""
+    from sculptmate_amd import ops
+
+    r = model.renderer.cfg.radius
+    rows = []
+    for _ in range(n):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        e[0].record()
+        ctx, _ = model.image_tokens(img_dev)
+        e[1].record()
+        _, outb = model.backbone_tokens(ctx)
+        e[2].record()
+        planes = model.scene_code(outb)
+        e[3].record()
+        vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
+                               out_add=-THRESHOLD)
+        e[4].record()
+        ops.marching_cubes(vol.view(MC_RES, MC_RES, MC_RES), 0.0, reference_order=True, vert_div=MC_RES - 1.0,
+                           vert_mul=r - (-r), vert_add=-r)
+        e[5].record()
+        torch.cuda.synchronize()
+        rows.append([e[i].elapsed_time(e[i + 1]) for i in range(5)])
+    med = np.median(np.array(rows), 0)
+    return dict(zip(("image_tokenizer", "backbone", "upsample", "density_grid", "marching_cubes"), [round(float(x), 3) for x in med]))
+
+
 def cpu_baseline(sd, img_np, planes_np):
     """The oracle (CPU restatement of the reference) timed on this box's host cores on a bounded
     sample of the same workload: full TSR.forward for one image (torch fp32, all cores), the dense
@@ -187,6 +214,8 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3},
         }
+        with torch.no_grad():
+            out["stages_ms"] = stage_split(model, imgs[0])  # outside the timed region
         if args.gpus == 1 and not args.no_cpu_baseline:
             with torch.no_grad():
                 ctx, _ = model.image_tokens(imgs[0])
