@@ -13,7 +13,7 @@
 //       sorted at run time.  Face order = all one-triangle tets in tet order, then all two-triangle tets
 //       (:190-207): two more scans.  Output is bit-identical to the reference given the same sdf / grid.
 //
-// All of this is HBM-bound index work: coalesced int32 streams, ballot/popcount block scans.
+// All of this is HBM-bound index work: coalesced int32 streams, shuffle-based block scans, no atomics.
 #include <math.h>
 
 #include "common.h"
