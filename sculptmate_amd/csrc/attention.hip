@@ -60,8 +60,11 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = wave % NQB, kh = wave / NQB;
     const int qc = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y;
-    const int q = blockIdx.x * (NQB * 32) + qi * 32 + qc;
+    // each XCD works on whole heads (2 of 16 here): their K/V (0.8 MB per head) stay in that XCD's 4 MB L2 while
+    // the head's 24 query blocks re-stage them
+    const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int head = tile / gridDim.x;
+    const int q = (tile % gridDim.x) * (NQB * 32) + qi * 32 + qc;
     const int qld = min(q, Tq - 1);
 
     // Q fragments (B operand): Q[q][16*ks + 8h + j]

@@ -38,6 +38,14 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // number of CUs of the current device (cached)
 int num_cus();
 
+// XCD-aware tile order (guide T1, bijective form): workgroups are handed to the 8 XCDs round-robin by linear id, and
+// every XCD has a private L2; this returns a tile index such that the workgroups sharing an XCD (same id % 8) get a
+// CONTIGUOUS chunk of the natural tile order, so tiles that share an operand panel hit the same L2.
+__device__ __forceinline__ int xcd_tile(int orig, int nwg) {
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));

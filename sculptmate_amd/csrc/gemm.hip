@@ -61,6 +61,7 @@ struct GemmArgs {
     uint16_t *out_t; int ldt;
     int M, N, K;
     int n_split;  // columns >= n_split go ONLY to out_t (row n - n_split); columns < n_split skip out_t
+    int n_major;  // XCD chunks run over all activation-row tiles of a few weight tiles (W larger than A) or the reverse
 };
 
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
@@ -79,8 +80,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? BW / 2 : BW;  // output columns per block
     constexpr int TI = BW / 32;                                     // 16-row weight sub-tiles per wave
-    const int n0 = blockIdx.x * NOUT;
-    const int m0 = blockIdx.y * BM;
+    // XCD-aware order: the workgroups of one XCD (private L2) take a contiguous band of the tile grid -- a band of
+    // activation rows with every weight tile, or (n_major, when W is the larger operand) a band of weight rows with
+    // every activation tile -- so the band's panel is fetched into that L2 once and only the smaller operand streams.
+    const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int n0 = (g.n_major ? tile / gridDim.y : tile % gridDim.x) * NOUT;
+    const int m0 = (g.n_major ? tile % gridDim.y : tile / gridDim.x) * BM;
 
     // ---- staging addresses.  One wave instruction fills 8 tile rows (1 KiB).  Lane l of the
     // instruction that fills rows 8q..8q+7 writes LDS chunk (row = 8q + l/8, slot = l%8) and must
@@ -255,7 +260,9 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     if (n_split <= 0 || n_split > N) n_split = N;  // no split: every column goes to every given output
     SC_REQUIRE(n_split % 16 == 0, "gemm_bf16: n_split=%d must be a multiple of 16", n_split);
     SC_REQUIRE(n_split == N || out_bf16_t, "gemm_bf16: n_split needs the transposed output");
-    GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split};
+    const long w_rows = (epilogue == SCULPT_EPI_GEGLU) ? 2L * N : N;
+    GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
+               w_rows > (long)M ? 1 : 0};
     const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     if (epilogue == SCULPT_EPI_GEGLU) {
