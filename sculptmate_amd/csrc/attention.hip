@@ -55,7 +55,8 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
                                                                   float scale_log2e) {
     constexpr int NW = 2 * NQB;  // waves
     // [stage][K0 | K1 | V0 | V1] sub-tiles of 8 KiB (64 rows x 128 B); reused as merge scratch at the end
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 4 * 8192];
+    constexpr int SMEM = (NQB * 34 * 64 * 4 > 2 * 4 * 8192) ? NQB * 34 * 64 * 4 : 2 * 4 * 8192;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = wave % NQB, kh = wave / NQB;
@@ -250,6 +251,12 @@ extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t 
     SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
     SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
+    // 256-query workgroups (16 waves, one per CU) halve the K/V re-staging; worth it once they still cover 3/4 of the CUs
+    const bool big = (long)cdiv(Tq, 256) * heads * 4 >= (long)num_cus() * 3;
+    if (big)
+        hipLaunchKernelGGL(attention_kernel<8>, dim3(cdiv(Tq, 256), heads), dim3(1024), 0, as_stream(stream), Q, ldq, K, ldk,
+                           Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
+    else
     hipLaunchKernelGGL(attention_kernel<4>, dim3(cdiv(Tq, 128), heads), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk,
                        Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
     SC_LAUNCH_CHECK();
