@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     if not force and is_fresh():
         return SO
     cmd = [hipcc(), "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", SO + ".tmp"] + sources()
+           "-Wno-unused-result", "-o", SO + ".tmp"] + os.environ.get("SCULPT_EXTRA_HIPCC_FLAGS", "").split() + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -72,10 +72,24 @@ __device__ __forceinline__ float silu_f(float x) {
     float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * x);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+typedef float tf32x2 __attribute__((ext_vector_type(2)));
+// 16 SiLUs with the three full-rate operations on PAIRS (v_pk_mul / v_pk_add / v_pk_mul: bit-identical to the scalar
+// forms): every VALU instruction, transcendental or not, takes the fp32 matrix pipe's issue slot for ~4 cycles
+// (measured: replacing v_rcp by 7 plain ops costs +8 %, sharing one v_rcp per pair at +3 plain ops costs +2 %), so
+// the lever is the instruction COUNT: 5 -> 3.5 per value (-1.7 % kernel time).
 __device__ __forceinline__ f32x16 silu16(f32x16 v) {
     f32x16 o;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = silu_f(v[i]);
+    for (int i = 0; i < 16; i += 2) {
+        tf32x2 x = {v[i], v[i + 1]};
+        const tf32x2 k = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.0f, 1.0f};
+        tf32x2 t = x * k;
+        tf32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        tf32x2 d = e + one;
+        tf32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        tf32x2 y = x * r;
+        o[i] = y[0]; o[i + 1] = y[1];
+    }
     return o;
 }
 
@@ -125,6 +139,8 @@ __device__ __forceinline__ void hidden_layers(const LdsView &L, int NH, int lane
         f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
         const f32x4 *A0 = reinterpret_cast<const f32x4 *>(L.hid) + ((l * 2 + 0) * 8) * 64 + lane;
         const f32x4 *A1 = reinterpret_cast<const f32x4 *>(L.hid) + ((l * 2 + 1) * 8) * 64 + lane;
+        // (reading the A operands one group ahead in the source changes nothing measurable: the scheduler places the
+        // ds_read_b128 pairs itself and four waves per SIMD cover the LDS latency)
 #pragma unroll
         for (int s4 = 0; s4 < 8; ++s4) {
             f32x4 a0 = A0[s4 * 64];
@@ -395,7 +411,8 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
     load_weights_to_lds(smem, blob, hd);
     const LdsView L = lds_view(smem, NH);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // tile bookkeeping stays on the scalar unit
     const int p = lane & 31, h = lane >> 5;
     // Measured (rocprofv3 PMC, profiles/round1/pmc_density_counters.txt): the matrix pipe is busy 78 % of
     // the kernel at 2.38 GHz; the rest is the SiLU VALU work (v_exp/v_rcp + 3 full-rate ops per value),
@@ -408,11 +425,15 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
     const long nw_total = (long)gridDim.x * nwave;
     const long wid = (long)blockIdx.x * nwave + wave;
     const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    // (iy, zb, ixl) of the first tile by division once, then carried incrementally (all wave-uniform)
+    int iy = (int)(t_begin % R);
+    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
 
-    for (long t = t_begin; t < t_end; ++t) {
-        const int iy = (int)(t % R);
-        const long u = t / R;
-        const int zb = (int)(u % nzb), ixl = (int)(u / nzb);
+    for (long t = t_begin; t < t_end; ++t, ++iy) {
+        if (iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+        }
         const int iz = zb * 32 + p;
         const int izc = min(iz, R - 1);
         f32x16 x0, x1, y0, y1;
