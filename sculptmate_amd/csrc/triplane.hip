@@ -404,7 +404,8 @@ __device__ __forceinline__ void load_row32(const float *row, f32x16 &a, f32x16 &
 template <int NT>
 __global__ __launch_bounds__(NT) void density_grid_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out,
+    int xcd_band) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
@@ -423,7 +424,11 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
     const long ntiles = (long)nx * nzb * R;
     // contiguous tile range per wave: consecutive tiles share (ix, zb) and walk iy
     const long nw_total = (long)gridDim.x * nwave;
-    const long wid = (long)blockIdx.x * nwave + wave;
+    // XCD-aware wave order: the workgroups of one XCD (same blockIdx % 8) take one contiguous band of ix, so that
+    // XCD's L2 streams only its band of the FA / FB tables (FC is indexed by (iy, iz) and is read by every XCD)
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (xcd_band && gridDim.x % 8 == 0)
+        wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
     const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
     // (iy, zb, ixl) of the first tile by division once, then carried incrementally (all wave-uniform)
     int iy = (int)(t_begin % R);
@@ -611,16 +616,17 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
     const float *FC = FB + (size_t)nx * R * 64;
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
     static int nthreads = getenv("SCULPT_DENSITY_THREADS") ? atoi(getenv("SCULPT_DENSITY_THREADS")) : 1024;
+    static int xcd_band = getenv("SCULPT_DENSITY_NO_XCD_BAND") ? 0 : 1;
     if (nthreads == 1024) {
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
         hipLaunchKernelGGL(density_grid_kernel<1024>, dim3(grid), dim3(1024), lds, st,
-                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out);
+                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out, xcd_band);
     } else {
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
         hipLaunchKernelGGL(density_grid_kernel<512>, dim3(grid), dim3(512), lds, st,
-                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out);
+                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out, xcd_band);
     }
     SC_LAUNCH_CHECK();
     return 0;
