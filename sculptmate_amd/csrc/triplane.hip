@@ -107,6 +107,8 @@ __device__ __forceinline__ LdsView lds_view(float *smem, int NH) {
     return v;
 }
 
+__host__ __device__ __forceinline__ int lds_floats_for(int NH) { return NH * 4096 + (NH + 1) * 64 + 256 + 4; }
+
 __device__ __forceinline__ void load_weights_to_lds(float *smem, const float *blob, const MlpPackHeader &hd) {
     const int NH = hd.NH;
     const int nh4 = NH * 4096 / 4;
@@ -205,11 +207,21 @@ __global__ __launch_bounds__(512) void query_points_kernel(
     const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
     const float *__restrict__ pts, long N, float radius, float span, float density_bias,
     float *__restrict__ density, float *__restrict__ features, float *__restrict__ density_act,
-    float *__restrict__ color) {
+    float *__restrict__ color, int a0_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K0 = 3 * C, S0 = K0 / 2;
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
+    // layer-0 A operands in LDS as [T][s/4][lane][4] (one ds_read_b128 = four k-steps) when they fit next to the
+    // hidden layers (30 KiB; not with 8 hidden layers = 128 KiB): 30 LDS reads per tile instead of 120 global loads
+    float *a0s = smem + lds_floats_for(NH);
+    if (CL && a0_lds) {
+        const float *src = blob + hd.off_a0;
+        for (int i = threadIdx.x; i < 2 * S0 * 64; i += blockDim.x) {
+            const int ln = i & 63, s = (i >> 6) % S0, T = (i >> 6) / S0;
+            a0s[((T * (S0 / 4) + (s >> 2)) * 64 + ln) * 4 + (s & 3)] = src[i];
+        }
+    }
     load_weights_to_lds(smem, blob, hd);
     const LdsView L = lds_view(smem, NH);
 
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(512) void query_points_kernel(
             static_assert(C % 4 == 0 && (3 * C / 2) % 4 == 0, "channel-last path reads groups of four channels");
             constexpr int C4 = C / 4;
             const f32x4 *P4 = reinterpret_cast<const f32x4 *>(planes);
-#pragma unroll 3
+#pragma unroll 5
             for (int gq = 0; gq < S0 / 4; ++gq) {
                 const int f = h * S0 + 4 * gq;
                 const int pl = f / C, ch4 = (f - pl * C) >> 2;
@@ -265,17 +277,25 @@ __global__ __launch_bounds__(512) void query_points_kernel(
                 const float w2 = pl == 0 ? wt[0][2] : (pl == 1 ? wt[1][2] : wt[2][2]);
                 const float w3 = pl == 0 ? wt[0][3] : (pl == 1 ? wt[1][3] : wt[2][3]);
                 const f32x4 t0 = B[(long)o0 * C4], t1 = B[(long)o1 * C4], t2 = B[(long)o2 * C4], t3 = B[(long)o3 * C4];
+                f32x4 qa0, qa1;
+                if (a0_lds) {
+                    qa0 = reinterpret_cast<const f32x4 *>(a0s)[(0 * (S0 / 4) + gq) * 64 + lane];
+                    qa1 = reinterpret_cast<const f32x4 *>(a0s)[(1 * (S0 / 4) + gq) * 64 + lane];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        qa0[j] = A0g[(0 * S0 + 4 * gq + j) * 64 + lane];
+                        qa1[j] = A0g[(1 * S0 + 4 * gq + j) * 64 + lane];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = t0[j] * w0;  // same tap order as torch: nw + ne + sw + se
                     v += t1[j] * w1;
                     v += t2[j] * w2;
                     v += t3[j] * w3;
-                    const int s = 4 * gq + j;
-                    const float a0 = A0g[(0 * S0 + s) * 64 + lane];
-                    const float a1 = A0g[(1 * S0 + s) * 64 + lane];
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, v, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, v, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa0[j], v, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa1[j], v, acc1, 0, 0, 0);
                 }
             }
         } else {
@@ -561,9 +581,12 @@ int sculpt_triplane_query_ex(const float *planes, int C, int H, int W, const voi
     if (N <= 0) return 0;
     SC_REQUIRE(points, "triplane_query: null points");
     SC_REQUIRE(n_hidden_64 >= 0, "triplane_query: bad n_hidden_64");
-    const size_t lds = lds_bytes_for(n_hidden_64);
+    size_t lds = lds_bytes_for(n_hidden_64);
     SC_REQUIRE(lds <= 160 * 1024, "triplane_query: %d hidden layers do not fit LDS", n_hidden_64);
     const bool ac = flags & SCULPT_QUERY_ALIGN_CORNERS, cl = flags & SCULPT_QUERY_CHANNEL_LAST;
+    const size_t a0_bytes = (size_t)3 * C * 64 * sizeof(float);
+    const int a0_lds = (cl && lds + a0_bytes <= 160 * 1024) ? 1 : 0;
+    if (a0_lds) lds += a0_bytes;
     auto kern = cl ? (ac ? query_points_kernel<40, true, true> : query_points_kernel<40, false, true>)
                    : (ac ? query_points_kernel<40, true, false> : query_points_kernel<40, false, false>);
     SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -572,7 +595,7 @@ int sculpt_triplane_query_ex(const float *planes, int C, int H, int W, const voi
     const float span = (float)((double)radius - (double)(-radius));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, planes, H, W,
                        reinterpret_cast<const float *>(mlp_packed), points, (long)N, radius, span,
-                       density_bias, density, features, density_act, color);
+                       density_bias, density, features, density_act, color, a0_lds);
     SC_LAUNCH_CHECK();
     return 0;
 }
