@@ -128,9 +128,9 @@ def make_post():
     from sf3d.models.network import PixelShuffleUpsampleNetwork
 
     torch.manual_seed(0)
-    net = PixelShuffleUpsampleNetwork(dict(in_channels=64, out_channels=40, scale_factor=4, conv_layers=4)).eval()
+    net = PixelShuffleUpsampleNetwork(dict(in_channels=32, out_channels=40, scale_factor=2, conv_layers=4)).eval()
     randomize(net, 7)
-    x = torch.randn(1, 3, 64, 4, 4, generator=torch.Generator().manual_seed(8))
+    x = torch.randn(1, 3, 32, 5, 5, generator=torch.Generator().manual_seed(8))
     with torch.no_grad():
         y = net(x)
     out = {"out": y.numpy(), "x": x.numpy()}
@@ -166,7 +166,7 @@ def make_decoder():
     randomize(dec, 9, scale=None)
     g = torch.Generator().manual_seed(10)
     planes = torch.randn(3, 40, 24, 24, generator=g)
-    pts = (torch.rand(4096, 3, generator=g) * 2 - 1) * 0.87
+    pts = (torch.rand(1024, 3, generator=g) * 2 - 1) * 0.87
     pts[:8] = torch.tensor([[0.87, 0.87, 0.87], [-0.87, -0.87, -0.87], [0.87, -0.87, 0.0], [0.0, 0.0, 0.0],
                             [0.9, 0.2, -0.95], [-1.2, 0.0, 0.3], [0.435, -0.435, 0.87], [-0.87, 0.5, 0.1]])
     stub = types.SimpleNamespace(cfg=types.SimpleNamespace(radius=0.87))
