@@ -11,6 +11,7 @@ find $OUT/trace -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $OUT/ker
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 python3 tools/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1
+python3 tools/pmc_to_json.py $OUT $OUT/pmc_density_grid.json > $OUT/pmc_to_json.log 2>&1
 # keep only small files
 find $OUT -name "*.csv" -size +8M -delete
 ls -la $OUT $OUT/trace/* | head -40
