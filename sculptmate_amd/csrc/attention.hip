@@ -240,6 +240,14 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     }
 }
 
+
+// A "ping-pong" variant of this kernel (the two key-half groups offset by half an iteration, so that on every SIMD
+// one wave runs its QK^T / PV MFMAs while its partner runs softmax; K/V prefetched two tile pairs ahead into LDS
+// rings, one 8-wave workgroup per CU) was built, was bit-identical, and was SLOWER: 88 us vs 70 us at
+// 3072 x 3072 x 16 heads, with the matrix and softmax segments adding up exactly (38 + 23 us) instead of overlapping.
+// tools/micro/mfma_valu_overlap.hip shows why: on gfx950 a partner wave's fp32 FMA-class VALU work (v_fma, v_pk_fma,
+// v_pk_mul, v_pk_add) does not overlap bf16 MFMAs on the same SIMD (times add), while v_exp, v_max3, v_cvt_pk and
+// integer VALU do (times ~max).  The structure above therefore stays; what pays is fewer FMA-class instructions.
 }  // namespace sculpt
 
 using namespace sculpt;
