@@ -28,6 +28,7 @@ import torch  # noqa: E402
 
 FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (only used with --decoder-precision bf16x3)
 MC_RES = 256
 THRESHOLD = 25.0
 
@@ -61,6 +62,9 @@ def calibrate(model, sd, img_dev, inside=0.015):
     return shift
 
 
+DECODER_PRECISION = "fp32"  # --decoder-precision bf16x3 selects the optional split-operand bf16 mode
+
+
 def one_step(model, img_dev, events=None):
     ctx, _ = model.image_tokens(img_dev)
     _, outb = model.backbone_tokens(ctx)
@@ -69,7 +73,7 @@ def one_step(model, img_dev, events=None):
 
     r = model.renderer.cfg.radius
     vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
-                           out_add=-THRESHOLD, events=events)
+                           out_add=-THRESHOLD, events=events, precision=DECODER_PRECISION)
     v, f = ops.marching_cubes(vol.view(MC_RES, MC_RES, MC_RES), 0.0, reference_order=True, vert_div=MC_RES - 1.0,
                               vert_mul=r - (-r), vert_add=-r)
     return v, f
@@ -91,7 +95,7 @@ def stage_split(model, img_dev, n=5):
         planes = model.scene_code(outb)
         e[3].record()
         vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
-                               out_add=-THRESHOLD)
+                               out_add=-THRESHOLD, precision=DECODER_PRECISION)
         e[4].record()
         ops.marching_cubes(vol.view(MC_RES, MC_RES, MC_RES), 0.0, reference_order=True, vert_div=MC_RES - 1.0,
                            vert_mul=r - (-r), vert_add=-r)
@@ -141,7 +145,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decoder-precision", choices=("fp32", "bf16x3"), default="fp32",
+                    help="fp32 (default, exact-fp32 MFMA density MLP) or bf16x3 (optional split-operand bf16 MFMA mode)")
     args = ap.parse_args()
+    global DECODER_PRECISION
+    DECODER_PRECISION = args.decoder_precision
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,6 +194,8 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0:
         achieved = FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12
+        x3 = DECODER_PRECISION == "bf16x3"
+        peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_density_grid.json")
         if os.path.exists(pmc):
@@ -204,14 +214,18 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (density MLP + marching cubes) / bf16 (transformer)",
+            "dtype": ("bf16x3 split operands, fp32 accumulate (density MLP hidden layers; ~3e-4 rel. density error) / f32 "
+                      "(tables, SiLU, marching cubes) / bf16 (transformer)") if x3 else
+                     "f32 (density MLP + marching cubes) / bf16 (transformer)",
             "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
             "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
                        "mc_resolution": MC_RES, "threshold": THRESHOLD, "images_per_gpu_per_step": 1,
                        "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
-            "roofline": {"kernel": "density_grid_kernel (fused triplane-sum + NeRF-MLP, fp32 MFMA)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"kernel": ("density_grid_x3_kernel (fused triplane-sum + NeRF-MLP, bf16x3 MFMA: 3 MFMA flops per "
+                                    "algorithmic flop)") if x3 else
+                                   "density_grid_kernel (fused triplane-sum + NeRF-MLP, fp32 MFMA)",
+                         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None if x3 else traffic,
                          "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3},
         }
         with torch.no_grad():

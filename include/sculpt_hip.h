@@ -111,6 +111,13 @@ int sculpt_plane_features(const float *planes, int C, int H, int W, const void *
 int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                         float density_bias, float out_add, const void *workspace, float *out,
                         sculpt_stream_t stream);
+/* Same with flags.  SCULPT_DENSITY_BF16X3 (optional fast mode, NOT the default): the 64x64 hidden layers run on bf16
+ * MFMA with both operands split into bf16 pairs (W.x ~= Wh.xh + Wh.xl + Wl.xh, fp32 accumulate: ~2^-17 relative
+ * product error, fp32 range); tables, SiLU, last layer and exp stay fp32. */
+#define SCULPT_DENSITY_BF16X3 1u
+int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
+                           float density_bias, float out_add, const void *workspace, float *out, unsigned flags,
+                           sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Marching cubes (Lewiner), output identical to skimage.measure.marching_cubes(vol, level)

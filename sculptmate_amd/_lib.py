@@ -43,6 +43,7 @@ SIGNATURES = {
     "sculpt_density_grid_workspace_bytes": (_sz, [_i, _i]),
     "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "sculpt_density_grid_ex": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _u, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
@@ -92,6 +93,7 @@ ERR_MC_EMPTY = 12
 EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_RELU = 0, 1, 2, 3
 QUERY_ALIGN_CORNERS = 1
 QUERY_CHANNEL_LAST = 2
+DENSITY_BF16X3 = 1
 
 
 def last_error():

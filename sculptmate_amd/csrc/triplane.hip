@@ -42,11 +42,25 @@ struct MlpPackHeader {
     int32_t off_hid;   // [NH][2 T][8 s4][64 lane][4]
     int32_t off_wlast; // [4][2 h][2 t][16 r]
     int32_t off_blast; // [4]
-    int32_t pad[5];
+    int32_t off_x3;    // [NH][hi|lo][2 T][4 s][64 lane][8] bf16 (as 4096 floats per layer): split weights, bf16x3 mode
+    int32_t pad[4];
 };
 static_assert(sizeof(MlpPackHeader) == 64, "header is 16 words");
 
 __host__ __device__ __forceinline__ int nrow(int t, int r, int h) { return 32 * t + 8 * (r >> 2) + 4 * h + (r & 3); }
+
+static inline uint16_t host_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float host_bf16_to_f32(uint16_t v) {
+    uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 
 static void pack_layout(int K0, int NH, MlpPackHeader *hd) {
     memset(hd, 0, sizeof(*hd));
@@ -61,6 +75,8 @@ static void pack_layout(int K0, int NH, MlpPackHeader *hd) {
     hd->off_hid = o;   o += NH * 2 * 8 * 64 * 4;
     hd->off_wlast = o; o += 4 * 64;
     hd->off_blast = o; o += 4;
+    o = (o + 3) & ~3;
+    hd->off_x3 = o;    o += NH * 4096;
     hd->total_floats = (o + 3) & ~3;
 }
 
@@ -474,6 +490,113 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x3 mode of the dense grid (optional, SCULPT_DENSITY_BF16X3): the eight 64x64 hidden layers on
+// v_mfma_f32_32x32x16_bf16 with BOTH operands split into bf16 pairs, x = xh + xl, W = Wh + Wl, and
+//   W.x ~= Wh.xh + Wh.xl + Wl.xh      (every bf16 x bf16 product is exact in fp32; fp32 accumulate)
+// i.e. products carry ~2^-17 relative error instead of fp32's 2^-24 -- "fp32-range, 16-bit-mantissa products".
+// 24 bf16 MFMAs (768 cycles) per layer and 32 points instead of 64 fp32 MFMAs (4096 cycles).  First layer
+// (fp32 tables), SiLU, the last layer and exp stay fp32.  The accumulator of layer l is the B operand of layer
+// l+1 after the split (k order permuted, see sculpt_mlp_pack), so activations still never leave registers.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 tbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// x (16 fp32 accumulator values of one 32-neuron tile) -> two B-operand vectors per part: hi[2], lo[2]
+__device__ __forceinline__ void split16(const f32x16 &x, tbf16x8 hi[2], tbf16x8 lo[2]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 ph, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = x[8 * q + 2 * i], b = x[8 * q + 2 * i + 1];
+            const unsigned h2 = cvt_pk_bf16(a, b);
+            const float ah = __uint_as_float(h2 << 16), bh = __uint_as_float(h2 & 0xffff0000u);
+            ph[i] = h2;
+            pl[i] = cvt_pk_bf16(a - ah, b - bh);
+        }
+        hi[q] = __builtin_bit_cast(tbf16x8, ph);
+        lo[q] = __builtin_bit_cast(tbf16x8, pl);
+    }
+}
+
+__global__ __launch_bounds__(1024) void density_grid_x3_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [x3 weights NH*4096][bacc][wlast][blast]
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
+        float *bacc = smem + NH * 4096;
+        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
+        float *wl = bacc + (NH + 1) * 64;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
+        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
+        __syncthreads();
+    }
+    const LdsView L = lds_view(smem, NH);
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int nzb = (R + 31) / 32;
+    const long ntiles = (long)nx * nzb * R;
+    const long nw_total = (long)gridDim.x * nwave;
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    int iy = (int)(t_begin % R);
+    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
+    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;  // [l][part][T][s][lane]
+
+    for (long t = t_begin; t < t_end; ++t, ++iy) {
+        if (iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+        }
+        const int iz = zb * 32 + p;
+        const int izc = min(iz, R - 1);
+        f32x16 x0, x1, y0, y1;
+        load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
+        load_row32(FB + ((long)ixl * R + izc) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        x0 = silu16(x0); x1 = silu16(x1);
+        for (int l = 0; l < NH; ++l) {
+            tbf16x8 bh[4], bl[4];  // B operands of the four k-steps: tiles (x0: s = 0,1), (x1: s = 2,3)
+            split16(x0, bh, bl);
+            split16(x1, bh + 2, bl + 2);
+            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
+            const tbf16x8 *Al = A + (long)l * 16 * 64;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const tbf16x8 ah0 = Al[((0 * 2 + 0) * 4 + s4) * 64], ah1 = Al[((0 * 2 + 1) * 4 + s4) * 64];
+                const tbf16x8 al0 = Al[((1 * 2 + 0) * 4 + s4) * 64], al1 = Al[((1 * 2 + 1) * 4 + s4) * 64];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[s4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[s4], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[s4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[s4], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[s4], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[s4], acc1, 0, 0, 0);
+            }
+            x0 = silu16(acc0);
+            x1 = silu16(acc1);
+        }
+        const float d = last_dot(L, 0, h, x0, x1);
+        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
+    }
+}
+
 }  // namespace sculpt
 
 namespace sculpt {
@@ -558,6 +681,23 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
             for (int t = 0; t < 2; ++t)
                 for (int r = 0; r < 16; ++r) o[hd.off_wlast + ((oo * 2 + h) * 2 + t) * 16 + r] = WL[(size_t)oo * HID + nrow(t, r, h)];
     for (int oo = 0; oo < 4; ++oo) o[hd.off_blast + oo] = bh[n_layers - 1][oo];
+    // bf16x3 mode: W = Wh + Wl (both bf16, round-to-nearest-even), k order = the accumulator order of the previous
+    // layer seen as a 32x32x16 B operand: k(s, kg, j) = 16 s + 8 (j >> 2) + 4 kg + (j & 3)
+    uint16_t *x3 = reinterpret_cast<uint16_t *>(o + hd.off_x3);
+    for (int l = 0; l < NH; ++l) {
+        const float *Wl = Wh[l + 1];
+        for (int part = 0; part < 2; ++part)
+            for (int T = 0; T < 2; ++T)
+                for (int s4 = 0; s4 < 4; ++s4)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * s4 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                            const float w = Wl[(size_t)(32 * T + (lane & 31)) * HID + k];
+                            const uint16_t hi = host_f32_to_bf16(w);
+                            const uint16_t lo = host_f32_to_bf16(w - host_bf16_to_f32(hi));
+                            x3[(size_t)l * 8192 + ((((part * 2 + T) * 4 + s4) * 64 + lane) * 8) + j] = part ? lo : hi;
+                        }
+    }
     return 0;
 }
 
@@ -627,6 +767,13 @@ int sculpt_plane_features(const float *planes, int C, int H, int W, const void *
 int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                         float density_bias, float out_add, const void *workspace, float *out,
                         sculpt_stream_t stream) {
+    return sculpt_density_grid_ex(mlp_packed, n_hidden_64, R, x_begin, x_end, density_bias, out_add, workspace, out, 0u,
+                                  stream);
+}
+
+int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
+                           float density_bias, float out_add, const void *workspace, float *out, unsigned flags,
+                           sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     SC_REQUIRE(mlp_packed && workspace && out, "density_grid: null argument");
     SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "density_grid: bad range [%d,%d) of %d", x_begin, x_end, R);
@@ -638,6 +785,14 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
     const float *FB = FA + (size_t)nx * R * 64;
     const float *FC = FB + (size_t)nx * R * 64;
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
+    if (flags & SCULPT_DENSITY_BF16X3) {
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
+        hipLaunchKernelGGL(density_grid_x3_kernel, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed),
+                           FA, FB, FC, R, nx, density_bias, out_add, out);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     static int nthreads = getenv("SCULPT_DENSITY_THREADS") ? atoi(getenv("SCULPT_DENSITY_THREADS")) : 1024;
     static int xcd_band = getenv("SCULPT_DENSITY_NO_XCD_BAND") ? 0 : 1;
     if (nthreads == 1024) {

@@ -139,3 +139,38 @@ def test_channel_last_query_is_bit_identical_to_reference_layout(cuda, align):
     b = ops.triplane_query(cl, mlp, pts, align_corners=align)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_density_grid_bf16x3_mode_accuracy_and_mesh(cuda):
+    """Optional split-operand bf16 mode of the dense query: density within 1e-3 relative of the fp32 kernel and of the
+    oracle (measured 3-4e-4), mesh vertices within 1e-4 of the bounding box of the fp32 mesh (north-star tolerance)."""
+    import torch
+    from scipy.spatial import cKDTree
+
+    from sculptmate_amd import ops, synth
+
+    sd = synth.decoder_state(1)
+    Ws, bs = synth.decoder_lists(sd)
+    tri_np = synth.smooth_triplane(seed=2, scale=3.0)
+    pre = np.log(capi.density_grid(tri_np, Ws, bs, 16)) + 1.0
+    bs[-1] = bs[-1].copy()
+    bs[-1][0] += synth.calibrate_density_bias(pre, inside_fraction=0.1)
+    mlp = ops.PackedMLP(Ws, bs, cuda)
+    tri = torch.from_numpy(tri_np).to(cuda)
+    R = 96
+    a = ops.density_grid(tri, mlp, R)
+    b = ops.density_grid(tri, mlp, R, precision="bf16x3")
+    rel = ((a - b).abs() / a).max().item()
+    assert rel < 1e-3, rel
+    ref = capi.density_grid(tri_np, Ws, bs, R)
+    assert np.abs(np.log(b.cpu().numpy()) - np.log(ref)).max() < 1e-3
+    # slabs of the lattice are consistent in this mode too
+    c = ops.density_grid(tri, mlp, R, precision="bf16x3", x_begin=10, x_end=20)
+    assert torch.equal(c, b.view(R, R, R)[10:20].reshape(-1))
+    va, fa = ops.marching_cubes((a - 25.0).view(R, R, R), 0.0)
+    vb, fb = ops.marching_cubes((b - 25.0).view(R, R, R), 0.0)
+    assert abs(va.shape[0] - vb.shape[0]) <= max(4, va.shape[0] // 500)
+    d, _ = cKDTree(va.cpu().numpy()).query(vb.cpu().numpy())
+    assert np.quantile(d, 0.999) < 1e-4 * (R - 1), np.quantile(d, 0.999)  # voxel units: 1e-4 of the box edge
+    with pytest.raises(Exception):
+        ops.density_grid(tri, mlp, R, precision="bf16")
