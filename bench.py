@@ -145,8 +145,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decoder-precision", choices=("fp32", "bf16x3"), default="fp32",
-                    help="fp32 (default, exact-fp32 MFMA density MLP) or bf16x3 (optional split-operand bf16 MFMA mode)")
+    ap.add_argument("--decoder-precision", choices=("fp32", "fp16x3", "bf16x3"), default="fp32",
+                    help="fp32 (default, exact-fp32 MFMA density MLP) or an optional split-operand 16-bit MFMA mode")
     args = ap.parse_args()
     global DECODER_PRECISION
     DECODER_PRECISION = args.decoder_precision
@@ -194,7 +194,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0:
         achieved = FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12
-        x3 = DECODER_PRECISION == "bf16x3"
+        x3 = DECODER_PRECISION != "fp32"
         peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_density_grid.json")
@@ -214,15 +214,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16x3 split operands, fp32 accumulate (density MLP hidden layers; ~3e-4 rel. density error) / f32 "
-                      "(tables, SiLU, marching cubes) / bf16 (transformer)") if x3 else
+            "dtype": ("%s split operands, fp32 accumulate (density MLP hidden layers) / f32 (tables, SiLU, marching "
+                      "cubes) / bf16 (transformer)" % DECODER_PRECISION) if x3 else
                      "f32 (density MLP + marching cubes) / bf16 (transformer)",
             "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
             "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
                        "mc_resolution": MC_RES, "threshold": THRESHOLD, "images_per_gpu_per_step": 1,
                        "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
-            "roofline": {"kernel": ("density_grid_x3_kernel (fused triplane-sum + NeRF-MLP, bf16x3 MFMA: 3 MFMA flops per "
-                                    "algorithmic flop)") if x3 else
+            "roofline": {"kernel": ("density_grid_x3_kernel (fused triplane-sum + NeRF-MLP, %s MFMA: 3 MFMA flops per "
+                                    "algorithmic flop)" % DECODER_PRECISION) if x3 else
                                    "density_grid_kernel (fused triplane-sum + NeRF-MLP, fp32 MFMA)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None if x3 else traffic,

@@ -115,6 +115,9 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
  * MFMA with both operands split into bf16 pairs (W.x ~= Wh.xh + Wh.xl + Wl.xh, fp32 accumulate: ~2^-17 relative
  * product error, fp32 range); tables, SiLU, last layer and exp stay fp32. */
 #define SCULPT_DENSITY_BF16X3 1u
+/* SCULPT_DENSITY_FP16X3: the same with IEEE-half parts (11-bit significands: operands represented to ~2^-22,
+ * hidden activations and weights must stay inside the fp16 range, |v| < 65504). */
+#define SCULPT_DENSITY_FP16X3 2u
 int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                            float density_bias, float out_add, const void *workspace, float *out, unsigned flags,
                            sculpt_stream_t stream);
@@ -141,6 +144,7 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
 #define SCULPT_MC_SLAB_HALO_LOW 16u
 #define SCULPT_ERR_MC_LEVEL 11
 #define SCULPT_ERR_MC_EMPTY 12
+#define SCULPT_ERR_MC_NAN 13 /* the volume contains NaN (e.g. a 16-bit split density mode left its range) */
 
 size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2);
 int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsigned flags,

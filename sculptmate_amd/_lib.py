@@ -90,10 +90,12 @@ MC_SLAB = 8
 MC_SLAB_HALO_LOW = 16
 ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
+ERR_MC_NAN = 13
 EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_RELU = 0, 1, 2, 3
 QUERY_ALIGN_CORNERS = 1
 QUERY_CHANNEL_LAST = 2
 DENSITY_BF16X3 = 1
+DENSITY_FP16X3 = 2
 
 
 def last_error():

@@ -389,7 +389,8 @@ struct McHeader {            // first 64 bytes of the workspace
     unsigned long long total_tri;
     unsigned long long total_vert;
     unsigned min_ord, max_ord;
-    unsigned pad[10];
+    unsigned nan_seen;  // some corner value was NaN (set by the classify pass)
+    unsigned pad[9];
 };
 
 // One record per ACTIVE cell, stored compactly per workgroup (slot b*256 + rank, rank in cell order):
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
                                                                double level, int classic, CellRec *__restrict__ recs,
                                                                int *__restrict__ block_counts,
                                                                int *__restrict__ block_nact,
-                                                               float2 *__restrict__ block_minmax) {
+                                                               float2 *__restrict__ block_minmax,
+                                                               McHeader *__restrict__ hdr) {
     __shared__ unsigned char s_list[MC_BLOCK];
     __shared__ int s_wcnt[MC_BLOCK / 64];
     __shared__ float s_mn[MC_BLOCK / 64], s_mx[MC_BLOCK / 64];
@@ -418,13 +420,16 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
         const float *p = vol + z * sz + y * sy + x;
         const float f[8] = {p[0], p[1], p[sy + 1], p[sy], p[sz], p[sz + 1], p[sz + sy + 1], p[sz + sy]};
         int idx = 0;
+        bool nan = false;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             mn = fminf(mn, f[k]);
             mx = fmaxf(mx, f[k]);
+            nan |= f[k] != f[k];
             idx |= (f[k] > levelf) ? (1 << k) : 0;  // == ((double)f - level > 0): levelf = largest float <= level
         }
         active = idx != 0 && idx != 255;
+        if (nan) hdr->nan_seen = 1u;  // fminf/fmaxf drop NaN silently; a plain racing store of 1 is enough
     }
     const unsigned long long bal = __ballot(active);
     const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -801,7 +806,7 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsi
     if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
     hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
                        reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
-                       reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax));
+                       reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr);
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(w.ngroups), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
                        reinterpret_cast<const float2 *>(ws + w.off_minmax), w.nblocks,
@@ -819,6 +824,10 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsi
     // skimage: "Surface level must be within volume data range." (ValueError)
     const float mn = ord2f(res.min_ord), mx = ord2f(res.max_ord);
     if (minmax_host) { minmax_host[0] = mn; minmax_host[1] = mx; }
+    if (res.nan_seen) {
+        set_error("marching_cubes: the volume contains NaN");
+        return SCULPT_ERR_MC_NAN;
+    }
     if (flags & SCULPT_MC_SLAB) return 0;  // a slab may be empty; the caller decides globally
     if ((double)level < (double)mn || (double)level > (double)mx) {
         set_error("Surface level must be within volume data range.");

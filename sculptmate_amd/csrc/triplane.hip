@@ -43,7 +43,8 @@ struct MlpPackHeader {
     int32_t off_wlast; // [4][2 h][2 t][16 r]
     int32_t off_blast; // [4]
     int32_t off_x3;    // [NH][hi|lo][2 T][4 s][64 lane][8] bf16 (as 4096 floats per layer): split weights, bf16x3 mode
-    int32_t pad[4];
+    int32_t off_x3h;   // same with fp16 halves (fp16x3 mode)
+    int32_t pad[3];
 };
 static_assert(sizeof(MlpPackHeader) == 64, "header is 16 words");
 
@@ -77,6 +78,7 @@ static void pack_layout(int K0, int NH, MlpPackHeader *hd) {
     hd->off_blast = o; o += 4;
     o = (o + 3) & ~3;
     hd->off_x3 = o;    o += NH * 4096;
+    hd->off_x3h = o;   o += NH * 4096;
     hd->total_floats = (o + 3) & ~3;
 }
 
@@ -500,6 +502,9 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
 // l+1 after the split (k order permuted, see sculpt_mlp_pack), so activations still never leave registers.
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 tbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     unsigned r;
@@ -509,7 +514,6 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 
 // x (16 fp32 accumulator values of one 32-neuron tile) -> two B-operand vectors per part: hi[2], lo[2]
 __device__ __forceinline__ void split16(const f32x16 &x, tbf16x8 hi[2], tbf16x8 lo[2]) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         u32x4 ph, pl;
@@ -525,7 +529,27 @@ __device__ __forceinline__ void split16(const f32x16 &x, tbf16x8 hi[2], tbf16x8 
         lo[q] = __builtin_bit_cast(tbf16x8, pl);
     }
 }
+// the same with IEEE half parts (x - xh is exact in fp32; xl carries the next 11 bits)
+__device__ __forceinline__ void split16(const f32x16 &x, tf16x8 hi[2], tf16x8 lo[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 ph, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = x[8 * q + 2 * i], b = x[8 * q + 2 * i + 1];
+            const tf16x2 h2 = {(_Float16)a, (_Float16)b};
+            const tf16x2 l2 = {(_Float16)(a - (float)h2[0]), (_Float16)(b - (float)h2[1])};
+            ph[i] = __builtin_bit_cast(unsigned, h2);
+            pl[i] = __builtin_bit_cast(unsigned, l2);
+        }
+        hi[q] = __builtin_bit_cast(tf16x8, ph);
+        lo[q] = __builtin_bit_cast(tf16x8, pl);
+    }
+}
+__device__ __forceinline__ f32x16 mfma16(tbf16x8 a, tbf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(tf16x8 a, tf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+template <typename V8>  // tbf16x8 (bf16x3) or tf16x8 (fp16x3)
 __global__ __launch_bounds__(1024) void density_grid_x3_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
     const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
@@ -533,7 +557,7 @@ __global__ __launch_bounds__(1024) void density_grid_x3_kernel(
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
     {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + (sizeof(V8) && __is_same(V8, tf16x8) ? hd.off_x3h : hd.off_x3));
         f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
         for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
         float *bacc = smem + NH * 4096;
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(1024) void density_grid_x3_kernel(
     const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
     int iy = (int)(t_begin % R);
     int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
-    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;  // [l][part][T][s][lane]
+    const V8 *A = reinterpret_cast<const V8 *>(smem) + lane;  // [l][part][T][s][lane]
 
     for (long t = t_begin; t < t_end; ++t, ++iy) {
         if (iy == R) {
@@ -572,22 +596,22 @@ __global__ __launch_bounds__(1024) void density_grid_x3_kernel(
         x0 += y0; x1 += y1;
         x0 = silu16(x0); x1 = silu16(x1);
         for (int l = 0; l < NH; ++l) {
-            tbf16x8 bh[4], bl[4];  // B operands of the four k-steps: tiles (x0: s = 0,1), (x1: s = 2,3)
+            V8 bh[4], bl[4];  // B operands of the four k-steps: tiles (x0: s = 0,1), (x1: s = 2,3)
             split16(x0, bh, bl);
             split16(x1, bh + 2, bl + 2);
             f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
             f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
-            const tbf16x8 *Al = A + (long)l * 16 * 64;
+            const V8 *Al = A + (long)l * 16 * 64;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const tbf16x8 ah0 = Al[((0 * 2 + 0) * 4 + s4) * 64], ah1 = Al[((0 * 2 + 1) * 4 + s4) * 64];
-                const tbf16x8 al0 = Al[((1 * 2 + 0) * 4 + s4) * 64], al1 = Al[((1 * 2 + 1) * 4 + s4) * 64];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[s4], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[s4], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[s4], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[s4], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[s4], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[s4], acc1, 0, 0, 0);
+                const V8 ah0 = Al[((0 * 2 + 0) * 4 + s4) * 64], ah1 = Al[((0 * 2 + 1) * 4 + s4) * 64];
+                const V8 al0 = Al[((1 * 2 + 0) * 4 + s4) * 64], al1 = Al[((1 * 2 + 1) * 4 + s4) * 64];
+                acc0 = mfma16(al0, bh[s4], acc0);
+                acc1 = mfma16(al1, bh[s4], acc1);
+                acc0 = mfma16(ah0, bl[s4], acc0);
+                acc1 = mfma16(ah1, bl[s4], acc1);
+                acc0 = mfma16(ah0, bh[s4], acc0);
+                acc1 = mfma16(ah1, bh[s4], acc1);
             }
             x0 = silu16(acc0);
             x1 = silu16(acc1);
@@ -698,6 +722,22 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
                             x3[(size_t)l * 8192 + ((((part * 2 + T) * 4 + s4) * 64 + lane) * 8) + j] = part ? lo : hi;
                         }
     }
+    // fp16x3 mode: the same with IEEE half parts (11-bit significands: W - (Wh + Wl) ~ 2^-22 |W|)
+    _Float16 *x3h = reinterpret_cast<_Float16 *>(o + hd.off_x3h);
+    for (int l = 0; l < NH; ++l) {
+        const float *Wl = Wh[l + 1];
+        for (int part = 0; part < 2; ++part)
+            for (int T = 0; T < 2; ++T)
+                for (int s4 = 0; s4 < 4; ++s4)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * s4 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                            const float w = Wl[(size_t)(32 * T + (lane & 31)) * HID + k];
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)(w - (float)hi);
+                            x3h[(size_t)l * 8192 + ((((part * 2 + T) * 4 + s4) * 64 + lane) * 8) + j] = part ? lo : hi;
+                        }
+    }
     return 0;
 }
 
@@ -785,10 +825,11 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
     const float *FB = FA + (size_t)nx * R * 64;
     const float *FC = FB + (size_t)nx * R * 64;
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
-    if (flags & SCULPT_DENSITY_BF16X3) {
-        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (flags & (SCULPT_DENSITY_BF16X3 | SCULPT_DENSITY_FP16X3)) {
+        auto kern = (flags & SCULPT_DENSITY_FP16X3) ? density_grid_x3_kernel<tf16x8> : density_grid_x3_kernel<tbf16x8>;
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
-        hipLaunchKernelGGL(density_grid_x3_kernel, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed),
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed),
                            FA, FB, FC, R, nx, density_bias, out_add, out);
         SC_LAUNCH_CHECK();
         return 0;

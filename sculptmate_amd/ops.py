@@ -109,14 +109,18 @@ def _workspace(key, nbytes, device):
     return t
 
 
+_DENSITY_FLAGS = {"fp32": 0, "bf16x3": _lib.DENSITY_BF16X3, "fp16x3": _lib.DENSITY_FP16X3}
+
+
 def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None,
                  out_add=0.0, events=None, precision="fp32"):
     """density_act (+ out_add) over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]
     (TSR.extract_mesh's dense query, system.py:171-183; out_add=-threshold folds system.py:184).
     events: optional (start, stop) torch.cuda.Event pair recorded around the fused MLP launch only.
-    precision: "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-operand bf16 MFMA, ~2^-17 products)."""
-    if precision not in ("fp32", "bf16x3"):
-        raise SculptError("density_grid: precision must be 'fp32' or 'bf16x3'")
+    precision: "fp32" (exact fp32 MFMA, default), "bf16x3" or "fp16x3" (split-operand 16-bit MFMA: operands
+    represented to ~2^-17 / ~2^-22)."""
+    if precision not in _DENSITY_FLAGS:
+        raise SculptError("density_grid: precision must be one of %s" % sorted(_DENSITY_FLAGS))
     planes = _req(planes, torch.float32, "planes")
     R = int(resolution)
     x_end = R if x_end is None else int(x_end)
@@ -132,7 +136,7 @@ def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begi
         events[0].record()
     check(lib.sculpt_density_grid_ex(_ptr(mlp.blob), mlp.n_hidden, R, int(x_begin), x_end, float(density_bias),
                                      float(out_add), _ptr(ws), _ptr(out),
-                                     _lib.DENSITY_BF16X3 if precision == "bf16x3" else 0, _stream()))
+                                     _DENSITY_FLAGS[precision], _stream()))
     if events is not None:
         events[1].record()
     return out

@@ -135,3 +135,19 @@ def test_dense_noisy_density_field_256_vs_oracle(cuda):
     assert len(v) > 200000
     rv, rf = capi.marching_cubes(vol.cpu().numpy(), 0.0)
     _same(v, f, rv, rf)
+
+
+def test_nan_volume_is_reported(cuda):
+    """fminf/fmaxf drop NaN, so the count pass looks for it explicitly (error 13) instead of meshing garbage."""
+    import torch
+
+    from sculptmate_amd import _lib, ops
+
+    vol = torch.randn(12, 12, 12, device=cuda)
+    vol[5, 6, 7] = float("nan")
+    with pytest.raises(_lib.SculptError) as ei:
+        ops.marching_cubes(vol, 0.0)
+    assert ei.value.code == _lib.ERR_MC_NAN
+    vol[5, 6, 7] = 0.5
+    v, f = ops.marching_cubes(vol, 0.0)
+    assert v.shape[0] > 0

@@ -174,3 +174,41 @@ def test_density_grid_bf16x3_mode_accuracy_and_mesh(cuda):
     assert np.quantile(d, 0.999) < 1e-4 * (R - 1), np.quantile(d, 0.999)  # voxel units: 1e-4 of the box edge
     with pytest.raises(Exception):
         ops.density_grid(tri, mlp, R, precision="bf16")
+    # fp16x3: half parts carry 22 bits -> the same error class as the fp32 kernel against the CPU oracle
+    h = ops.density_grid(tri, mlp, R, precision="fp16x3")
+    e32 = np.abs(np.log(a.cpu().numpy()) - np.log(ref)).max()
+    e16 = np.abs(np.log(h.cpu().numpy()) - np.log(ref)).max()
+    assert e16 < 1e-4 and e16 < 4 * e32 + 1e-6, (e16, e32)
+    vh, fh = ops.marching_cubes((h - 25.0).view(R, R, R), 0.0)
+    assert abs(va.shape[0] - vh.shape[0]) <= max(2, va.shape[0] // 5000)
+    d, _ = cKDTree(va.cpu().numpy()).query(vh.cpu().numpy())
+    assert np.quantile(d, 0.999) < 1e-5 * (R - 1)
+
+
+def test_fp16x3_range_overflow_falls_back_to_fp32(cuda):
+    """Hidden activations beyond the fp16 range make the split mode produce NaN; TSR.extract_meshes redoes the grid in
+    exact fp32 (same mesh as a pure fp32 model)."""
+    import torch
+
+    from sculptmate_amd import _lib, ops, synth
+    from sculptmate_amd.tsr import TSR
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+
+    sd = synth.tsr_state(3, SMALL_CFG)
+    # blow up one hidden layer and undo it in the next: fp32 is fine with 1e6-sized activations, fp16 parts are not
+    sd["decoder.layers.4.weight"] = (sd["decoder.layers.4.weight"] * np.float32(1e6)).astype(np.float32)
+    sd["decoder.layers.4.bias"] = (sd["decoder.layers.4.bias"] * np.float32(1e6)).astype(np.float32)
+    sd["decoder.layers.6.weight"] = (sd["decoder.layers.6.weight"] * np.float32(1e-6)).astype(np.float32)
+    planes = torch.from_numpy(synth.smooth_triplane(seed=5, size=16, scale=2.0)).to(cuda)[None]
+    meshes = {}
+    for prec in ("fp32", "fp16x3"):
+        m = TSR(SMALL_CFG, decoder_precision=prec)
+        m.load_state_dict(sd)
+        m.to(cuda)
+        dens = ops.density_grid(planes[0], m.decoder, 32, precision=prec)
+        if prec == "fp16x3":
+            assert not torch.isfinite(dens).all()
+        thr = float(np.quantile(ops.density_grid(planes[0], m.decoder, 32).cpu().numpy(), 0.9))
+        meshes[prec] = m.extract_meshes(planes, resolution=32, threshold=thr)[0]
+    assert torch.equal(meshes["fp32"].faces, meshes["fp16x3"].faces)
+    assert torch.equal(meshes["fp32"].vertices, meshes["fp16x3"].vertices)
