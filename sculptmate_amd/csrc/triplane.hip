@@ -529,16 +529,18 @@ __device__ __forceinline__ void split16(const f32x16 &x, tbf16x8 hi[2], tbf16x8 
         lo[q] = __builtin_bit_cast(tbf16x8, pl);
     }
 }
-// the same with IEEE half parts (x - xh is exact in fp32; xl carries the next 11 bits)
+// the same with IEEE half parts (x - xh is exact in fp32; xl carries the next 11 bits).  Pairwise vector
+// conversions: v_cvt_pk_f16_f32 (RNE), two v_cvt_f32_f16, one v_pk_add_f32 with a negated operand, v_cvt_pk_f16_f32.
 __device__ __forceinline__ void split16(const f32x16 &x, tf16x8 hi[2], tf16x8 lo[2]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         u32x4 ph, pl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float a = x[8 * q + 2 * i], b = x[8 * q + 2 * i + 1];
-            const tf16x2 h2 = {(_Float16)a, (_Float16)b};
-            const tf16x2 l2 = {(_Float16)(a - (float)h2[0]), (_Float16)(b - (float)h2[1])};
+            const tf32x2 v = {x[8 * q + 2 * i], x[8 * q + 2 * i + 1]};
+            const tf16x2 h2 = __builtin_convertvector(v, tf16x2);
+            const tf32x2 back = __builtin_convertvector(h2, tf32x2);
+            const tf16x2 l2 = __builtin_convertvector(v - back, tf16x2);
             ph[i] = __builtin_bit_cast(unsigned, h2);
             pl[i] = __builtin_bit_cast(unsigned, l2);
         }
