@@ -175,6 +175,13 @@ int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, con
                      const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
                      uint16_t *out_bf16_t, int ldt, int n_split, int M, int N, int K, int epilogue,
                      sculpt_stream_t stream);
+/* Same with n_store: only output columns n < n_store are written (N stays a multiple of 128, i.e. W and bias are padded;
+ * n_store % 4 == 0): lets a layer with few output channels write straight into a narrow slice of a wider activation
+ * buffer (`out` pointing at the slice's first column, ldo = the buffer's row stride). */
+int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
+                        const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
+                        uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
+                        sculpt_stream_t stream);
 
 /* fp32 "parity mode" of the same stack (exact-fp32 MFMA, ~5x slower; not timed by bench.py):
  *   out[m][n] = epi(alpha * A[m][:].W[n][:] + bias[n]) (+ residual); A, W, out fp32; K % 16 == 0; N % 4 == 0
@@ -293,6 +300,25 @@ int sculpt_mtet_count(const float *sdf, const int32_t *tets, int64_t n_tets, con
 int sculpt_mtet_emit(const float *pos, const float *sdf, const int32_t *tets, int64_t n_tets, const int32_t *edges,
                      int64_t n_edges, const int32_t *tet_edges, void *workspace, float vert_mul, float vert_add,
                      float *verts, int64_t *faces, sculpt_stream_t stream);
+
+/* Channel-last bf16 conv-net building blocks (U^2-Net background removal; the reference runs it
+ * as an opaque ONNX graph: rembg/sessions/u2net.py:16-46).  Activations are [H*W][ld] bf16, `in`/`out` point at the first
+ * channel of a slice, C = real channels (multiple of 8).
+ *   sculpt_im2col3x3_dilated: rows [H*W][9*C_pad], k = (ky*3+kx)*C_pad + c, taps at (y+(ky-1)*d, x+(kx-1)*d), zero outside
+ *     the image and for c >= C -- followed by sculpt_gemm_bf16_ex = Conv2d(3x3, padding=d, dilation=d) (+ folded
+ *     BatchNorm, ReLU epilogue).
+ *   sculpt_maxpool2x2_ceil = nn.MaxPool2d(2, stride=2, ceil_mode=True); sculpt_upsample_bilinear_* =
+ *     F.interpolate(mode="bilinear", align_corners=False) to (H, W); sculpt_add_bf16 = elementwise sum of two slices;
+ *   sculpt_fuse_sigmoid: out[i] = sigmoid(sum_k w[k]*maps[k][i] + bias) (the 1x1 fusion of the six side outputs). */
+int sculpt_im2col3x3_dilated(const uint16_t *in, int ld_in, int H, int W, int C, int C_pad, int dilation, uint16_t *out,
+                             sculpt_stream_t stream);
+int sculpt_maxpool2x2_ceil(const uint16_t *in, int ld_in, int H, int W, int C, uint16_t *out, int ld_out, sculpt_stream_t stream);
+int sculpt_upsample_bilinear_bf16(const uint16_t *in, int ld_in, int h, int w, int C, uint16_t *out, int ld_out, int H, int W,
+                                  sculpt_stream_t stream);
+int sculpt_upsample_bilinear_f32(const float *in, int ld_in, int h, int w, float *out, int H, int W, sculpt_stream_t stream);
+int sculpt_add_bf16(const uint16_t *a, int lda, const uint16_t *b, int ldb, uint16_t *out, int ldo, int64_t rows, int C,
+                    sculpt_stream_t stream);
+int sculpt_fuse_sigmoid(const float *maps, int n_maps, int64_t n, const float *w, float bias, float *out, sculpt_stream_t stream);
 
 /* StableFast geometry tail:
  *   dilate_fill (sf3d/models/utils.py:96-133): img f32 [3][H][W], mask f32 [H][W]; scratch 8*H*W floats

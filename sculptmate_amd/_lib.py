@@ -48,6 +48,13 @@ SIGNATURES = {
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sculpt_gemm_bf16_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sculpt_im2col3x3_dilated": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sculpt_maxpool2x2_ceil": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "sculpt_upsample_bilinear_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "sculpt_upsample_bilinear_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "sculpt_add_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    "sculpt_fuse_sigmoid": (_i, [_vp, _i, _i64, _vp, _f, _vp, _vp]),
     "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -62,6 +62,7 @@ struct GemmArgs {
     int M, N, K;
     int n_split;  // columns >= n_split go ONLY to out_t (row n - n_split); columns < n_split skip out_t
     int n_major;  // XCD chunks run over all activation-row tiles of a few weight tiles (W larger than A) or the reverse
+    int n_store;  // only columns n < n_store are written (N is padded to the tile; the output slice may be narrower)
 };
 
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int n = n0 + wr * (BW / 2) + i * 16 + fq * 4;
+                if (n >= g.n_store) continue;
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -262,6 +264,14 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
                                 const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
                                 uint16_t *out_bf16_t, int ldt, int n_split, int M, int N, int K, int epilogue,
                                 sculpt_stream_t stream) {
+    return sculpt_gemm_bf16_ex(A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, n_split, 0, M, N, K,
+                               epilogue, stream);
+}
+
+extern "C" int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
+                                   const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
+                                   uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
+                                   sculpt_stream_t stream) {
     SC_REQUIRE(A && W, "gemm_bf16: null operand");
     SC_REQUIRE(out_f32 || out_bf16 || out_bf16_t, "gemm_bf16: no output");
     SC_REQUIRE(M >= 1 && N >= 1 && K >= BK, "gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
@@ -272,8 +282,11 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     SC_REQUIRE(n_split % 16 == 0, "gemm_bf16: n_split=%d must be a multiple of 16", n_split);
     SC_REQUIRE(n_split == N || out_bf16_t, "gemm_bf16: n_split needs the transposed output");
     const long w_rows = (epilogue == SCULPT_EPI_GEGLU) ? 2L * N : N;
+    if (n_store <= 0 || n_store > N) n_store = N;
+    SC_REQUIRE(n_store % 4 == 0, "gemm_bf16: n_store=%d must be a multiple of 4", n_store);
+    SC_REQUIRE(n_store == N || (epilogue != SCULPT_EPI_GEGLU && !out_bf16_t), "gemm_bf16: n_store is for plain outputs only");
     GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
-               w_rows > (long)M ? 1 : 0};
+               w_rows > (long)M ? 1 : 0, n_store};
     const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of

@@ -473,3 +473,63 @@ def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores):
         gemm_f32(q, k, out=scores, M=Tq, N=((Tk + 3) // 4) * 4, w_rows=Tk, alpha=scale)
         softmax_rows_f32(scores, Tq, Tk, Tkp)
         gemm_f32(scores[:, :Tkp], Vt[64 * h:64 * h + 64, :Tkp], out=O[:, 64 * h:64 * h + 64], M=Tq, N=64)
+
+
+# ----------------------------------------------------------------------------------------------
+# channel-last bf16 conv-net blocks (U^2-Net)
+# ----------------------------------------------------------------------------------------------
+class Act:
+    """A slice [H*W][C] of a channel-last bf16 activation buffer (buf: [H*W, ld] bf16, channels off..off+C)."""
+
+    def __init__(self, buf, off, C, H, W):
+        assert buf.dtype == BF16 and buf.is_contiguous() and buf.shape[0] == H * W and off % 8 == 0 and C % 8 == 0
+        assert off + C <= buf.shape[1]
+        self.buf, self.off, self.C, self.H, self.W = buf, off, C, H, W
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + 2 * self.off)
+
+    @property
+    def ld(self):
+        return self.buf.stride(0)
+
+
+def conv3x3_bf16(x: Act, W2, bias, out, n_store, dilation, relu, col):
+    """Conv2d(3x3, padding=dilation, dilation) of the slice x with packed weights W2 [Npad][9*C_pad] (+bias [Npad]).
+    out: an Act (bf16 slice, n_store columns written) or an fp32 tensor [H*W, Npad]; col: bf16 scratch >= H*W*9*C_pad."""
+    K = W2.shape[1]
+    C_pad = K // 9
+    M = x.H * x.W
+    assert col.numel() >= M * K and W2.dtype == BF16
+    check(lib.sculpt_im2col3x3_dilated(x.ptr, x.ld, x.H, x.W, x.C, C_pad, int(dilation), _ptr(col), _stream()))
+    epi = _lib.EPI_RELU if relu else _lib.EPI_NONE
+    if isinstance(out, Act):
+        check(lib.sculpt_gemm_bf16_ex(_ptr(col), K, _ptr(W2), K, _ptr(bias), None, 0, None, out.ptr, out.ld, None, 0, 0,
+                                      int(n_store), M, W2.shape[0], K, epi, _stream()))
+    else:
+        check(lib.sculpt_gemm_bf16_ex(_ptr(col), K, _ptr(W2), K, _ptr(bias), None, 0, _ptr(out), None, out.stride(0), None, 0,
+                                      0, 0, M, W2.shape[0], K, epi, _stream()))
+
+
+def maxpool2x2_ceil(x: Act, out: Act):
+    assert out.H == (x.H + 1) // 2 and out.W == (x.W + 1) // 2 and out.C == x.C
+    check(lib.sculpt_maxpool2x2_ceil(x.ptr, x.ld, x.H, x.W, x.C, out.ptr, out.ld, _stream()))
+
+
+def upsample_bilinear(x: Act, out: Act):
+    assert out.C == x.C
+    check(lib.sculpt_upsample_bilinear_bf16(x.ptr, x.ld, x.H, x.W, x.C, out.ptr, out.ld, out.H, out.W, _stream()))
+
+
+def upsample_bilinear_f32(x, ld, h, w, out, H, W):
+    check(lib.sculpt_upsample_bilinear_f32(_ptr(x), int(ld), h, w, _ptr(out), H, W, _stream()))
+
+
+def add_bf16(a: Act, b: Act, out: Act):
+    assert a.C == b.C == out.C and a.H * a.W == out.H * out.W
+    check(lib.sculpt_add_bf16(a.ptr, a.ld, b.ptr, b.ld, out.ptr, out.ld, a.H * a.W, a.C, _stream()))
+
+
+def fuse_sigmoid(maps, w, bias, out):
+    check(lib.sculpt_fuse_sigmoid(_ptr(maps), maps.shape[0], maps.shape[1], _ptr(w), float(bias), _ptr(out), _stream()))

@@ -159,3 +159,27 @@ def sf3d_state(seed=0, cfg=None):
                 fan_in = int(np.prod(shape[1:]))
             sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(fan_in))
     return sd
+
+
+def u2net_state(seed=0):
+    """U^2-Net parameters (authors' module names): Conv2d default init, BatchNorm affine ~1 / ~0 with running statistics
+    of a trained-looking network (mean ~0, var in [0.5, 1.5])."""
+    from .rembg.spec import param_spec
+
+    rng = np.random.default_rng([seed, 17])
+    sd = {}
+    for name, shape in param_spec().items():
+        if name.endswith("running_var"):
+            sd[name] = (0.5 + rng.random(shape, dtype=np.float32)).astype(np.float32)
+        elif name.endswith("running_mean"):
+            sd[name] = _uniform(rng, shape, 0.1)
+        elif "bn_s1.weight" in name:
+            sd[name] = (1.0 + _uniform(rng, shape, 0.2)).astype(np.float32)
+        elif "bn_s1.bias" in name:
+            sd[name] = _uniform(rng, shape, 0.1)
+        elif name.endswith(".weight"):
+            sd[name] = _uniform(rng, shape, math.sqrt(3.0 / float(np.prod(shape[1:]))))  # unit-gain uniform
+        else:
+            wshape = sd[name[:-4] + "weight"].shape
+            sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(float(np.prod(wshape[1:]))))
+    return sd

@@ -1,0 +1,75 @@
+"""U^2-Net (background removal network) on the MI355X vs the torch oracle of the published architecture."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import u2net_ref as R
+from sculptmate_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12)), float((a - b).abs().max())
+
+
+def test_conv_blocks_vs_torch(cuda):
+    import torch.nn.functional as F
+
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    H, W, ci, co, d = 13, 9, 24, 40, 2
+    x = torch.randn(1, ci, H, W, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(co, ci, 3, 3, generator=g) / 10).to(torch.bfloat16).float()
+    b = torch.randn(co, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, padding=d, dilation=d))
+    buf = torch.zeros(H * W, 64, dtype=torch.bfloat16, device=cuda)
+    buf[:, 8:8 + ci] = x[0].permute(1, 2, 0).reshape(H * W, ci).to(torch.bfloat16).to(cuda)  # a slice at offset 8
+    xin = ops.Act(buf, 8, ci, H, W)
+    W2 = torch.zeros(128, 9, 64)
+    W2[:co, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+    b2 = torch.zeros(128)
+    b2[:co] = b
+    obuf = torch.full((H * W, 128), 7.0, dtype=torch.bfloat16, device=cuda)
+    out = ops.Act(obuf, 16, co, H, W)
+    col = torch.empty(H * W * 9 * 64, dtype=torch.bfloat16, device=cuda)
+    ops.conv3x3_bf16(xin, W2.reshape(128, -1).to(torch.bfloat16).to(cuda), b2.to(cuda), out, co, d, True, col)
+    got = obuf[:, 16:16 + co].float().cpu().reshape(H, W, co).permute(2, 0, 1)
+    assert _rel(got, ref[0])[0] < 4e-3
+    assert (obuf[:, :16] == 7).all() and (obuf[:, 16 + co:] == 7).all()  # nothing outside the slice is written
+    # pool / upsample / add
+    pb = torch.zeros(((H + 1) // 2) * ((W + 1) // 2), 64, dtype=torch.bfloat16, device=cuda)
+    ops.maxpool2x2_ceil(xin, ops.Act(pb, 0, ci, (H + 1) // 2, (W + 1) // 2))
+    rp = F.max_pool2d(x, 2, stride=2, ceil_mode=True)[0]
+    assert torch.equal(pb[:, :ci].float().cpu().reshape((H + 1) // 2, (W + 1) // 2, ci).permute(2, 0, 1), rp)
+    ub = torch.zeros(31 * 20, 64, dtype=torch.bfloat16, device=cuda)
+    ops.upsample_bilinear(xin, ops.Act(ub, 0, ci, 31, 20))
+    ru = F.interpolate(x, size=(31, 20), mode="bilinear", align_corners=False)[0]
+    assert _rel(ub[:, :ci].float().cpu().reshape(31, 20, ci).permute(2, 0, 1), ru)[1] < 3e-2  # bf16 output rounding
+    ab = torch.zeros(H * W, 64, dtype=torch.bfloat16, device=cuda)
+    ops.add_bf16(xin, xin, ops.Act(ab, 0, ci, H, W))
+    assert torch.equal(ab[:, :ci].float().cpu(), (2 * x[0]).permute(1, 2, 0).reshape(H * W, ci).to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("size", [(64, 64), (72, 56)])
+def test_u2net_forward_vs_oracle(cuda, size):
+    from sculptmate_amd.rembg.u2net import U2Net
+
+    sd = synth.u2net_state(0)
+    net = U2Net()
+    net.load_state_dict(sd)
+    net.to(cuda)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, *size, generator=g)
+    d0 = net.forward(x.to(cuda))
+    assert d0.shape == size and d0.dtype == torch.float32
+    ref_bf = R.u2net_forward(sd, x[None], bf16=True)[0, 0]
+    ref_32 = R.u2net_forward(sd, x[None])[0, 0]
+    rb, r32 = _rel(d0, ref_bf), _rel(d0, ref_32)
+    assert rb[1] < 2e-2 and r32[1] < 5e-2, (rb, r32)  # ~112 bf16 convolutions deep
+    with pytest.raises(RuntimeError):
+        bad = dict(sd)
+        bad.pop("outconv.bias")
+        U2Net().load_state_dict(bad)
