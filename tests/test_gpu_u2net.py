@@ -73,3 +73,36 @@ def test_u2net_forward_vs_oracle(cuda, size):
         bad = dict(sd)
         bad.pop("outconv.bias")
         U2Net().load_state_dict(bad)
+
+
+def test_remove_end_to_end(cuda):
+    """bg.remove() through the HIP session: same mask as the oracle network + the reference's pre/post-processing."""
+    from PIL import Image
+
+    from sculptmate_amd.rembg import bg, session
+
+    sd = synth.u2net_state(0)
+    s = session.U2netSession(device=cuda, state_dict=sd)
+    rgba = synth.image_rgba(3, 160)
+    img = Image.fromarray(rgba[..., :3], mode="RGB")
+    mask = bg.remove(img, session=s, only_mask=True)
+    assert mask.size == img.size and mask.mode == "L"
+    x = session.normalize(img)
+    ref = R.u2net_forward(sd, torch.from_numpy(x), bf16=True)[0].numpy()
+    ref_mask = np.asarray(session.prediction_to_mask(ref, img.size)).astype(np.int32)
+    d = np.abs(np.asarray(mask).astype(np.int32) - ref_mask)
+    assert d.max() <= 12 and d.mean() < 1.5, (d.max(), d.mean())  # 8-bit levels after min-max stretching
+    cut = bg.remove(np.asarray(img), session=s)
+    assert cut.shape == (160, 160, 4)
+    png = bg.remove(img, session=s, bgcolor=(255, 0, 0, 255))
+    assert png.mode == "RGBA"
+    with pytest.raises(NotImplementedError):
+        bg.remove(img, session=s, alpha_matting=True)
+    import time
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        d0 = s.net.forward(torch.from_numpy(x[0]).to(cuda))
+    torch.cuda.synchronize()
+    print("U2Net 320x320 forward: %.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
