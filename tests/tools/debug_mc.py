@@ -1,7 +1,7 @@
 """GPU debug: locate the first cell where HIP marching cubes diverges from the oracle."""
 import ctypes, sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import capi
 from sculptmate_amd import ops
 

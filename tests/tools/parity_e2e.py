@@ -1,6 +1,6 @@
 """End-to-end image -> mesh parity of the fp32 mode against the CPU path (oracle), full-size model, and timing."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import capi, tsr_ref
 from sculptmate_amd import ops, synth
