@@ -312,6 +312,14 @@ int sculpt_mtet_emit(const float *pos, const float *sdf, const int32_t *tets, in
  *   sculpt_fuse_sigmoid: out[i] = sigmoid(sum_k w[k]*maps[k][i] + bias) (the 1x1 fusion of the six side outputs). */
 int sculpt_im2col3x3_dilated(const uint16_t *in, int ld_in, int H, int W, int C, int C_pad, int dilation, uint16_t *out,
                              sculpt_stream_t stream);
+/* The same convolution WITHOUT materialising the im2col rows (implicit GEMM): the activation tile of K-step
+ * (tap, 64-channel chunk) is fetched by LDS-DMA straight from the shifted pixels of the channel-last input (a zero page for
+ * taps outside the image).  in: [n_images][H*W][ld_in] with at least C_pad readable channels from `in` in every pixel row
+ * (channels beyond the real ones must be finite; their weights are zero); Wt bf16 [N][9*C_pad], k = (ky*3+kx)*C_pad + c;
+ * outputs as sculpt_gemm_bf16_ex (fp32 and/or bf16, row stride ldo, columns < n_store); epilogue NONE or RELU. */
+int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, int H, int W, int C_pad, int dilation,
+                        const uint16_t *Wt, const float *bias, float *out_f32, uint16_t *out_bf16, int ldo, int n_store,
+                        int N, int epilogue, sculpt_stream_t stream);
 int sculpt_maxpool2x2_ceil(const uint16_t *in, int ld_in, int H, int W, int C, uint16_t *out, int ld_out, sculpt_stream_t stream);
 int sculpt_upsample_bilinear_bf16(const uint16_t *in, int ld_in, int h, int w, int C, uint16_t *out, int ld_out, int H, int W,
                                   sculpt_stream_t stream);

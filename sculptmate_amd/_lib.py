@@ -49,6 +49,7 @@ SIGNATURES = {
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_bf16_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sculpt_conv3x3_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sculpt_im2col3x3_dilated": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_maxpool2x2_ceil": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "sculpt_upsample_bilinear_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

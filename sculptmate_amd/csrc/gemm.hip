@@ -63,12 +63,16 @@ struct GemmArgs {
     int n_split;  // columns >= n_split go ONLY to out_t (row n - n_split); columns < n_split skip out_t
     int n_major;  // XCD chunks run over all activation-row tiles of a few weight tiles (W larger than A) or the reverse
     int n_store;  // only columns n < n_store are written (N is padded to the tile; the output slice may be narrower)
+    // implicit 3x3 convolution (CONV): A = channel-last activations [images][H*W][lda], row m = output pixel, K-tile kt =
+    // 64 channels cc of tap (ky, kx): source pixel (y + (ky-1) d, x + (kx-1) d) or a zero page outside the image
+    int cv_H, cv_W, cv_c64, cv_dil;
+    const uint16_t *cv_zero;
 };
 
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
 // NW: waves per workgroup.  4 = 2x2 waves of 64 activation x BW/2 weight rows; 8 = 2 (weight) x 4 (activation)
 // waves of 32 x BW/2: twice the waves per SIMD to hide LDS / barrier latency, at 1.5x the LDS bytes per MFMA.
-template <int EPI, int BW, int NW>
+template <int EPI, int BW, int NW, bool CONV = false>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int WT = BW * 128;  // bytes of a weight tile
     constexpr int AT = BM * 128;
@@ -100,6 +104,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int AI = BM / 8 / NW;  // ... and for the activation tile
     const uint16_t *wsrc0, *wsrc1, *wsrc2, *wsrc3;
     const uint16_t *asrc0, *asrc1, *asrc2, *asrc3;
+    unsigned amask0 = 0, amask1 = 0, amask2 = 0, amask3 = 0;  // CONV: bit t = tap t of this staged row is inside the image
+    const uint16_t *zsrc = CONV ? g.cv_zero + (sslot << 3) : nullptr;
     {
         auto wrow = [&](int j) -> int {
             if (EPI == SCULPT_EPI_GEGLU) {
@@ -117,8 +123,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             const int m = min(m0 + r, g.M - 1);
             return g.A + (long)m * g.lda + ((sslot ^ ((r >> 1) & 7)) << 3);
         };
+        auto am = [&](int q) -> unsigned {
+            if (!CONV) return 0u;
+            const int r = 8 * (wave * AI + q) + srow;
+            const int m = min(m0 + r, g.M - 1);
+            const int x = m % g.cv_W, y = (m / g.cv_W) % g.cv_H;
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + (t / 3 - 1) * g.cv_dil, xx = x + (t % 3 - 1) * g.cv_dil;
+                mask |= (yy >= 0 && yy < g.cv_H && xx >= 0 && xx < g.cv_W) ? (1u << t) : 0u;
+            }
+            return mask;
+        };
         wsrc0 = wp(0); wsrc1 = wp(1 % WI); wsrc2 = wp(2 % WI); wsrc3 = wp(3 % WI);
         asrc0 = ap(0); asrc1 = ap(1 % AI); asrc2 = ap(2 % AI); asrc3 = ap(3 % AI);
+        amask0 = am(0); amask1 = am(1 % AI); amask2 = am(2 % AI); amask3 = am(3 % AI);
     }
     const int wdst = (wave * WI) * 1024, adst = (wave * AI) * 1024;  // wave-uniform LDS byte offsets
 
@@ -134,11 +154,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc2 + ko), (lds_ptr_t)(wb + wdst + 2048), 16, 0, 0); \
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc3 + ko), (lds_ptr_t)(wb + wdst + 3072), 16, 0, 0); \
         }                                                                                                    \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc0 + ko), (lds_ptr_t)(ab + adst), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc1 + ko), (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);  \
+        long ao = ko;                                                                                        \
+        int tap = 0;                                                                                         \
+        if (CONV) {                                                                                          \
+            tap = (kt) / g.cv_c64;                                                                           \
+            const int cc = (kt) - tap * g.cv_c64, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;            \
+            ao = ((long)(dy * g.cv_dil) * g.cv_W + dx * g.cv_dil) * g.lda + cc * 64;                         \
+        }                                                                                                    \
+        const uint16_t *a0 = (!CONV || ((amask0 >> tap) & 1u)) ? asrc0 + ao : zsrc;                          \
+        const uint16_t *a1 = (!CONV || ((amask1 >> tap) & 1u)) ? asrc1 + ao : zsrc;                          \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)a0, (lds_ptr_t)(ab + adst), 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)a1, (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);            \
         if (AI == 4) {                                                                                       \
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc2 + ko), (lds_ptr_t)(ab + adst + 2048), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(asrc3 + ko), (lds_ptr_t)(ab + adst + 3072), 16, 0, 0); \
+            const uint16_t *a2 = (!CONV || ((amask2 >> tap) & 1u)) ? asrc2 + ao : zsrc;                      \
+            const uint16_t *a3 = (!CONV || ((amask3 >> tap) & 1u)) ? asrc3 + ao : zsrc;                      \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)a2, (lds_ptr_t)(ab + adst + 2048), 16, 0, 0);        \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)a3, (lds_ptr_t)(ab + adst + 3072), 16, 0, 0);        \
         }                                                                                                    \
     } while (0)
 
@@ -268,6 +299,49 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
                                epilogue, stream);
 }
 
+static const uint16_t *zero_page() {
+    // 256 zero bytes per device for the out-of-image taps of the implicit convolution (allocated once, never freed)
+    static const uint16_t *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = reinterpret_cast<const uint16_t *>(p);
+    }
+    return pages[dev];
+}
+
+extern "C" int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, int H, int W, int C_pad, int dilation,
+                                   const uint16_t *Wt, const float *bias, float *out_f32, uint16_t *out_bf16, int ldo,
+                                   int n_store, int N, int epilogue, sculpt_stream_t stream) {
+    SC_REQUIRE(in && Wt && (out_f32 || out_bf16), "conv3x3_bf16: null argument");
+    SC_REQUIRE(n_images >= 1 && H >= 1 && W >= 1 && dilation >= 1, "conv3x3_bf16: bad image shape");
+    SC_REQUIRE(C_pad >= 64 && C_pad % 64 == 0 && ld_in % 8 == 0, "conv3x3_bf16: C_pad=%d must be a multiple of 64 (ld %d of 8)", C_pad, ld_in);
+    SC_REQUIRE(N % 128 == 0 && ldo % 4 == 0, "conv3x3_bf16: N=%d must be a multiple of 128", N);
+    SC_REQUIRE(epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_RELU, "conv3x3_bf16: epilogue must be NONE or RELU");
+    if (n_store <= 0 || n_store > N) n_store = N;
+    SC_REQUIRE(n_store % 4 == 0, "conv3x3_bf16: n_store must be a multiple of 4");
+    const uint16_t *zp = zero_page();
+    SC_REQUIRE(zp, "conv3x3_bf16: could not allocate the zero page");
+    const long M = (long)n_images * H * W;
+    const int K = 9 * C_pad;
+    GemmArgs g{in, ld_in, Wt, K, bias, nullptr, 0, out_f32, out_bf16, ldo, nullptr, 0, (int)M, N, K, N, (long)N > M ? 1 : 0,
+               n_store, H, W, C_pad / 64, dilation, zp};
+    const int mt = cdiv(M, BM);
+    hipStream_t st = as_stream(stream);
+    const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
+    if (epilogue == SCULPT_EPI_RELU) {
+        if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_RELU, 64, 8, true>), dim3(N / 64, mt), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_RELU, 128, 8, true>), dim3(N / 128, mt), dim3(512), 0, st, g);
+    } else {
+        if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, true>), dim3(N / 64, mt), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8, true>), dim3(N / 128, mt), dim3(512), 0, st, g);
+    }
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
                                    const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
                                    uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
@@ -286,7 +360,7 @@ extern "C" int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W
     SC_REQUIRE(n_store % 4 == 0, "gemm_bf16: n_store=%d must be a multiple of 4", n_store);
     SC_REQUIRE(n_store == N || (epilogue != SCULPT_EPI_GEGLU && !out_bf16_t), "gemm_bf16: n_store is for plain outputs only");
     GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
-               w_rows > (long)M ? 1 : 0, n_store};
+               w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr};
     const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of

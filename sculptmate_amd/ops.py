@@ -358,6 +358,15 @@ def im2col3x3(act, n_planes, S, out):
     check(lib.sculpt_im2col3x3(_ptr(act), n_planes, S, C, act.element_size(), _ptr(out), _stream()))
 
 
+def conv3x3_planes(act, n_planes, S, W2, bias, out_f32=None, out_bf16=None, relu=False):
+    """3x3 / pad 1 convolution of n_planes S x S channel-last images act [n_planes*S*S][C] (C % 64 == 0), implicit GEMM."""
+    C = act.shape[1]
+    assert act.is_contiguous() and W2.shape[1] == 9 * C
+    o = out_f32 if out_f32 is not None else out_bf16
+    check(lib.sculpt_conv3x3_bf16(_ptr(act), act.stride(0), n_planes, S, S, C, 1, _ptr(W2), _ptr(bias), _ptr(out_f32), _ptr(out_bf16),
+                                  o.stride(0), 0, W2.shape[0], _lib.EPI_RELU if relu else _lib.EPI_NONE, _stream()))
+
+
 def pixel_shuffle(g, planes, n_planes, S, Co, r):
     """nn.PixelShuffle(r) of g f32 [n_planes*S*S][>= Co*r*r] into planes f32 [n_planes][Co][S*r][S*r]."""
     g = _req(g, torch.float32, "g")
@@ -495,15 +504,30 @@ class Act:
         return self.buf.stride(0)
 
 
-def conv3x3_bf16(x: Act, W2, bias, out, n_store, dilation, relu, col):
+def conv3x3_bf16(x: Act, W2, bias, out, n_store, dilation, relu, col=None, implicit=None):
     """Conv2d(3x3, padding=dilation, dilation) of the slice x with packed weights W2 [Npad][9*C_pad] (+bias [Npad]).
-    out: an Act (bf16 slice, n_store columns written) or an fp32 tensor [H*W, Npad]; col: bf16 scratch >= H*W*9*C_pad."""
+    out: an Act (bf16 slice, n_store columns written) or an fp32 tensor [H*W, Npad].
+    implicit (default: whenever the slice has C_pad readable channels per pixel): no im2col rows, the GEMM fetches the
+    shifted pixels itself (sculpt_conv3x3_bf16); otherwise im2col into `col` (bf16 scratch >= H*W*9*C_pad) + GEMM."""
     K = W2.shape[1]
     C_pad = K // 9
     M = x.H * x.W
-    assert col.numel() >= M * K and W2.dtype == BF16
-    check(lib.sculpt_im2col3x3_dilated(x.ptr, x.ld, x.H, x.W, x.C, C_pad, int(dilation), _ptr(col), _stream()))
+    assert W2.dtype == BF16
     epi = _lib.EPI_RELU if relu else _lib.EPI_NONE
+    can = x.off + C_pad <= x.buf.shape[1] and C_pad % 64 == 0
+    if implicit is None:
+        implicit = can
+    if implicit:
+        assert can, "implicit conv needs C_pad readable channels in the slice's rows"
+        if isinstance(out, Act):
+            check(lib.sculpt_conv3x3_bf16(x.ptr, x.ld, 1, x.H, x.W, C_pad, int(dilation), _ptr(W2), _ptr(bias), None, out.ptr,
+                                          out.ld, int(n_store), W2.shape[0], epi, _stream()))
+        else:
+            check(lib.sculpt_conv3x3_bf16(x.ptr, x.ld, 1, x.H, x.W, C_pad, int(dilation), _ptr(W2), _ptr(bias), _ptr(out), None,
+                                          out.stride(0), 0, W2.shape[0], epi, _stream()))
+        return
+    assert col is not None and col.numel() >= M * K
+    check(lib.sculpt_im2col3x3_dilated(x.ptr, x.ld, x.H, x.W, x.C, C_pad, int(dilation), _ptr(col), _stream()))
     if isinstance(out, Act):
         check(lib.sculpt_gemm_bf16_ex(_ptr(col), K, _ptr(W2), K, _ptr(bias), None, 0, None, out.ptr, out.ld, None, 0, 0,
                                       int(n_store), M, W2.shape[0], K, epi, _stream()))

@@ -84,21 +84,15 @@ class U2Net:
         k = (key, H, W, C)
         t = self._buffers.get(k)
         if t is None:
-            t = torch.zeros((H * W, _r(C, 64)), dtype=BF16, device=self.device)  # pad channels stay zero forever
+            # pad channels stay zero forever; 64 more so that a slice starting inside the row still has a whole
+            # 64-channel K-step readable for the implicit convolution (weights of channels past the slice are zero)
+            t = torch.zeros((H * W, _r(C, 64) + 64), dtype=BF16, device=self.device)
             self._buffers[k] = t
-        return t
-
-    def _col(self, n):
-        t = self._buffers.get("col")
-        if t is None or t.numel() < n:
-            t = torch.empty(n, dtype=BF16, device=self.device)
-            self._buffers["col"] = t
         return t
 
     def _conv(self, key, x, out, relu=True):
         W2, b, co, d = self._w[key]
-        col = self._col(x.H * x.W * W2.shape[1])
-        ops.conv3x3_bf16(x, W2, b, out, co, d, relu, col)
+        ops.conv3x3_bf16(x, W2, b, out, co, d, relu)
 
     # ------------------------------------------------------------------ blocks
     def _rsu(self, name, kind, cin, mid, cout, x, out):
@@ -183,7 +177,7 @@ class U2Net:
             if sideo is None:
                 sideo = torch.empty((a.H * a.W, W2.shape[0]), dtype=torch.float32, device=self.device)
                 self._buffers[("side", k, a.H, a.W)] = sideo
-            ops.conv3x3_bf16(a, W2, b, sideo, 0, 1, False, self._col(a.H * a.W * W2.shape[1]))
+            ops.conv3x3_bf16(a, W2, b, sideo, 0, 1, False)
             ops.upsample_bilinear_f32(sideo, sideo.stride(0), a.H, a.W, maps[k - 1], H, W)
         d0 = torch.empty(H * W, dtype=torch.float32, device=self.device)
         ops.fuse_sigmoid(maps, self._w["fuse_w"], self._w["fuse_b"], d0)

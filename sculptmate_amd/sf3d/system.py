@@ -581,17 +581,25 @@ class SF3D(KernelEngine):
         n = len(w["convs"])
         for i, (W2, b2, co) in enumerate(w["convs"]):
             cin = act.shape[1]
-            col = self._b("pp_col", (T, 9 * cin), self.adt)
-            ops.im2col3x3(act, 3, S, col)
+            implicit = self.precision == "bf16" and cin % 64 == 0  # the GEMM fetches the shifted pixels itself
+            if not implicit:
+                col = self._b("pp_col", (T, 9 * cin), self.adt)
+                ops.im2col3x3(act, 3, S, col)
             if i != n - 1:
                 nxt = self._b("pp_act%d" % (1 + i % 2), (T, W2.shape[0]), self.adt)
-                self._gemm(col, W2, bias=b2, out_bf16=nxt, epilogue=_lib.EPI_RELU)
+                if implicit:
+                    ops.conv3x3_planes(act, 3, S, W2, b2, out_bf16=nxt, relu=True)
+                else:
+                    self._gemm(col, W2, bias=b2, out_bf16=nxt, epilogue=_lib.EPI_RELU)
                 act = nxt[:, :co] if co != W2.shape[0] else nxt
                 if not act.is_contiguous():
                     act = act.contiguous()
             else:
                 g = self._b("pp_out", (T, W2.shape[0]), torch.float32)
-                self._gemm(col, W2, bias=b2, out_f32=g)
+                if implicit:
+                    ops.conv3x3_planes(act, 3, S, W2, b2, out_f32=g)
+                else:
+                    self._gemm(col, W2, bias=b2, out_f32=g)
         r, Co = pp["scale_factor"], pp["out_channels"]
         planes = torch.empty((3, Co, S * r, S * r), dtype=torch.float32, device=self.device)
         ops.pixel_shuffle(g, planes, 3, S, Co, r)

@@ -35,10 +35,22 @@ def test_conv_blocks_vs_torch(cuda):
     obuf = torch.full((H * W, 128), 7.0, dtype=torch.bfloat16, device=cuda)
     out = ops.Act(obuf, 16, co, H, W)
     col = torch.empty(H * W * 9 * 64, dtype=torch.bfloat16, device=cuda)
-    ops.conv3x3_bf16(xin, W2.reshape(128, -1).to(torch.bfloat16).to(cuda), b2.to(cuda), out, co, d, True, col)
+    W2d = W2.reshape(128, -1).to(torch.bfloat16).to(cuda)
+    ops.conv3x3_bf16(xin, W2d, b2.to(cuda), out, co, d, True, col, implicit=False)
     got = obuf[:, 16:16 + co].float().cpu().reshape(H, W, co).permute(2, 0, 1)
     assert _rel(got, ref[0])[0] < 4e-3
     assert (obuf[:, :16] == 7).all() and (obuf[:, 16 + co:] == 7).all()  # nothing outside the slice is written
+    # implicit GEMM (no im2col rows): needs 64 readable channels from the slice start -> a wider buffer; same result
+    wide = torch.zeros(H * W, 128, dtype=torch.bfloat16, device=cuda)
+    wide[:, 8:8 + ci] = buf[:, 8:8 + ci]
+    wide[:, 8 + ci:72] = 3.0  # finite junk in the channels whose weights are zero
+    obuf2 = torch.full((H * W, 128), 7.0, dtype=torch.bfloat16, device=cuda)
+    ops.conv3x3_bf16(ops.Act(wide, 8, ci, H, W), W2d, b2.to(cuda), ops.Act(obuf2, 16, co, H, W), co, d, True, implicit=True)
+    assert torch.equal(obuf2, obuf)
+    f32o = torch.empty(H * W, 128, device=cuda)
+    ops.conv3x3_bf16(ops.Act(wide, 8, ci, H, W), W2d, b2.to(cuda), f32o, 0, d, False, implicit=True)
+    pre = F.conv2d(x, w, b, padding=d, dilation=d)[0].permute(1, 2, 0).reshape(H * W, co)
+    assert _rel(f32o[:, :co], pre)[0] < 1e-5
     # pool / upsample / add
     pb = torch.zeros(((H + 1) // 2) * ((W + 1) // 2), 64, dtype=torch.bfloat16, device=cuda)
     ops.maxpool2x2_ceil(xin, ops.Act(pb, 0, ci, (H + 1) // 2, (W + 1) // 2))
