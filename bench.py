@@ -106,6 +106,27 @@ def stage_split(model, img_dev, n=5):
     return dict(zip(("image_tokenizer", "backbone", "upsample", "density_grid", "marching_cubes"), [round(float(x), 3) for x in med]))
 
 
+def optional_mode_rates(model, imgs, steps):
+    """Whole-step rate with the optional split-operand density modes, measured after the timed region."""
+    global DECODER_PRECISION
+    res = {}
+    keep = DECODER_PRECISION
+    try:
+        for mode in ("fp16x3", "bf16x3"):
+            DECODER_PRECISION = mode
+            one_step(model, imgs[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                one_step(model, imgs[i % len(imgs)])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[mode] = {"meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3}
+    finally:
+        DECODER_PRECISION = keep
+    return res
+
+
 def cpu_baseline(sd, img_np, planes_np):
     """The oracle (CPU restatement of the reference) timed on this box's host cores on a bounded
     sample of the same workload: full TSR.forward for one image (torch fp32, all cores), the dense
@@ -230,6 +251,8 @@ def main():
         }
         with torch.no_grad():
             out["stages_ms"] = stage_split(model, imgs[0])  # outside the timed region
+            if args.gpus == 1 and DECODER_PRECISION == "fp32":
+                out["optional_modes"] = optional_mode_rates(model, imgs, args.steps)  # informational, not `value`
         if args.gpus == 1 and not args.no_cpu_baseline:
             with torch.no_grad():
                 ctx, _ = model.image_tokens(imgs[0])
