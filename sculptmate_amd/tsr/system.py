@@ -43,6 +43,17 @@ class Mesh:
 
         return trimesh.Trimesh(vertices=self.vertices, faces=self.faces, vertex_colors=self.vertex_colors)
 
+    def export(self, path):
+        """Write .obj / .ply / .glb by extension (sculptmate_amd/meshio.py), the call upstream users make on the
+        trimesh object their extract_mesh returns."""
+        from .. import meshio
+
+        ext = str(path).rsplit(".", 1)[-1].lower()
+        writer = {"obj": meshio.write_obj, "ply": meshio.write_ply, "glb": meshio.write_glb}.get(ext)
+        if writer is None:
+            raise ValueError(f"unsupported mesh format .{ext} (obj, ply, glb)")
+        writer(str(path), self.vertices, self.faces, vertex_colors=self.vertex_colors)
+
 
 class MarchingCubeHelper:
     """tsr/models/isosurface.py:17-54 on the GPU (sculpt_mc_*)."""

@@ -147,3 +147,78 @@ def test_obj_round_trip(tmp_path):
     assert np.array_equal(f2, f) and np.allclose(v2, v, rtol=1e-6) and np.allclose(c2, c, atol=1e-5)
     meshio.write_obj(str(tmp_path / "n.obj"), v, f)
     assert meshio.read_obj(str(tmp_path / "n.obj"))[2] is None
+
+
+def _random_mesh(n_v=60, n_f=90, seed=1):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((n_v, 3)).astype(np.float32), rng.integers(0, n_v, (n_f, 3)).astype(np.int64),
+            rng.random((n_v, 3)).astype(np.float32), rng)
+
+
+def test_png_codec_round_trip():
+    from sculptmate_amd import meshio
+
+    rng = np.random.default_rng(2)
+    for shape in [(5, 7, 3), (16, 16, 4), (3, 9, 1)]:
+        img = rng.integers(0, 256, shape).astype(np.uint8)
+        png = meshio.encode_png(img)
+        assert np.array_equal(meshio.decode_png(png), img)
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+
+    img = rng.integers(0, 256, (11, 13, 3)).astype(np.uint8)
+    assert np.array_equal(np.array(PIL.open(io.BytesIO(meshio.encode_png(img)))), img)   # an independent decoder agrees
+
+
+def test_glb_round_trip(tmp_path):
+    import json
+    import struct
+
+    from sculptmate_amd import meshio
+
+    v, f, c, rng = _random_mesh()
+    uv = (rng.integers(0, 1025, (len(v), 2)) / 1024.0).astype(np.float32)   # 1 - v is exact on this lattice
+    nrm = rng.standard_normal((len(v), 3)).astype(np.float32)
+    tex = rng.integers(0, 256, (32, 32, 3)).astype(np.uint8)
+    bump = rng.integers(0, 256, (32, 32, 3)).astype(np.uint8)
+    path = str(tmp_path / "m.glb")
+    meshio.write_glb(path, v, f, vertex_colors=c, normals=nrm, uvs=uv, basecolor_tex=tex, normal_tex=bump,
+                     roughness=np.float32(0.25), metallic=[0.75])
+    got = meshio.read_glb(path)
+    assert np.array_equal(got["vertices"], v) and np.array_equal(got["faces"], f)
+    assert np.array_equal(got["vertex_colors"], c) and np.array_equal(got["uvs"], uv) and np.array_equal(got["normals"], nrm)
+    assert np.array_equal(got["basecolor_tex"], tex) and np.array_equal(got["normal_tex"], bump)
+    assert got["roughness"] == 0.25 and got["metallic"] == 0.75
+    # glTF's origin is the top-left of the image: the stored TEXCOORD_0 is (u, 1 - v)
+    stored = meshio.read_glb(path, uv_origin="top_left")["uvs"]
+    assert np.array_equal(stored[:, 0], uv[:, 0]) and np.array_equal(stored[:, 1], 1.0 - uv[:, 1])
+    meshio.write_sf3d_glb(str(tmp_path / "s.glb"), dict(vertices=v, faces=f, uvs=uv, basecolor_tex=np.dstack([tex, tex[..., :1]]),
+                                                        bump_tex=None, roughness=0.5, metallic=0.0))
+    s = meshio.read_glb(str(tmp_path / "s.glb"))
+    assert np.array_equal(s["basecolor_tex"], tex) and s["normal_tex"] is None and np.array_equal(s["uvs"], uv)
+    # container-level checks a strict loader makes: 4-byte alignment, declared lengths, POSITION bounds
+    raw = open(path, "rb").read()
+    assert len(raw) % 4 == 0 and struct.unpack("<I", raw[8:12])[0] == len(raw)
+    n_json = struct.unpack("<I", raw[12:16])[0]
+    doc = json.loads(raw[20:20 + n_json])
+    assert n_json % 4 == 0 and all(bv["byteOffset"] % 4 == 0 for bv in doc["bufferViews"])
+    pos = doc["accessors"][doc["meshes"][0]["primitives"][0]["attributes"]["POSITION"]]
+    assert np.allclose(pos["min"], v.min(0)) and np.allclose(pos["max"], v.max(0))
+    # geometry only, and the bad-index error
+    meshio.write_glb(str(tmp_path / "g.glb"), v, f)
+    bare = meshio.read_glb(str(tmp_path / "g.glb"))
+    assert bare["uvs"] is None and bare["basecolor_tex"] is None and np.array_equal(bare["faces"], f)
+    with pytest.raises(ValueError):
+        meshio.write_glb(str(tmp_path / "bad.glb"), v, f + len(v))
+
+
+def test_ply_round_trip(tmp_path):
+    from sculptmate_amd import meshio
+
+    v, f, c, _ = _random_mesh(seed=3)
+    meshio.write_ply(str(tmp_path / "m.ply"), v, f, c)
+    v2, f2, c2 = meshio.read_ply(str(tmp_path / "m.ply"))
+    assert np.array_equal(v2, v) and np.array_equal(f2, f) and np.abs(c2 - c).max() <= 0.5 / 255 + 1e-7
+    meshio.write_ply(str(tmp_path / "n.ply"), v, f)
+    v3, f3, c3 = meshio.read_ply(str(tmp_path / "n.ply"))
+    assert np.array_equal(v3, v) and np.array_equal(f3, f) and c3 is None
