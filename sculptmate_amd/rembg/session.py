@@ -36,25 +36,39 @@ def prediction_to_mask(pred: np.ndarray, size) -> Image.Image:
     return mask.resize(size, Image.LANCZOS)
 
 
+def load_weights(weights_path=None):
+    """-> state dict (authors' parameter names) from .onnx / .safetensors / torch file; see U2netSession.__init__."""
+    if weights_path is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        ckpt = os.path.join(os.path.dirname(os.path.dirname(here)), "checkpoints")
+        tried = [os.path.join(ckpt, "u2net" + ext) for ext in (".onnx", ".pth", ".safetensors")]
+        weights_path = next((p for p in tried if os.path.isfile(p)), None)
+        if weights_path is None:
+            raise FileNotFoundError("U2netSession: no weights at %s" % " or ".join(tried))
+    elif not os.path.isfile(weights_path):
+        raise FileNotFoundError("U2netSession: no weights at %s" % weights_path)
+    if weights_path.endswith(".onnx"):
+        from .onnx_weights import u2net_state_dict
+
+        return u2net_state_dict(weights_path)
+    if weights_path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+
+        return load_file(weights_path)
+    return torch.load(weights_path, map_location="cpu")
+
+
 class U2netSession:
     def __init__(self, model_name: str = "u2net", device=None, state_dict=None, weights_path=None, *args, **kwargs):
-        """device: a HIP device (default cuda:0).  Weights: `state_dict` (authors' parameter names, see spec.py) or a
-        torch / safetensors file at `weights_path` (default <package>/../checkpoints/u2net.pth -- the reference ships an
-        ONNX file there whose graph cannot be read without onnx; converting it is outside this package)."""
+        """device: a HIP device (default cuda:0).  Weights: `state_dict` (authors' parameter names, see spec.py) or a file
+        at `weights_path`: the reference's own `u2net.onnx` (initialisers read by onnx_weights.py, no onnx package
+        needed), a torch checkpoint or a safetensors file.  Default: <package>/../checkpoints/u2net.onnx -- the place the
+        reference opens (rembg/sessions/base.py:38-42) -- then u2net.pth / u2net.safetensors beside it."""
         self.model_name = model_name
         self.device = torch.device(device if device is not None else "cuda:0")
         self.net = U2Net()
         if state_dict is None:
-            here = os.path.dirname(os.path.abspath(__file__))
-            weights_path = weights_path or os.path.join(os.path.dirname(os.path.dirname(here)), "checkpoints", "u2net.pth")
-            if not os.path.isfile(weights_path):
-                raise FileNotFoundError("U2netSession: no weights at %s" % weights_path)
-            if weights_path.endswith(".safetensors"):
-                from safetensors.torch import load_file
-
-                state_dict = load_file(weights_path)
-            else:
-                state_dict = torch.load(weights_path, map_location="cpu")
+            state_dict = load_weights(weights_path)
         self.net.load_state_dict(state_dict)
         self.net.to(self.device)
 

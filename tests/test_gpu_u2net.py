@@ -118,3 +118,23 @@ def test_remove_end_to_end(cuda):
         d0 = s.net.forward(torch.from_numpy(x[0]).to(cuda))
     torch.cuda.synchronize()
     print("U2Net 320x320 forward: %.2f ms" % ((time.perf_counter() - t0) / 5 * 1e3))
+
+
+def test_session_from_onnx_container(cuda, tmp_path):
+    """The reference opens checkpoints/u2net.onnx (rembg/sessions/base.py:38-42): a session built from an ONNX container
+    (initialisers named like the exporter would, with BatchNormalization nodes) predicts bit-identically to one built
+    from the state dict."""
+    from PIL import Image
+
+    from sculptmate_amd.rembg import onnx_weights as ow
+    from sculptmate_amd.rembg import session
+
+    sd = synth.u2net_state(0)
+    path = str(tmp_path / "u2net.onnx")
+    with open(path, "wb") as fh:
+        fh.write(ow.encode_model([], [ow.encode_tensor(k, np.asarray(v, np.float32)) for k, v in sd.items()]))
+    a = session.U2netSession(device=cuda, state_dict=sd)
+    b = session.U2netSession(device=cuda, weights_path=path)
+    img = Image.fromarray(synth.image_rgba(5, 96)[..., :3], mode="RGB")
+    ma, mb = a.predict(img)[0], b.predict(img)[0]
+    assert np.array_equal(np.asarray(ma), np.asarray(mb))
