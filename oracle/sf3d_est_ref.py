@@ -1,0 +1,176 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (never imported by sculptmate_amd/).
+
+Plain PyTorch fp32 restatement (CPU) of StableFast-3D's two estimators (BASELINE config 4):
+
+  global_estimator_forward   StableFast/sf3d/models/global_estimator/multi_head_estimator.py:38-55 (stride-2 3x3
+                             convolutions, padding 0, activation), :86-118 (reshape to [B, 3F, H, W], max / mean pool,
+                             heads: output_bias added BEFORE the output activation, reshape, decoder_ prefix)
+  image_estimator_forward    sf3d/models/image_estimator/clip_based_estimator.py:88-105 (bilinear resize to 224,
+                             align_corners=False, no antialias; Normalize with open_clip's OPENAI mean / std),
+                             :107-135 (shared MLP, two branches -> softplus(d + output_bias) -> Beta), :137-166
+                             (distribution_eval == "mode", output activation, reshape, decoder_ prefix)
+  beta_mode                  torch.distributions.Beta.mode (what the reference calls): Dirichlet mode of
+                             (concentration1, concentration0), first component
+  clip_visual_forward        the visual tower of open_clip "ViT-B-32" (clip_based_estimator.py:43-46:
+                             open_clip.create_model_and_transforms("ViT-B-32", "laion2b_s34b_b79k") -> encode_image).
+                             open_clip 's source is NOT in /root/reference and not installed: this restates the published
+                             CLIP ViT (Radford et al. 2021; open_clip model config ViT-B-32: width 768, 12 layers, 12 heads,
+                             patch 32, image 224, embed 512, nn.GELU): bias-free patch convolution, class embedding,
+                             learned positions, ln_pre, pre-LN residual blocks with nn.MultiheadAttention (packed
+                             in_proj) and a 4x GELU MLP, ln_post on the class token, projection matrix.
+
+PARITY PIN: tests/golden/sf3d_global_est.npz and sf3d_image_est.npz come out of the reference's own classes
+(tests/golden/make_sf3d_est_goldens.py); the CLIP tower is pinned to an independent installed implementation of the
+same architecture (transformers' CLIPVisionModelWithProjection, sf3d_clip.npz) -- against open_clip itself it is
+"parity unpinned".  tests/test_oracle_sf3d_est.py.
+
+`bf16=True` rounds where the HIP pipeline stores bf16 (see oracle/tsr_ref.py).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .tsr_ref import _Q, _attn, _t
+
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _act(name):
+    if name == "relu":
+        return F.relu
+    if name == "silu":
+        return F.silu
+    raise NotImplementedError(name)
+
+
+def _out_act(name, x):
+    """sf3d/models/network.py:98-136 for the activations the estimator configs use."""
+    if name is None or name.lower() in ("none", "linear", "identity"):
+        return x
+    name = name.lower()
+    if name == "softplus":
+        return F.softplus(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "exp":
+        return torch.exp(x)
+    if name == "tanh":
+        return torch.tanh(x)
+    raise NotImplementedError(name)
+
+
+# ----------------------------------------------------------------------------- global (illumination) estimator
+def global_estimator_forward(sd, prefix, cfg, triplane, bf16=False):
+    """triplane [B, 3, F, H, W] -> dict like MultiHeadEstimator.forward."""
+    Q = _Q(bf16)
+    act = _act(cfg.get("activation", "relu"))
+    x = _t(triplane).float()
+    x = x.reshape(x.shape[0], -1, x.shape[-2], x.shape[-1])
+    for i in range(cfg.get("n_layers", 2)):
+        w, b = _t(sd[prefix + "layers.%d.weight" % (2 * i)]).float(), _t(sd[prefix + "layers.%d.bias" % (2 * i)]).float()
+        x = act(F.conv2d(Q(x), Q(w), b, stride=2, padding=0))
+    pool = cfg.get("pool", "max")
+    x = x.amax(dim=[-2, -1]) if pool == "max" else x.mean(dim=[-2, -1])
+    out = {}
+    for h in cfg["heads"]:
+        y = x
+        key = prefix + "heads.%s." % h["name"]
+        n = h["n_hidden_layers"]
+        for j in range(n):
+            y = act(F.linear(y, _t(sd[key + "%d.weight" % (2 * j)]).float(), _t(sd[key + "%d.bias" % (2 * j)]).float()))
+        y = F.linear(y, _t(sd[key + "%d.weight" % (2 * n)]).float(), _t(sd[key + "%d.bias" % (2 * n)]).float())
+        y = _out_act(h.get("output_activation"), y + h.get("output_bias", 0.0))
+        if h.get("shape"):
+            y = y.reshape(*h["shape"])
+        out[("decoder_" if h.get("add_to_decoder_features") else "") + h["name"]] = y
+    return out
+
+
+# ----------------------------------------------------------------------------- CLIP visual tower
+def clip_visual_forward(sd, prefix, image_nchw, heads, eps=1e-5, bf16=False, return_tokens=False):
+    """image_nchw float32 [B, 3, S, S], already normalised -> image features [B, E] (encode_image, normalize=False)."""
+    Q = _Q(bf16)
+    g = lambda k: _t(sd[prefix + k]).float()  # noqa: E731
+    x = _t(image_nchw).float()
+    conv = g("conv1.weight")
+    W, P = conv.shape[0], conv.shape[-1]
+    x = F.conv2d(Q(x), Q(conv), None, stride=P)                       # [B, W, n, n]
+    x = x.reshape(x.shape[0], W, -1).permute(0, 2, 1)                 # [B, n*n, W]
+    cls = g("class_embedding").view(1, 1, W).expand(x.shape[0], 1, W)
+    x = torch.cat([cls, x], 1) + g("positional_embedding")[None]
+    x = F.layer_norm(x, (W,), g("ln_pre.weight"), g("ln_pre.bias"), eps)
+    n_layers = 1 + max(int(k[len(prefix + "transformer.resblocks."):].split(".")[0]) for k in sd
+                       if k.startswith(prefix + "transformer.resblocks."))
+    outs = []
+    for b in range(x.shape[0]):
+        h = x[b]
+        for i in range(n_layers):
+            p = "transformer.resblocks.%d." % i
+            y = Q(F.layer_norm(h, (W,), g(p + "ln_1.weight"), g(p + "ln_1.bias"), eps))
+            qkv = Q(F.linear(y, Q(g(p + "attn.in_proj_weight")), g(p + "attn.in_proj_bias")))
+            a = Q(_attn(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], heads, Q))
+            h = h + F.linear(a, Q(g(p + "attn.out_proj.weight")), g(p + "attn.out_proj.bias"))
+            y = Q(F.layer_norm(h, (W,), g(p + "ln_2.weight"), g(p + "ln_2.bias"), eps))
+            y = Q(F.gelu(F.linear(y, Q(g(p + "mlp.c_fc.weight")), g(p + "mlp.c_fc.bias"))))
+            h = h + F.linear(y, Q(g(p + "mlp.c_proj.weight")), g(p + "mlp.c_proj.bias"))
+        outs.append(h)
+    tokens = torch.stack(outs, 0)
+    pooled = Q(F.layer_norm(tokens[:, 0], (W,), g("ln_post.weight"), g("ln_post.bias"), eps))
+    feats = pooled @ Q(g("proj"))
+    return (feats, tokens) if return_tokens else feats
+
+
+# ----------------------------------------------------------------------------- image (material) estimator
+def resize_for_clip(cond_image_bhwc, size=224):
+    """[B, H, W, 3] -> [B, 3, size, size]: F.interpolate(bilinear, align_corners=False), no antialiasing."""
+    x = _t(cond_image_bhwc).float().permute(0, 3, 1, 2).contiguous()
+    return F.interpolate(x, size=(size, size), mode="bilinear", align_corners=False)
+
+
+def clip_normalize(x_nchw):
+    mean = torch.tensor(OPENAI_DATASET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(OPENAI_DATASET_STD).view(1, 3, 1, 1)
+    return (x_nchw - mean) / std
+
+
+def beta_mode(alpha, beta):
+    """torch.distributions.Beta(alpha, beta).mode, written out (Dirichlet.mode on [alpha, beta], component 0)."""
+    conc = torch.stack([alpha, beta], -1)
+    cm1 = (conc - 1).clamp(min=0.0)
+    mode = cm1 / cm1.sum(-1, True)
+    small = (conc < 1).all(dim=-1)
+    mode[small] = F.one_hot(mode[small].argmax(dim=-1), conc.shape[-1]).to(mode)
+    return mode[..., 0]
+
+
+def image_estimator_heads(sd, prefix, cfg, features):
+    """features [B, hidden] -> (outputs dict, {name: (alpha, beta)})."""
+    if cfg.get("distribution", "beta") != "beta" or cfg.get("distribution_eval", "mode") != "mode":
+        raise NotImplementedError("only the shipped configuration (beta / mode) is restated")
+    act = _act(cfg.get("activation", "relu"))
+    f = _t(features).float()
+    out, dists = {}, {}
+    for h in cfg["heads"]:
+        key = prefix + "heads.%s." % h["name"]
+        lin = lambda x, k: F.linear(x, _t(sd[key + k + ".weight"]).float(), _t(sd[key + k + ".bias"]).float())  # noqa: E731
+        y = f
+        for j in range(h["n_hidden_layers"]):
+            y = act(lin(y, "0.%d" % (2 * j)))
+        d = [lin(act(lin(y, "%d.0" % br)), "%d.2" % br).squeeze(-1) for br in (1, 2)]
+        bias = h.get("output_bias", 0.0)
+        alpha, beta = F.softplus(d[0] + bias), F.softplus(d[1] + bias)
+        v = _out_act(h.get("output_activation"), beta_mode(alpha, beta))
+        if h.get("shape"):
+            v = v.reshape(*h["shape"])
+        out[("decoder_" if h.get("add_to_decoder_features") else "") + h["name"]] = v
+        dists[h["name"]] = (alpha, beta)
+    return out, dists
+
+
+def image_estimator_forward(sd, prefix, cfg, cond_image_bhwc, clip_heads=12, bf16=False):
+    """ClipBasedHeadEstimator.forward on cond_image = rgb_cond * mask_cond, [B, H, W, 3] in [0, 1]."""
+    x = clip_normalize(resize_for_clip(cond_image_bhwc))
+    feats = clip_visual_forward(sd, prefix + "model.visual.", x, clip_heads, bf16=bf16)
+    return image_estimator_heads(sd, prefix, cfg, feats)[0]
