@@ -328,6 +328,21 @@ int sculpt_add_bf16(const uint16_t *a, int lda, const uint16_t *b, int ldb, uint
                     sculpt_stream_t stream);
 int sculpt_fuse_sigmoid(const float *maps, int n_maps, int64_t n, const float *w, float bias, float *out, sculpt_stream_t stream);
 
+/* StableFast-3D estimators (SURVEY.md 8b "SF3D boundary": run_image returns roughness / metallic):
+ *   sculpt_resize_bilinear_hwc: F.interpolate(bilinear, align_corners=False, no antialias) of an fp32 [Hin][Win][C] image,
+ *     each source pixel first multiplied by mul_hw[Hin][Win] when given -- ClipBasedHeadEstimator's input
+ *     rgb_cond * mask_cond resized to 224 (sf3d/system.py:326-329, image_estimator/clip_based_estimator.py:95-100);
+ *   sculpt_im2col3x3_strided: rows of a 3x3 / padding 0 / stride s convolution over n_groups channel-last maps
+ *     [n_groups][S*S][C] treated as ONE image with n_groups*C channels (channel = g*C + c, the reshape at
+ *     global_estimator/multi_head_estimator.py:90-94): out [So*So][9*n_groups*C], k = (ky*3+kx)*n_groups*C + g*C + c,
+ *     So = (S-3)/s + 1; elements of 2 (bf16) or 4 (f32) bytes, C*elem_bytes a multiple of 16;
+ *   sculpt_col_reduce_f32: out[c] = max (mean = 0) or mean (mean != 0) over the rows of x [rows][ld]
+ *     (x.amax / x.mean over the pixels, multi_head_estimator.py:96-101). */
+int sculpt_resize_bilinear_hwc(const float *in_hwc, const float *mul_hw /* may be NULL */, int Hin, int Win, int C, float *out_hwc,
+                               int Hout, int Wout, sculpt_stream_t stream);
+int sculpt_im2col3x3_strided(const void *in, int n_groups, int S, int C, int elem_bytes, int stride, void *out, sculpt_stream_t stream);
+int sculpt_col_reduce_f32(const float *x, int ld, int rows, int cols, int mean, float *out, sculpt_stream_t stream);
+
 /* StableFast geometry tail:
  *   dilate_fill (sf3d/models/utils.py:96-133): img f32 [3][H][W], mask f32 [H][W]; scratch 8*H*W floats
  *   vertex normals / tangents (sf3d/models/mesh.py:66-139): area-weighted face normal / UV tangent splat

@@ -75,6 +75,9 @@ SIGNATURES = {
     "sculpt_bake_interpolate": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _vp, _vp]),
     "sculpt_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_pixel_shuffle": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sculpt_resize_bilinear_hwc": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "sculpt_im2col3x3_strided": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sculpt_col_reduce_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_normalize_rows3": (_i, [_vp, _i64, _f, _vp, _vp]),
     "sculpt_bake_material": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sculpt_uv_cell_atlas": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp]),

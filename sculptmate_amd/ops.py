@@ -367,6 +367,38 @@ def conv3x3_planes(act, n_planes, S, W2, bias, out_f32=None, out_bf16=None, relu
                                   o.stride(0), 0, W2.shape[0], _lib.EPI_RELU if relu else _lib.EPI_NONE, _stream()))
 
 
+def resize_bilinear_hwc(image_hwc, size, mul_hw=None, out=None):
+    """F.interpolate(bilinear, align_corners=False, no antialias) of an fp32 [H][W][C] image to size x size; every source
+    pixel is first multiplied by mul_hw [H][W] when given (sculpt_resize_bilinear_hwc)."""
+    H, W, C = image_hwc.shape
+    assert image_hwc.dtype == torch.float32 and image_hwc.is_contiguous()
+    if mul_hw is not None:
+        mul_hw = mul_hw.reshape(H, W)
+        assert mul_hw.dtype == torch.float32 and mul_hw.is_contiguous()
+    if out is None:
+        out = torch.empty((size, size, C), dtype=torch.float32, device=image_hwc.device)
+    check(lib.sculpt_resize_bilinear_hwc(_ptr(image_hwc), _ptr(mul_hw), H, W, C, _ptr(out), size, size, _stream()))
+    return out
+
+
+def im2col3x3_strided(act, n_groups, S, stride, out):
+    """act [n_groups*S*S][C] channel-last groups (bf16 or f32) -> out [So*So][9*n_groups*C] of the 3x3 / padding 0 /
+    stride convolution over the channel-concatenated image, k = (ky*3+kx)*n_groups*C + g*C + c."""
+    C = act.shape[1]
+    So = (S - 3) // stride + 1
+    assert act.is_contiguous() and act.shape[0] == n_groups * S * S and out.is_contiguous() and out.dtype == act.dtype
+    assert out.shape == (So * So, 9 * n_groups * C)
+    check(lib.sculpt_im2col3x3_strided(_ptr(act), n_groups, S, C, act.element_size(), stride, _ptr(out), _stream()))
+    return So
+
+
+def col_reduce(x, rows, out, mean=False):
+    """out[c] = max (or mean) over the first `rows` rows of fp32 x [*, cols] (sculpt_col_reduce_f32)."""
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.stride(1) == 1
+    check(lib.sculpt_col_reduce_f32(_ptr(x), x.stride(0), rows, x.shape[1], 1 if mean else 0, _ptr(out), _stream()))
+    return out
+
+
 def pixel_shuffle(g, planes, n_planes, S, Co, r):
     """nn.PixelShuffle(r) of g f32 [n_planes*S*S][>= Co*r*r] into planes f32 [n_planes][Co][S*r][S*r]."""
     g = _req(g, torch.float32, "g")

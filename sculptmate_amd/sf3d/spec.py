@@ -2,8 +2,9 @@
 
 Constants: /root/reference/StableFast/checkpoints/config.yaml:1-96, SF3D.Config defaults
 (StableFast/sf3d/system.py:44-74), facebook/dinov2-large (hidden 1024, 24 layers, 16 heads, patch 14, image 518,
-mlp_ratio 4, layer_norm_eps 1e-6, layerscale).  The CLIP-based image estimator and the illumination estimator are
-not part of the geometry/texture path built here (their weights are listed as "ignored" prefixes).
+mlp_ratio 4, layer_norm_eps 1e-6, layerscale).  The CLIP-based image estimator and the illumination estimator have their
+own inventories in estimators.py (image_estimator_param_spec / global_estimator_param_spec); SF3D.load_state_dict builds
+them when the checkpoint carries their weights, so their prefixes are not "unexpected" here.
 """
 import copy
 
@@ -27,6 +28,8 @@ DEFAULT_CFG = dict(
                   norm_x_input=False, cross_attention_dim=1024),
     post_processor=dict(in_channels=1024, out_channels=40, scale_factor=4, conv_layers=4),
     decoder=dict(in_channels=120, n_neurons=64, activation="silu", heads=HEADS),
+    image_estimator=None,    # None -> estimators.IMAGE_ESTIMATOR_CFG (config.yaml:67-85)
+    global_estimator=None,   # None -> estimators.GLOBAL_ESTIMATOR_CFG (config.yaml:87-96)
 )
 
 IGNORED_PREFIXES = ("image_estimator.", "global_estimator.", "image_tokenizer.modulations.", "bbox",

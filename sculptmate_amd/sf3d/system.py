@@ -227,7 +227,9 @@ class SF3D(KernelEngine):
         self.decoder = None
         self.unwrapper = None   # callable(v_pos, v_nrm, faces, island_padding) -> (uv, indices)
         self.remesher = None    # callable(mesh, mode, vertex_count) -> Mesh  (gpytoolbox in the reference)
-        self.image_estimator = None   # CLIP-based roughness/metallic estimator: not built (open_clip weights)
+        # built by load_state_dict when the checkpoint carries their weights (estimators.py); None otherwise, and
+        # then roughness / metallic stay None in run_image's dict
+        self.image_estimator = None
         self.global_estimator = None
 
     # ------------------------------------------------------------------ loading
@@ -268,9 +270,20 @@ class SF3D(KernelEngine):
             if k in sd and tuple(sd[k].shape) != tuple(shp):
                 raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), shp))
         self._sd = {k: sd[k].detach().to(torch.float32) for k in self._spec if k in sd}
+        self._load_estimators(sd)
         if self.device is not None:
             self._prepare(self.device)
         return self
+
+    def _load_estimators(self, sd):
+        """system.py:109-114: the checkpoint's `image_estimator.*` (CLIP visual tower + heads) and `global_estimator.*`."""
+        from .estimators import ClipBasedHeadEstimator, MultiHeadEstimator
+
+        self.image_estimator = self.global_estimator = None
+        if any(k.startswith("image_estimator.heads.") for k in sd):
+            self.image_estimator = ClipBasedHeadEstimator(self.cfg.get("image_estimator"), self.precision).load_state_dict(sd)
+        if any(k.startswith("global_estimator.layers.") for k in sd):
+            self.global_estimator = MultiHeadEstimator(self.cfg.get("global_estimator"), self.precision).load_state_dict(sd)
 
     def to(self, device):
         device = torch.device(device)
@@ -280,6 +293,13 @@ class SF3D(KernelEngine):
         if self._sd is not None:
             self._prepare(device)
         return self
+
+    def state_dict_estimators(self):
+        out = {}
+        for e in (self.image_estimator, self.global_estimator):
+            if e is not None and e._sd is not None:
+                out.update(e._sd)
+        return out
 
     # ------------------------------------------------------------------ weight preparation
     def camera_embedding(self) -> np.ndarray:
@@ -294,6 +314,9 @@ class SF3D(KernelEngine):
 
     def _prepare(self, dev):
         sd, cfg = self._sd, self.cfg
+        for e in (self.image_estimator, self.global_estimator):
+            if e is not None:
+                e.to(dev)
         wt = _bf if self.precision == "bf16" else _f32
         v, b, t, pp = cfg["image_tokenizer"], cfg["backbone"], cfg["tokenizer"], cfg["post_processor"]
         H, P = v["hidden_size"], v["patch_size"]
@@ -702,10 +725,21 @@ class SF3D(KernelEngine):
         if rgb.shape[-3] != S or rgb.shape[-2] != S:
             rgb = torch.stack([ops.resize_aa_bilinear(im.contiguous(), S) for im in rgb], 0)
             batch = dict(batch, rgb_cond=rgb)
-        scene_codes, _direct = self.get_scene_codes(batch)
+        scene_codes, direct_codes = self.get_scene_codes(batch)
         global_dict = {}
-        if estimate_illumination or self.image_estimator is not None:
-            pass  # estimators are not built here (see class docstring); roughness/metallic stay None
+        if self.image_estimator is not None:
+            # system.py:326-329: image_estimator(rgb_cond * mask_cond); the product is formed inside the resize kernel
+            rgb_e = batch["rgb_cond"].reshape(-1, *batch["rgb_cond"].shape[-3:]).to(self.device, torch.float32)
+            mask_e = batch["mask_cond"].to(self.device, torch.float32)
+            mask_e = mask_e.reshape(-1, *mask_e.shape[-3:])
+            if mask_e.shape[1] != S or mask_e.shape[2] != S:   # image_processor on mask_cond (system.py:321-323)
+                mask_e = torch.stack([ops.resize_aa_bilinear(m.contiguous(), S) for m in mask_e], 0)
+            global_dict.update(self.image_estimator(rgb_e, mask=mask_e[..., 0].contiguous()))
+        if self.global_estimator is not None and estimate_illumination:
+            # system.py:330-331 on non_postprocessed_codes [B,3,C,S,S], handed over channel-last
+            Sp = direct_codes.shape[-1]
+            toks = [d.permute(0, 2, 3, 1).reshape(3 * Sp * Sp, -1).contiguous() for d in direct_codes]
+            global_dict.update(self.global_estimator(toks, Sp))
         meshes = self.triplane_to_meshes(scene_codes)
         rets = []
         for i, mesh in enumerate(meshes):
@@ -772,4 +806,13 @@ def load_config(config_yaml: str):
                               output_activation=h.get("output_activation"), out_bias=float(h.get("out_bias", 0.0))))
         cfg["decoder"] = dict(in_channels=d.get("in_channels", 120), n_neurons=d.get("n_neurons", 64),
                               activation=d.get("activation", "silu"), heads=tuple(heads))
+    from .estimators import GLOBAL_ESTIMATOR_CFG, IMAGE_ESTIMATOR_CFG
+
+    for key, base in (("image_estimator", IMAGE_ESTIMATOR_CFG), ("global_estimator", GLOBAL_ESTIMATOR_CFG)):
+        if y.get(key):
+            e = dict(base)
+            e.update({k: v for k, v in y[key].items() if k != "heads"})
+            if y[key].get("heads"):
+                e["heads"] = tuple(dict(h) for h in y[key]["heads"])
+            cfg[key] = e
     return cfg

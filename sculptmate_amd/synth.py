@@ -127,6 +127,34 @@ def calibrate_density_bias(pre_activation, inside_fraction=0.015, threshold=25.0
     return float(math.log(threshold) - density_bias - qv)
 
 
+def sf3d_estimator_state(seed=0, image_cfg=None, global_cfg=None):
+    """Weights of SF3D's image (CLIP ViT-B/32 visual tower + heads) and global estimators under the reference's
+    state_dict names: CLIP like open_clip initialises it (normal std width^-0.5 scaled per role, LayerNorm ~1 / ~0), heads
+    and convolutions nn.Linear / Conv2d default."""
+    from .sf3d.estimators import (GLOBAL_ESTIMATOR_CFG, IMAGE_ESTIMATOR_CFG, global_estimator_param_spec,
+                                  image_estimator_param_spec)
+
+    rng = np.random.default_rng([seed, 18])
+    sd = {}
+    spec = image_estimator_param_spec(image_cfg or IMAGE_ESTIMATOR_CFG)
+    spec.update(global_estimator_param_spec(global_cfg or GLOBAL_ESTIMATOR_CFG))
+    for name, shape in spec.items():
+        is_bias = name.endswith(".bias") or name.endswith("in_proj_bias")
+        if ".ln_" in name:
+            sd[name] = _uniform(rng, shape, 0.05) if is_bias else (1.0 + _uniform(rng, shape, 0.1)).astype(np.float32)
+        elif ".model.visual." in name and not is_bias:
+            width = shape[-1] if len(shape) == 2 and not name.endswith("proj") else shape[0]
+            sd[name] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(width ** -0.5)).astype(np.float32)
+        elif ".model.visual." in name:
+            sd[name] = _uniform(rng, shape, 0.02)
+        elif is_bias:
+            wshape = sd[name[:-4] + "weight"].shape
+            sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(int(np.prod(wshape[1:]))))
+        else:
+            sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(int(np.prod(shape[1:]))))
+    return sd
+
+
 def sf3d_state(seed=0, cfg=None):
     """Full SF3D state dict (NumPy float32) for the geometry/texture path (sculptmate_amd.sf3d.spec.param_spec):
     DINOv2 trunc-normal(0.02), LayerScale 1.0 +- 0.1, adaLN modulations small but non-zero (the shipped model trains

@@ -26,3 +26,16 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device; there is no CPU fallback")
     return torch.device("cuda:0")
+
+
+def golden_weights(z):
+    """{"w.<name>": float32 array, "wb.<name>": uint16 bf16 pattern} of a fixture -> {name: float32 array}."""
+    import numpy as np
+
+    out = {}
+    for k in (z.files if hasattr(z, "files") else z):
+        if k.startswith("w."):
+            out[k[2:]] = z[k]
+        elif k.startswith("wb."):
+            out[k[3:]] = (z[k].astype(np.uint32) << 16).view(np.float32)
+    return out

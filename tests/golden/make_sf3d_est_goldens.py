@@ -15,7 +15,8 @@
                        published architecture and is pinned to an INDEPENDENT implementation of it that is installed:
                        transformers' CLIPVisionModelWithProjection (hidden_act="gelu", as open_clip's ViT-B-32 config
                        has no quick_gelu), small widths, weights renamed to open_clip's parameter names
-                       (visual.transformer.resblocks.N.attn.in_proj_weight = cat(q, k, v), visual.proj = W^T, ...).
+                       (visual.transformer.resblocks.N.attn.in_proj_weight = cat(q, k, v), visual.proj = W^T, ...);
+                       the weights are bf16-representable and stored as their 16-bit patterns ("wb." keys).
 """
 import os
 import sys
@@ -138,8 +139,8 @@ def make_image():
 def make_clip():
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
 
-    W, L, NH, P, S, E = 128, 2, 2, 8, 32, 128
-    cfg = CLIPVisionConfig(hidden_size=W, intermediate_size=4 * W, num_hidden_layers=L, num_attention_heads=NH, image_size=S,
+    W, L, NH, P, S, E, MLP = 256, 2, 4, 8, 32, 128, 512     # LayerNorm kernel: width % 256 == 0; attention: head width 64
+    cfg = CLIPVisionConfig(hidden_size=W, intermediate_size=MLP, num_hidden_layers=L, num_attention_heads=NH, image_size=S,
                            patch_size=P, projection_dim=E, hidden_act="gelu", layer_norm_eps=1e-5, attention_dropout=0.0)
     torch.manual_seed(0)
     m = CLIPVisionModelWithProjection(cfg).eval()
@@ -147,6 +148,9 @@ def make_clip():
     with torch.no_grad():
         m.vision_model.embeddings.position_embedding.weight.copy_(0.3 * torch.randn(m.vision_model.embeddings.position_embedding.weight.shape,
                                                                                    generator=torch.Generator().manual_seed(42)))
+    with torch.no_grad():   # weights are bf16-representable so that the fixture can hold them as 16-bit patterns (half the size)
+        for p_ in m.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())
     x = torch.randn(2, 3, S, S, generator=torch.Generator().manual_seed(43))
     with torch.no_grad():
         r = m(pixel_values=x, output_hidden_states=True)
@@ -166,8 +170,11 @@ def make_clip():
                      ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
             oc[d + a + ".weight"], oc[d + a + ".bias"] = hf[s + b + ".weight"], hf[s + b + ".bias"]
     fx = {"image": x.numpy(), "out": r.image_embeds.numpy(), "hidden_last": r.hidden_states[-1].numpy(),
-          "cfg": np.array([W, L, NH, P, S, E], np.int64)}
-    fx.update({"w." + k: t.numpy().copy() for k, t in oc.items()})
+          "cfg": np.array([W, L, NH, P, S, E, MLP], np.int64)}
+    for k, t in oc.items():     # "wb.<name>": the upper 16 bits of the float32 pattern (exact, see above)
+        a = t.contiguous().numpy()
+        assert np.array_equal((a.view(np.uint32) & 0xFFFF), np.zeros(a.shape, np.uint32))
+        fx["wb." + k] = (a.view(np.uint32) >> 16).astype(np.uint16)
     np.savez_compressed(os.path.join(HERE, "sf3d_clip.npz"), **fx)
     print("sf3d_clip:", r.image_embeds.shape, len(oc), "tensors")
 

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import torch
 
+from conftest import golden_weights
 from oracle import sf3d_est_ref as E
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -22,7 +23,7 @@ IMAGE_CFG = dict(distribution="beta", distribution_eval="mode", activation="relu
 
 def _load(name):
     z = np.load(os.path.join(G, name))
-    return z, {k[2:]: z[k] for k in z.files if k.startswith("w.")}
+    return z, golden_weights(z)
 
 
 def test_global_estimator_matches_reference():
@@ -63,7 +64,7 @@ def test_beta_mode_matches_torch_distribution():
 
 def test_clip_tower_matches_transformers_clip():
     z, sd = _load("sf3d_clip.npz")
-    W, L, NH, P, S, Edim = [int(x) for x in z["cfg"]]
+    W, L, NH, P, S, Edim, MLP = [int(x) for x in z["cfg"]]
     feats, tokens = E.clip_visual_forward(sd, "visual.", z["image"], NH, return_tokens=True)
     assert feats.shape == (2, Edim)
     assert np.abs(tokens.numpy() - z["hidden_last"]).max() < 2e-5
