@@ -138,3 +138,19 @@ def test_session_from_onnx_container(cuda, tmp_path):
     img = Image.fromarray(synth.image_rgba(5, 96)[..., :3], mode="RGB")
     ma, mb = a.predict(img)[0], b.predict(img)[0]
     assert np.array_equal(np.asarray(ma), np.asarray(mb))
+
+
+def test_preprocess_image_end_to_end(cuda, tmp_path):
+    """preprocessing.preprocess_image (the add-on's caller, GUIPanel.py:158-160) with the HIP session."""
+    from PIL import Image
+
+    from sculptmate_amd import preprocessing
+    from sculptmate_amd.rembg import session
+
+    s = session.U2netSession(device=cuda, state_dict=synth.u2net_state(0))
+    path = str(tmp_path / "in.png")
+    Image.fromarray(synth.image_rgba(4, 400)[..., :3], mode="RGB").save(path)
+    rgba = preprocessing.preprocess_image(path, ratio=0.85, use_alpha=True, session=s)
+    assert rgba.mode == "RGBA" and rgba.size[0] == rgba.size[1]
+    rgb = preprocessing.preprocess_image(path, ratio=0.75, session=s)
+    assert rgb is None or (rgb.mode == "RGB" and rgb.size == (1024, 1024))
