@@ -16,6 +16,7 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else DEFAULT_CFG["isosurface_resolut
 cfg = dict(DEFAULT_CFG, isosurface_resolution=res)
 t0 = time.time()
 sd = synth.sf3d_state(0, cfg)
+sd.update(synth.sf3d_estimator_state(0))   # CLIP image estimator + illumination estimator, like the shipped checkpoint
 print("synthetic weights: %.1f s, %.1f M params" % (time.time() - t0, sum(v.size for v in sd.values()) / 1e6))
 m = SF3D(cfg)
 m.load_state_dict(sd)
@@ -55,8 +56,23 @@ def stage_times(n=5):
     return np.median(np.array(rows), 0), mesh
 
 
+def estimator_times(n=7):
+    mask = torch.ones(1, 512, 512, device=dev)
+    toks = [torch.randn(3 * 96 * 96, 1024, device=dev)]
+    rows = []
+    for _ in range(n):
+        e = [ev()]
+        m.image_estimator(img[None], mask=mask); e.append(ev())
+        m.global_estimator(toks, 96); e.append(ev())
+        torch.cuda.synchronize()
+        rows.append([e[i].elapsed_time(e[i + 1]) for i in range(2)])
+    return np.median(np.array(rows), 0)
+
+
 stage_times(2)
 t, mesh = stage_times(7)
+te = estimator_times()
+print("image estimator (CLIP ViT-B/32 + heads, every image) %.2f ms | illumination estimator (only on request) %.2f ms" % (te[0], te[1]))
 print("dinov2 %.2f ms | backbone %.2f ms | upsampler %.2f ms | query+mtet %.2f ms | total %.2f ms -> %.1f meshes/s"
       % (t[0], t[1], t[2], t[3], t.sum(), 1e3 / t.sum()))
 print("mesh: %d vertices, %d faces" % (mesh.v_pos.shape[0], mesh.t_pos_idx.shape[0]))
