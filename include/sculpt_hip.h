@@ -343,6 +343,38 @@ int sculpt_resize_bilinear_hwc(const float *in_hwc, const float *mul_hw /* may b
 int sculpt_im2col3x3_strided(const void *in, int n_groups, int S, int C, int elem_bytes, int stride, void *out, sculpt_stream_t stream);
 int sculpt_col_reduce_f32(const float *x, int ld, int rows, int cols, int mean, float *out, sculpt_stream_t stream);
 
+/* Box-projection UV unwrapping (StableFast/sf3d/uv_unwrapper/unwrap.py:625-697), one entry point per
+ * stage; the host side (sculptmate_amd/sf3d/unwrap.py) mirrors Unwrapper.forward.  `stats`: device scratch of
+ * sculpt_uv_stats_words() 32-bit words, initialised by sculpt_uv_box_project and carried through the later stages of the
+ * same mesh.  faces: int32 or int64 [nf][3] (faces_i64).
+ *   sculpt_uv_moments         sums9 (device doubles) = sum of x, y, z, xx, xy, xz, yy, yz, zz over the vertices: the statistics
+ *                             behind _align_mesh_with_main_axis (:546-623; exact principal axes instead of the reference's
+ *                             randomised torch.pca_lowrank)
+ *   sculpt_uv_box_project     rot_pos / rot_nrm = rot (row-major 3x3, host) applied to every vertex; face_uv [nf][3][2] and
+ *                             chart [nf] in 0..5 = _box_assign_vertex_to_cube_face (:16-122)
+ *   sculpt_uv_chart_tangents  vertex_tangents4 [nv][4] (xyz = _calculate_tangents, :239-305); sums42 (device doubles) [6][7] =
+ *                             per chart the sum over its corners of the vertex tangent (3), of the expected tangent (3; with
+ *                             the reference's F.normalize(x, -1) scaling, :326-341) and the corner count
+ *   sculpt_uv_rotate_charts   face_uv rotated per chart by the angle (cos, sin given per chart) about the chart centre and
+ *                             stretched to [0, 1] by the chart's joint min / max (:357-381), in place
+ *   sculpt_uv_assign_atlas    assigned [nf]: chart c stays c, moves to the overlap slice c + 6, or to 12 ("remaining") -- the
+ *                             contract of assign_faces_uv_to_atlas_index in uv_unwrapper.dll (:124-175), own algorithm
+ *                             (UV-space z-buffer of res x res pixels per chart, zbuf = 6*res*res uint64 scratch)
+ *   sculpt_uv_place           out_uv [nf][3][2] atlas coordinates (:177-237, 383-527); block_scratch: ceil(nf/256) ints */
+size_t sculpt_uv_stats_words(void);
+int sculpt_uv_moments(const float *v_pos, size_t nv, double *sums9, sculpt_stream_t stream);
+int sculpt_uv_box_project(const float *v_pos, const float *v_nrm, size_t nv, const void *faces, int faces_i64, size_t nf,
+                          const float *rot9_host, float *rot_pos, float *rot_nrm, float *face_uv, int *chart, unsigned *stats,
+                          sculpt_stream_t stream);
+int sculpt_uv_chart_tangents(const float *rot_pos, const float *rot_nrm, size_t nv, const void *faces, int faces_i64, size_t nf,
+                             const float *face_uv, const int *chart, float *vertex_tangents4, double *sums42, sculpt_stream_t stream);
+int sculpt_uv_rotate_charts(float *face_uv, const int *chart, size_t nf, const float *cos6_host, const float *sin6_host, unsigned *stats,
+                            sculpt_stream_t stream);
+int sculpt_uv_assign_atlas(const float *rot_pos, const void *faces, int faces_i64, size_t nf, const float *face_uv, const int *chart,
+                           int res, unsigned long long *zbuf, int *assigned, sculpt_stream_t stream);
+int sculpt_uv_place(const float *face_uv, const int *assigned, size_t nf, double island_padding, unsigned *stats, int *block_scratch,
+                    float *out_uv, sculpt_stream_t stream);
+
 /* StableFast geometry tail:
  *   dilate_fill (sf3d/models/utils.py:96-133): img f32 [3][H][W], mask f32 [H][W]; scratch 8*H*W floats
  *   vertex normals / tangents (sf3d/models/mesh.py:66-139): area-weighted face normal / UV tangent splat

@@ -27,6 +27,7 @@ lib = ctypes.CDLL(SO_PATH)
 
 _vp, _i, _i64, _f, _sz, _u = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                               ctypes.c_size_t, ctypes.c_uint)
+_d = ctypes.c_double
 _pp = ctypes.POINTER(ctypes.c_void_p)
 _pi64 = ctypes.POINTER(ctypes.c_int64)
 
@@ -75,6 +76,13 @@ SIGNATURES = {
     "sculpt_bake_interpolate": (_i, [_vp, _sz, _vp, _sz, _vp, _i, _vp, _vp]),
     "sculpt_im2col3x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_pixel_shuffle": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sculpt_uv_stats_words": (_sz, []),
+    "sculpt_uv_moments": (_i, [_vp, _sz, _vp, _vp]),
+    "sculpt_uv_box_project": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_uv_chart_tangents": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "sculpt_uv_rotate_charts": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "sculpt_uv_assign_atlas": (_i, [_vp, _vp, _i, _sz, _vp, _vp, _i, _vp, _vp, _vp]),
+    "sculpt_uv_place": (_i, [_vp, _vp, _sz, _d, _vp, _vp, _vp, _vp]),
     "sculpt_resize_bilinear_hwc": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "sculpt_im2col3x3_strided": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_col_reduce_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
