@@ -169,9 +169,8 @@ class Mesh:
         """mesh.py:236-262: (uv, indices) from the unwrapper, then one vertex per face corner."""
         if self.unwrapper is None:
             raise _lib.SculptError(
-                "Mesh.unwrap_uv: no UV unwrapper configured (the reference's box-projection unwrapper ends in a "
-                "Windows DLL, uv_unwrapper/unwrap.py:144-175); set SF3D.unwrapper = callable(v_pos, v_nrm, faces, "
-                "island_padding) -> (uv [Nuv,2], indices [Nf,3])")
+                "Mesh.unwrap_uv: no UV unwrapper configured; set Mesh.unwrapper / SF3D.unwrapper = callable(v_pos, v_nrm, "
+                "faces, island_padding) -> (uv [Nuv,2], indices [Nf,3]), e.g. sf3d.unwrap.BoxProjectionUnwrapper()")
         uv, indices = self.unwrapper(self.v_pos, self.v_nrm, self.t_pos_idx, island_padding)
         self.v_pos = self.v_pos[self.t_pos_idx].reshape(-1, 3).contiguous()
         self.t_pos_idx = torch.arange(self.v_pos.shape[0], device=self.v_pos.device,
@@ -225,7 +224,11 @@ class SF3D(KernelEngine):
         self.tets_path = tets_path
         self.isosurface_helper = None
         self.decoder = None
-        self.unwrapper = None   # callable(v_pos, v_nrm, faces, island_padding) -> (uv, indices)
+        # callable(v_pos, v_nrm, faces, island_padding) -> (uv, indices); default: the reference's box projection
+        # (mesh.py:33 `self.unwrapper = Unwrapper()`) on the GPU.  None: no UVs (and no texture bake).
+        from .unwrap import BoxProjectionUnwrapper
+
+        self.unwrapper = BoxProjectionUnwrapper()
         self.remesher = None    # callable(mesh, mode, vertex_count) -> Mesh  (gpytoolbox in the reference)
         # built by load_state_dict when the checkpoint carries their weights (estimators.py); None otherwise, and
         # then roughness / metallic stay None in run_image's dict

@@ -300,10 +300,18 @@ def test_small_sf3d_run_image_with_textures(cuda):
     _, rgb = m.prepare_image(img)
     codes = m.scene_code(rgb.contiguous())
     m.load_state_dict(_calibrated(m, sd, codes))
+    from sculptmate_amd.sf3d.unwrap import BoxProjectionUnwrapper
+
+    assert isinstance(m.unwrapper, BoxProjectionUnwrapper)        # the reference's default (mesh.py:33), on the GPU
+    m.unwrapper = None
     mesh, gd = m.run_image(img, bake_resolution=0, enable_texture=False)
     assert mesh["uvs"] is None and mesh["basecolor_tex"] is None and mesh["vertices"].shape[1] == 3
     with pytest.raises(Exception):
         m.run_image(img, bake_resolution=128, enable_texture=True)  # no unwrapper configured
+    m.unwrapper = BoxProjectionUnwrapper(512)
+    boxed, _ = m.run_image(img, bake_resolution=128, enable_texture=True)
+    assert boxed["uvs"].shape == (3 * mesh["faces"].shape[0], 2) and boxed["basecolor_tex"].size == (128, 128)
+    assert 0.0 <= boxed["uvs"].min() and boxed["uvs"].max() <= 1.0
     m.unwrapper = cell_atlas_unwrapper
     mesh2, _ = m.run_image(img, bake_resolution=300, enable_texture=True)
     nf = mesh["faces"].shape[0]
