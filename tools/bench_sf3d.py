@@ -76,5 +76,25 @@ print("image estimator (CLIP ViT-B/32 + heads, every image) %.2f ms | illuminati
 print("dinov2 %.2f ms | backbone %.2f ms | upsampler %.2f ms | query+mtet %.2f ms | total %.2f ms -> %.1f meshes/s"
       % (t[0], t[1], t[2], t[3], t.sum(), 1e3 / t.sum()))
 print("mesh: %d vertices, %d faces" % (mesh.v_pos.shape[0], mesh.t_pos_idx.shape[0]))
+
+
+def unwrap_time(n=3):
+    from sculptmate_amd.sf3d.system import Mesh
+
+    ts = []
+    for _ in range(n):
+        mm = Mesh(mesh.v_pos.clone(), mesh.t_pos_idx.clone(), unwrapper=m.unwrapper)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mm.unwrap_uv()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    a = m.unwrapper.last["assigned"]
+    return min(ts), float((a < 6).float().mean()), float(((a >= 6) & (a < 12)).float().mean()), float((a >= 12).float().mean())
+
+
+tu, f0, f1, f2 = unwrap_time()
+print("box-projection unwrap (incl. normals / tangents of the unrolled mesh): %.2f ms; front layer %.1f %%, overlap slice %.1f %%, "
+      "remaining %.1f %%" % (tu, 100 * f0, 100 * f1, 100 * f2))
 fl = dict(dino=0.95e12, backbone=8.5e12, post=1.9e12)
 print("approx TFLOP/s: dino %.0f backbone %.0f upsampler %.0f" % (fl["dino"] / t[0] / 1e9, fl["backbone"] / t[1] / 1e9, fl["post"] / t[2] / 1e9))
