@@ -229,7 +229,11 @@ class SF3D(KernelEngine):
         from .unwrap import BoxProjectionUnwrapper
 
         self.unwrapper = BoxProjectionUnwrapper()
-        self.remesher = None    # callable(mesh, mode, vertex_count) -> Mesh  (gpytoolbox in the reference)
+        # callable(mesh, mode, vertex_count) -> Mesh: gpytoolbox (the reference's package, mesh.py:176-234) when it is
+        # installed, else None and run_image refuses remesh != "none"
+        from .remesh import default_remesher
+
+        self.remesher = default_remesher()
         # built by load_state_dict when the checkpoint carries their weights (estimators.py); None otherwise, and
         # then roughness / metallic stay None in run_image's dict
         self.image_estimator = None

@@ -386,8 +386,33 @@ def test_fast3d_generator_facade(cuda, tmp_path):
     g.model.load_state_dict(_calibrated(g.model, sd, codes))
     assert g.generate_mesh(img, "thing", remesh_option="none", texture_resolution=64, enable_texture=False) == 0
     assert g.last_mesh["faces"].shape[1] == 3
+    nf_plain = g.last_mesh["faces"].shape[0]
+    # the add-on always asks for 'triangle' (generate.py:33): without gpytoolbox the facade hands over the un-remeshed mesh
+    # (with a printed warning), the model itself refuses
+    assert g.model.remesher is None
+    assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, enable_texture=False) == 0
+    assert g.last_mesh["faces"].shape[0] == nf_plain
     with pytest.raises(Exception):
-        g.generate_mesh(img, "thing", remesh_option="triangle", enable_texture=False)  # no remesher configured
+        g.model.run_image(img, bake_resolution=64, remesh="triangle", enable_texture=False)
+    # with a remesher (here: gpytoolbox's call sequence on a stand-in module) the hook is used
+    import types
+
+    from sculptmate_amd.sf3d.remesh import gpytoolbox_remesher
+
+    calls = []
+    fake = types.SimpleNamespace(
+        subdivide=lambda v, f, iters: calls.append(("subdivide", iters)) or (v, f),
+        decimate=lambda v, f, face_ratio: calls.append(("decimate", round(face_ratio, 3), v.dtype, f.dtype)) or (v, f[: len(f) // 2], None, None),
+        remesh_botsch=lambda v, f, steps, h: calls.append(("remesh_botsch", steps, h, v.dtype, f.dtype)) or (v, f))
+    g.model.remesher = lambda mesh, mode, n: gpytoolbox_remesher(mesh, mode, n, gpytoolbox=fake)
+    assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, vertex_simplification_factor="medium",
+                           enable_texture=False) == 0
+    assert g.last_mesh["faces"].shape[0] == nf_plain // 2
+    # 'medium' is not 'med' -> the low setting, 0.1 x the vertices (the reference's quirk, system.py:346-351)
+    assert [c[0] for c in calls] == ["decimate", "remesh_botsch"] and abs(calls[0][1] - 0.1) < 2e-3
+    assert calls[0][2] == np.float32 and calls[0][3] == np.int32 and calls[1][1:] == (10, None, np.float64, np.int32)
+    with pytest.raises(NotImplementedError):
+        gpytoolbox_remesher(None, "quad", 10, gpytoolbox=fake)
 
 
 def test_small_sf3d_with_norm_x_input(cuda):
