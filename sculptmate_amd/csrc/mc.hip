@@ -447,6 +447,15 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
         if (w < wave) wbase += s_wcnt[w];
         nact += s_wcnt[w];
     }
+    if (nact == 0) {  // workgroup-uniform: most row segments are far from the surface -- no list, no scan
+        if (threadIdx.x == 0) {
+            for (int w = 0; w < MC_BLOCK / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+            block_counts[blockIdx.x] = 0;
+            block_nact[blockIdx.x] = 0;
+            block_minmax[blockIdx.x] = make_float2(mn, mx);
+        }
+        return;
+    }
     if (active) s_list[wbase + wrank] = (unsigned char)threadIdx.x;
     __syncthreads();
     // dense part
