@@ -66,8 +66,7 @@ DECODER_PRECISION = "fp32"  # --decoder-precision bf16x3 selects the optional sp
 
 
 def one_step(model, img_dev, events=None):
-    ctx, _ = model.image_tokens(img_dev)
-    _, outb = model.backbone_tokens(ctx)
+    _, outb = model.encode_image(img_dev)   # ViT + backbone (its image-independent head on a second stream under the ViT)
     planes = model.scene_code(outb)
     from sculptmate_amd import ops
 

@@ -294,18 +294,30 @@ class TSR(KernelEngine):
             ctx = ctx32
         return ctx, ctx32
 
-    def _run_blocks(self, h: torch.Tensor, ctx: torch.Tensor):
+    def _self_attention(self, h: torch.Tensor, L):
+        """h += attn1(LN1(h)) of one BasicTransformerBlock (basic_transformer_block.py:149-167)."""
+        b = self.cfg["backbone"]
+        nh, hd = b["num_attention_heads"], b["attention_head_dim"]
+        D, T = nh * hd, h.shape[0]
+        Tp = ((T + 63) // 64) * 64
+        xn = self._b("bb_xn", (T, D), self.adt)
+        qk = self._b("bb_qk", (T, 2 * D), self.adt)
+        vt = self._b("bb_vt", (D, Tp), self.adt, zero=True)
+        att = self._b("bb_att", (T, D), self.adt)
+        self._ln(h, L["n1_w"], L["n1_b"], 1e-5, xn)
+        self._gemm(xn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
+        self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, 1.0 / math.sqrt(hd))
+        self._gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
+
+    def _run_blocks(self, h: torch.Tensor, ctx: torch.Tensor, first_self_attention_done: bool = False):
         """All BasicTransformerBlocks on the fp32 residual stream h [T, D] (updated in place)."""
         b, w = self.cfg["backbone"], self._w
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
         D = nh * hd
         T, Tc = h.shape[0], ctx.shape[0]
         Tcp = ((Tc + 63) // 64) * 64
-        Tp = ((T + 63) // 64) * 64
         xn = self._b("bb_xn", (T, D), self.adt)
-        qk = self._b("bb_qk", (T, 2 * D), self.adt)
         q = self._b("bb_q", (T, D), self.adt)
-        vt = self._b("bb_vt", (D, Tp), self.adt, zero=True)
         nL = len(w["blocks"])
         ck_all = self._b("bb_ck", (Tc, nL * D), self.adt)
         cvt_all = self._b("bb_cvt", (nL * D, Tcp), self.adt, zero=True)
@@ -315,10 +327,8 @@ class TSR(KernelEngine):
         scale = 1.0 / math.sqrt(hd)
         for li, L in enumerate(w["blocks"]):
             ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
-            self._ln(h, L["n1_w"], L["n1_b"], 1e-5, xn)
-            self._gemm(xn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
-            self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, scale)
-            self._gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
+            if li > 0 or not first_self_attention_done:
+                self._self_attention(h, L)
             self._ln(h, L["n2_w"], L["n2_b"], 1e-5, xn)
             self._gemm(xn, L["ca_q"], out_bf16=q)
             self._attn(q, ck, cvt, att, T, Tc, nh, scale)
@@ -328,22 +338,23 @@ class TSR(KernelEngine):
             self._gemm(ff, L["ff2"], bias=L["ff2_b"], residual=h, out_f32=h)
         return h
 
-    def backbone_tokens(self, ctx: torch.Tensor):
-        """Triplane1DTokenizer + Transformer1D for one image; ctx bf16 [Tc, cross_dim].
-        Returns the output tokens token-major: fp32 [3*S*S, C] (+ bf16 copy)."""
+    def _backbone_head(self):
+        """The part of Transformer1D.forward that does not depend on the image: GroupNorm of the learned triplane tokens,
+        proj_in (transformer_1d.py:181-189) and the first block's self-attention."""
         b, w = self.cfg["backbone"], self._w
-        C = self.cfg["tokenizer"]["num_channels"]
-        nh, hd = b["num_attention_heads"], b["attention_head_dim"]
-        D = nh * hd
+        D = b["num_attention_heads"] * b["attention_head_dim"]
         T = w["emb_ct"].shape[1]
-        Tc = ctx.shape[0]
-        Tcp = ((Tc + 63) // 64) * 64
         xn = self._b("bb_xn", (T, D), self.adt)
         stats = self._b("gn_stats", (2 * b["norm_num_groups"],), torch.float32)
         ops.groupnorm_tokens(w["emb_ct"], b["norm_num_groups"], w["gn_w"], w["gn_b"], 1e-6, xn, stats)
         h = self._b("bb_h", (T, D), torch.float32)
         self._gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
-        h = self._run_blocks(h, ctx)
+        return h
+
+    def _backbone_tail(self, h: torch.Tensor):
+        w = self._w
+        C = self.cfg["tokenizer"]["num_channels"]
+        T, D = h.shape
         out = self._b("bb_out", (T, C), torch.float32)
         if self.precision == "bf16":
             hb = self._b("bb_hb", (T, D), BF16)
@@ -354,6 +365,33 @@ class TSR(KernelEngine):
             ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out=out)
             outb = out
         return out, outb
+
+    def backbone_tokens(self, ctx: torch.Tensor):
+        """Triplane1DTokenizer + Transformer1D for one image; ctx bf16 [Tc, cross_dim].
+        Returns the output tokens token-major: fp32 [3*S*S, C] (+ bf16 copy)."""
+        h = self._run_blocks(self._backbone_head(), ctx)
+        return self._backbone_tail(h)
+
+    def encode_image(self, image_hwc: torch.Tensor):
+        """image_tokens + backbone_tokens for one [S,S,3] fp32 device image, with the image-independent head of the backbone
+        (GroupNorm, proj_in, first self-attention: 6 launches) issued on a second HIP stream so that it runs under the ViT,
+        whose 1025-token launches leave most CUs idle.  Same kernels on the same operands as the sequential calls:
+        bit-identical tokens."""
+        main = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(self.device)
+        fork, join = torch.cuda.Event(), torch.cuda.Event()
+        fork.record(main)               # everything queued so far (the previous image's readers of these buffers) comes first
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            h = self._backbone_head()
+            self._self_attention(h, self._w["blocks"][0])
+            join.record(side)
+        ctx, _ = self.image_tokens(image_hwc)
+        main.wait_event(join)
+        h = self._run_blocks(h, ctx, first_self_attention_done=True)
+        return self._backbone_tail(h)
 
     def scene_code(self, tokens_bf16: torch.Tensor):
         """detokenize + TriplaneUpsampleNetwork: tokens [3*S*S, C] -> planes fp32 [3, Co, 2S, 2S]."""
@@ -383,8 +421,7 @@ class TSR(KernelEngine):
                 raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
             if img.shape[0] != size or img.shape[1] != size:
                 img = ops.resize_aa_bilinear(img, size)
-            ctx, _ = self.image_tokens(img)
-            _, outb = self.backbone_tokens(ctx)
+            _, outb = self.encode_image(img)
             codes.append(self.scene_code(outb))
         return torch.stack(codes, 0)
 

@@ -406,3 +406,27 @@ def test_fp32_parity_mode_small_and_mesh(cuda):
     if mesh.faces.shape == rf.shape and np.array_equal(mesh.faces, rf):
         # same topology: vertices within the north-star tolerance (1e-4 relative to the scene extent)
         assert np.abs(mesh.vertices - rv).max() < 1e-4 * 0.87
+
+
+def test_encode_image_two_stream_overlap_is_bit_identical(cuda):
+    """TSR.encode_image issues the image-independent head of the backbone on a second HIP stream under the ViT: same kernels,
+    same operands -> the same bits as the sequential calls, also back to back without host synchronisation."""
+    m, sd = _small_model(cuda)
+    S = SMALL_CFG["cond_image_size"]
+    imgs = [torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=40 + i, size=S))).to(cuda) for i in range(3)]
+    want = []
+    for im in imgs:
+        ctx, _ = m.image_tokens(im)
+        out, outb = m.backbone_tokens(ctx)
+        want.append((out.clone(), outb.clone()))
+    got = []
+    for rep in range(3):
+        for im in imgs:                       # no synchronisation between images: the fork event orders the buffer reuse
+            out, outb = m.encode_image(im)
+            got.append((out.clone(), outb.clone()))
+    torch.cuda.synchronize()
+    for k, (o, ob) in enumerate(got):
+        assert torch.equal(o, want[k % 3][0]) and torch.equal(ob, want[k % 3][1]), k
+    # forward() goes through the same path
+    codes = m([synth.composite_rgb(synth.image_rgba(seed=40, size=S))], device=cuda)
+    assert torch.equal(codes[0], m.scene_code(want[0][1]))

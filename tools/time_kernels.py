@@ -30,6 +30,11 @@ vol = (25.0 * torch.exp(9.0 * (0.5 - torch.sqrt(x * x + 1.3 * y * y + 0.8 * z * 
 v, f = ops.marching_cubes(vol, 0.0)
 t = timeit(lambda: ops.marching_cubes(vol, 0.0))
 print("marching_cubes %d^3: %.3f ms (%d verts %d faces) -> %.1f GB/s of 4B/voxel" % (R, t, len(v), len(f), 4 * R ** 3 / t / 1e6))
+gy = (torch.sin(9 * x) * torch.cos(9 * y) + torch.sin(9 * y) * torch.cos(9 * z) + torch.sin(9 * z) * torch.cos(9 * x)).contiguous()
+v, f = ops.marching_cubes(gy, 0.0)
+t = timeit(lambda: ops.marching_cubes(gy, 0.0))
+print("marching_cubes %d^3 gyroid (high active fraction): %.3f ms (%d verts %d faces) -> %.1f GB/s of 4B/voxel + mesh bytes"
+      % (R, t, len(v), len(f), (4 * R ** 3 + 12 * len(v) + 24 * len(f)) / t / 1e6))
 pts = (torch.rand(300000, 3, device=dev) * 2 - 1) * 0.87
 t = timeit(lambda: ops.triplane_query(tri, mlp, pts, want=("color",)))
 print("triplane_query 300k pts: %.3f ms" % t)
