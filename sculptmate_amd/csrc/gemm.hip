@@ -22,6 +22,8 @@
 // read address (guide rule 21).
 // The 64-row weight tile is chosen when the 128x128 grid would leave CUs idle (N=1024, M=3072 is
 // only 192 tiles for 256 CUs).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sculpt {
@@ -365,7 +367,11 @@ extern "C" int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W
     hipStream_t st = as_stream(stream);
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of
     // the two transformers except the deep-K 64-row-tile case (K = 4096, N = 1024: -4 %), which keeps 4 waves
-    const bool nw8 = true, nw8s = K < 2048;
+    // ... unless the launch has fewer workgroups than CUs (the ViT's 1025 x 768 x 3072): then 8 waves are the only
+    // latency hiding a CU gets
+    static const int force = [] { const char *e = getenv("SCULPT_GEMM_NW8S"); return e ? atoi(e) : -1; }();
+    const bool underfilled = (long)(N / 64) * mt < (long)num_cus();
+    const bool nw8 = true, nw8s = force >= 0 ? force != 0 : (K < 2048 || underfilled);
     if (epilogue == SCULPT_EPI_GEGLU) {
         SC_REQUIRE(N % 64 == 0, "gemm_bf16(GEGLU): N=%d must be a multiple of 64", N);
         SC_REQUIRE(!residual && !out_bf16_t, "gemm_bf16(GEGLU): residual/transposed output unsupported");
