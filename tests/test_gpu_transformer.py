@@ -20,7 +20,8 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12)), float((a - b).abs().max())
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1025, 768, 768), (3072, 1024, 1024), (300, 256, 4096), (1, 128, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1025, 768, 768), (3072, 1024, 1024), (300, 256, 4096), (1, 128, 64),
+                                   (3072, 1024, 4096), (2950, 1024, 512), (3073, 1024, 128)])  # deep K, ragged M
 def test_gemm_bias_residual_vs_fp32_reference(cuda, M, N, K):
     from sculptmate_amd import ops
 
