@@ -26,7 +26,6 @@ same architecture (transformers' CLIPVisionModelWithProjection, sf3d_clip.npz) -
 
 `bf16=True` rounds where the HIP pipeline stores bf16 (see oracle/tsr_ref.py).
 """
-import math
 
 import torch
 import torch.nn.functional as F
