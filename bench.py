@@ -105,6 +105,19 @@ def stage_split(model, img_dev, n=5):
     return dict(zip(("image_tokenizer", "backbone", "upsample", "density_grid", "marching_cubes"), [round(float(x), 3) for x in med]))
 
 
+def density_deviation(model, img_dev, mode, R=96):
+    """max |density_act(mode) - density_act(fp32 kernel)| / max(|density_act(fp32 kernel)|, 1e-3) over an R^3 lattice of the
+    bench's own scene code (the fp32 kernel itself is within 2e-5 of the CPU oracle, tests/test_gpu_triplane.py)."""
+    from sculptmate_amd import ops
+
+    _, outb = model.encode_image(img_dev)
+    planes = model.scene_code(outb)
+    cfg = model.renderer.cfg
+    a = ops.density_grid(planes, model.decoder, R, radius=cfg.radius, density_bias=cfg.density_bias).clone()
+    b = ops.density_grid(planes, model.decoder, R, radius=cfg.radius, density_bias=cfg.density_bias, precision=mode)
+    return float(((a - b).abs() / a.abs().clamp_min(1e-3)).max())
+
+
 def optional_mode_rates(model, imgs, steps):
     """Whole-step rate with the optional split-operand density modes, measured after the timed region."""
     global DECODER_PRECISION
@@ -120,7 +133,8 @@ def optional_mode_rates(model, imgs, steps):
                 one_step(model, imgs[i % len(imgs)])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            res[mode] = {"meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3}
+            res[mode] = {"meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
+                         "density_max_rel_dev_vs_fp32_kernel": density_deviation(model, imgs[0], mode)}
     finally:
         DECODER_PRECISION = keep
     return res
