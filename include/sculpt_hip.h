@@ -374,6 +374,11 @@ int sculpt_uv_assign_atlas(const float *rot_pos, const void *faces, int faces_i6
                            int res, unsigned long long *zbuf, int *assigned, sculpt_stream_t stream);
 int sculpt_uv_place(const float *face_uv, const int *assigned, size_t nf, double island_padding, unsigned *stats, int *block_scratch,
                     float *out_uv, sculpt_stream_t stream);
+/* The DLL's own entry point (HOST pointers, same name / signature as unwrap.py:147-154 declares for uv_unwrapper.dll):
+ * vertices [nv][3] (already rotated into the principal frame), indices int64 [nf][3], face_uv [nf][3][2], face_index int64 [nf]
+ * in 0..5 -> out int64 [nf] in {c, c + 6, 12} */
+void assign_faces_uv_to_atlas_index(const float *vertices, size_t nv, const long long *indices, size_t nf, const float *face_uv,
+                                    const long long *face_index, long long *out);
 
 /* StableFast geometry tail:
  *   dilate_fill (sf3d/models/utils.py:96-133): img f32 [3][H][W], mask f32 [H][W]; scratch 8*H*W floats

@@ -82,6 +82,7 @@ SIGNATURES = {
     "sculpt_uv_chart_tangents": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sculpt_uv_rotate_charts": (_i, [_vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "sculpt_uv_assign_atlas": (_i, [_vp, _vp, _i, _sz, _vp, _vp, _i, _vp, _vp, _vp]),
+    "assign_faces_uv_to_atlas_index": (None, [_vp, _sz, _vp, _sz, _vp, _vp, _vp]),
     "sculpt_uv_place": (_i, [_vp, _vp, _sz, _d, _vp, _vp, _vp, _vp]),
     "sculpt_resize_bilinear_hwc": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "sculpt_im2col3x3_strided": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

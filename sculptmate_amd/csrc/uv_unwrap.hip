@@ -22,6 +22,8 @@
 #include <float.h>
 #include <math.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace sculpt {
@@ -678,6 +680,37 @@ int sculpt_uv_place(const float *face_uv, const int *assigned, size_t nf, double
     hipLaunchKernelGGL(uv_place_kernel, dim3(nb), dim3(UVB), 0, st, face_uv, assigned, (long)nf, island_padding, stats, block_scratch, out_uv);
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+// The DLL's own entry point (HOST pointers; name and signature as unwrap.py:147-154 declares them for uv_unwrapper.dll), so
+// that the reference's Unwrapper class runs unchanged on Linux with ctypes.CDLL pointed at this library.
+void assign_faces_uv_to_atlas_index(const float *vertices, size_t nv, const long long *indices, size_t nf, const float *face_uv,
+                                    const long long *face_index, long long *out) {
+    if (nf == 0) return;
+    const int res = 1024;
+    float *d_v = nullptr, *d_uv = nullptr;
+    long long *d_f = nullptr;
+    int *d_chart = nullptr, *d_assigned = nullptr;
+    unsigned long long *d_z = nullptr;
+    std::vector<int> chart(nf), assigned(nf);
+    for (size_t i = 0; i < nf; ++i) chart[i] = (int)face_index[i];
+    bool ok = hipMalloc(&d_v, sizeof(float) * 3 * (nv ? nv : 1)) == hipSuccess && hipMalloc(&d_f, sizeof(long long) * 3 * nf) == hipSuccess &&
+              hipMalloc(&d_uv, sizeof(float) * 6 * nf) == hipSuccess && hipMalloc(&d_chart, sizeof(int) * nf) == hipSuccess &&
+              hipMalloc(&d_assigned, sizeof(int) * nf) == hipSuccess &&
+              hipMalloc(&d_z, sizeof(unsigned long long) * 6 * (size_t)res * res) == hipSuccess;
+    if (ok && nv) ok = hipMemcpy(d_v, vertices, sizeof(float) * 3 * nv, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = hipMemcpy(d_f, indices, sizeof(long long) * 3 * nf, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(d_uv, face_uv, sizeof(float) * 6 * nf, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(d_chart, chart.data(), sizeof(int) * nf, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = sculpt_uv_assign_atlas(d_v, d_f, 1, nf, d_uv, d_chart, res, d_z, d_assigned, nullptr) == 0;
+    if (ok) ok = hipMemcpy(assigned.data(), d_assigned, sizeof(int) * nf, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        set_error("assign_faces_uv_to_atlas_index: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+        for (size_t i = 0; i < nf; ++i) out[i] = face_index[i];   // the function returns void: leave every face in its chart
+    } else {
+        for (size_t i = 0; i < nf; ++i) out[i] = assigned[i];
+    }
+    (void)hipFree(d_v); (void)hipFree(d_f); (void)hipFree(d_uv); (void)hipFree(d_chart); (void)hipFree(d_assigned); (void)hipFree(d_z);
 }
 
 }  // extern "C"

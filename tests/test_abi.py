@@ -9,7 +9,8 @@ def _declared():
     src = open(os.path.join(ROOT, "include", "sculpt_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set(re.findall(r"\b(sculpt_[a-z0-9_]+)\s*\(", src))
-    names |= set(re.findall(r"\bvoid\s+((?:rasterize|interpolate)_cpu)\s*\(", src))  # texture_baker.dll's own names
+    # texture_baker.dll's and uv_unwrapper.dll's own export names
+    names |= set(re.findall(r"\bvoid\s+((?:rasterize|interpolate)_cpu|assign_faces_uv_to_atlas_index)\s*\(", src))
     return sorted(names)
 
 

@@ -139,3 +139,31 @@ def test_unwrapper_in_sf3d_mesh_and_bake(cuda):
     assert cover > 0.25, cover                                            # six large charts fill a good part of the 3x2 atlas
     with pytest.raises(Exception):
         BoxProjectionUnwrapper()(v.cpu(), v.cpu(), f.cpu(), 0.02)
+
+
+def test_dll_entry_point_called_like_the_reference_does(cuda, z):
+    """uv_unwrapper.dll's export under its own name and host-pointer signature (unwrap.py:143-172): the ctypes call the
+    reference makes, pointed at libsculpt_hip.so, returns the same assignment as the device entry point."""
+    import ctypes
+
+    from sculptmate_amd import _lib
+
+    dll = ctypes.CDLL(_lib.SO_PATH)
+    fn = dll.assign_faces_uv_to_atlas_index
+    fn.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_longlong), ctypes.c_size_t,
+                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]
+    fn.restype = None
+    g = lambda k: z["tor." + k]  # noqa: E731
+    v = np.ascontiguousarray(g("rot_pos").reshape(-1), np.float32)
+    f = np.ascontiguousarray(g("faces").reshape(-1), np.int64)
+    uv = np.ascontiguousarray(g("uv_rot").reshape(-1), np.float32)
+    fi = np.ascontiguousarray(g("face_index"), np.int64)
+    out = np.zeros(fi.shape[0], np.int64)
+    fn(v.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), v.size // 3, f.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), fi.shape[0],
+       uv.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), fi.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+       out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)))
+    uw = BoxProjectionUnwrapper(1024)
+    want = uw.assign_atlas(torch.from_numpy(g("rot_pos")).to(cuda), torch.from_numpy(g("faces")).to(cuda),
+                           torch.from_numpy(g("uv_rot")).to(cuda).contiguous(), torch.from_numpy(fi.astype(np.int32)).to(cuda))
+    assert np.array_equal(out, want.cpu().numpy().astype(np.int64))
+    assert np.all((out == fi) | (out == fi + 6) | (out == 12)) and (out != fi).any()
