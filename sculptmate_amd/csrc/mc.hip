@@ -293,6 +293,37 @@ __device__ __forceinline__ bool cell_of_block(const Grid &g, int &x, int &y, int
     return x < g.c2;
 }
 
+// The emit passes run over the ACTIVE cells only, packed: global active index i -> (workgroup b of the classify pass, rank
+// k inside it) through the two-level exclusive scan of the per-workgroup active counts (act_ofs local to a group of 1024
+// workgroups, gact_base per group).  "Largest index whose offset is <= i" lands on the non-empty workgroup among equals.
+struct ActiveIndex {
+    const unsigned *act_ofs, *gact_base;
+    int nblocks, ngroups;
+};
+__device__ __forceinline__ void locate_active(const ActiveIndex &ai, unsigned i, int &b, int &k) {
+    int lo = 0, hi = ai.ngroups;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ai.gact_base[mid] <= i) lo = mid; else hi = mid;
+    }
+    const unsigned r = i - ai.gact_base[lo];
+    int b0 = lo << 10, b1 = min(ai.nblocks, b0 + 1024);
+    while (b1 - b0 > 1) {
+        const int mid = (b0 + b1) >> 1;
+        if (ai.act_ofs[mid] <= r) b0 = mid; else b1 = mid;
+    }
+    b = b0;
+    k = (int)(r - ai.act_ofs[b0]);
+}
+// first cell (x0, y, z) of classify workgroup b
+__device__ __forceinline__ void origin_of_block(const Grid &g, int b, int &x0, int &y, int &z) {
+    const int bpr = (g.c2 + MC_BLOCK - 1) / MC_BLOCK;
+    const unsigned row = (unsigned)b / (unsigned)bpr;
+    x0 = (b - (int)(row * (unsigned)bpr)) * MC_BLOCK;
+    y = (int)(row % (unsigned)g.c1);
+    z = (int)(row / (unsigned)g.c1);
+}
+
 // does cell (x,y,z) own edge e (is it the first cell, in sweep order, that touches it)?
 __device__ __forceinline__ bool owns_edge(int e, int x, int y, int z, int halo_low) {
     if (halo_low && z == 0 && e < 4) return false;  // owned by the last cell layer of the previous slab
@@ -390,7 +421,8 @@ struct McHeader {            // first 64 bytes of the workspace
     unsigned long long total_vert;
     unsigned min_ord, max_ord;
     unsigned nan_seen;  // some corner value was NaN (set by the classify pass)
-    unsigned pad[9];
+    unsigned total_active;  // number of active cells (= CellRec records) of the whole grid
+    unsigned pad[8];
 };
 
 // One record per ACTIVE cell, stored compactly per workgroup (slot b*256 + rank, rank in cell order):
@@ -492,8 +524,11 @@ __global__ __launch_bounds__(1024) void mc_scan1_kernel(const int *__restrict__ 
                                                         const float2 *__restrict__ block_minmax, int nblocks,
                                                         unsigned *__restrict__ tri_ofs, unsigned *__restrict__ vert_ofs,
                                                         unsigned long long *__restrict__ group_tot,
-                                                        float2 *__restrict__ group_minmax) {
+                                                        float2 *__restrict__ group_minmax,
+                                                        const int *__restrict__ block_nact, unsigned *__restrict__ act_ofs,
+                                                        unsigned *__restrict__ group_act) {
     __shared__ unsigned long long wsum[16];
+    __shared__ unsigned wasum[16];
     __shared__ float s_mn[16], s_mx[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 1024 + threadIdx.x;
@@ -501,43 +536,53 @@ __global__ __launch_bounds__(1024) void mc_scan1_kernel(const int *__restrict__ 
     float mn = FLT_MAX, mx = -FLT_MAX;
     if (i < nblocks) { const float2 mm = block_minmax[i]; mn = mm.x; mx = mm.y; }
     const unsigned long long val = (unsigned long long)(pk & 0xffff) | ((unsigned long long)(pk >> 16) << 32);
+    const unsigned na = i < nblocks ? (unsigned)block_nact[i] : 0u;
     unsigned long long inc = val;
+    unsigned ainc = na;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         unsigned long long up = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += up;
+        const unsigned aup = __shfl_up(ainc, d, 64);
+        if (lane >= d) { inc += up; ainc += aup; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, d, 64));
         mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     }
-    if (lane == 63) wsum[wave] = inc;
+    if (lane == 63) { wsum[wave] = inc; wasum[wave] = ainc; }
     if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
     __syncthreads();
     unsigned long long wbase = 0, tot = 0;
+    unsigned awbase = 0, atot = 0;
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) wbase += wsum[w];
+        if (w < wave) { wbase += wsum[w]; awbase += wasum[w]; }
         tot += wsum[w];
+        atot += wasum[w];
     }
     const unsigned long long ex = wbase + inc - val;
     if (i < nblocks) {
         tri_ofs[i] = (unsigned)(ex & 0xffffffffull);   // local to the group; the group base is added by the consumers
         vert_ofs[i] = (unsigned)(ex >> 32);
+        act_ofs[i] = awbase + ainc - na;
     }
     if (threadIdx.x == 0) {
         for (int w = 0; w < 16; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
         group_tot[blockIdx.x] = tot;
         group_minmax[blockIdx.x] = make_float2(mn, mx);
+        group_act[blockIdx.x] = atot;
     }
 }
 
 // level 2: one workgroup turns the group totals into exclusive group bases (in place) and the grand totals
 __global__ __launch_bounds__(1024) void mc_scan2_kernel(unsigned long long *__restrict__ group_tot,
                                                         const float2 *__restrict__ group_minmax, int ngroups,
-                                                        McHeader *__restrict__ hdr) {
+                                                        McHeader *__restrict__ hdr, unsigned *__restrict__ group_act) {
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long carry_s;
+    __shared__ unsigned wasum[16];
+    __shared__ unsigned acarry_s;
+    if (threadIdx.x == 0) acarry_s = 0;
     __shared__ float s_mn[16], s_mx[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
@@ -546,23 +591,28 @@ __global__ __launch_bounds__(1024) void mc_scan2_kernel(unsigned long long *__re
     for (int base = 0; base < ngroups; base += 1024) {
         const int i = base + threadIdx.x;
         const unsigned long long val = i < ngroups ? group_tot[i] : 0ull;
+        const unsigned aval = i < ngroups ? group_act[i] : 0u;
         if (i < ngroups) { const float2 mm = group_minmax[i]; mn = fminf(mn, mm.x); mx = fmaxf(mx, mm.y); }
         unsigned long long inc = val;
+        unsigned ainc = aval;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             unsigned long long up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += up;
+            const unsigned aup = __shfl_up(ainc, d, 64);
+            if (lane >= d) { inc += up; ainc += aup; }
         }
-        if (lane == 63) wsum[wave] = inc;
+        if (lane == 63) { wsum[wave] = inc; wasum[wave] = ainc; }
         __syncthreads();
         unsigned long long wbase = carry_s, tot = 0;
+        unsigned awbase = acarry_s, atot = 0;
         for (int w = 0; w < 16; ++w) {
-            if (w < wave) wbase += wsum[w];
+            if (w < wave) { wbase += wsum[w]; awbase += wasum[w]; }
             tot += wsum[w];
+            atot += wasum[w];
         }
-        if (i < ngroups) group_tot[i] = wbase + inc - val;
+        if (i < ngroups) { group_tot[i] = wbase + inc - val; group_act[i] = awbase + ainc - aval; }
         __syncthreads();
-        if (threadIdx.x == 0) carry_s += tot;
+        if (threadIdx.x == 0) { carry_s += tot; acarry_s += atot; }
         __syncthreads();
     }
 #pragma unroll
@@ -576,6 +626,7 @@ __global__ __launch_bounds__(1024) void mc_scan2_kernel(unsigned long long *__re
         for (int w = 0; w < 16; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
         hdr->total_tri = carry_s & 0xffffffffull;
         hdr->total_vert = carry_s >> 32;
+        hdr->total_active = acarry_s;
         hdr->min_ord = f2ord(mn);
         hdr->max_ord = f2ord(mx);
     }
@@ -599,22 +650,23 @@ __device__ __forceinline__ Tiling tiling_of(unsigned w0) {
 // Pass 2, active cells only (dense lanes): the owner of every crossing edge writes the vertex and the
 // lattice-edge -> id map.
 __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restrict__ vol, Grid g, double level,
-                                                            const CellRec *__restrict__ recs,
-                                                            const int *__restrict__ block_nact,
+                                                            const CellRec *__restrict__ recs, ActiveIndex ai,
+                                                            const McHeader *__restrict__ hdr,
                                                             const unsigned *__restrict__ vert_ofs,
                                                             const unsigned long long *__restrict__ group_base,
                                                             int *__restrict__ edge_map, float *__restrict__ verts,
                                                             float vdiv, float vmul, float vadd, int affine) {
-    const int nact = block_nact[blockIdx.x];
-    if ((int)threadIdx.x >= nact) return;
-    int x, y, z;
-    cell_of_block(g, x, y, z);
-    const CellRec rec = recs[(long)blockIdx.x * MC_BLOCK + threadIdx.x];
-    x = x - (int)threadIdx.x + (int)(rec.w0 & 0xffu);
+  const unsigned total_active = hdr->total_active;
+  for (unsigned ci = blockIdx.x * MC_BLOCK + threadIdx.x; ci < total_active; ci += gridDim.x * MC_BLOCK) {
+    int b, k, x, y, z;
+    locate_active(ai, ci, b, k);
+    origin_of_block(g, b, x, y, z);
+    const CellRec rec = recs[(long)b * MC_BLOCK + k];
+    x += (int)(rec.w0 & 0xffu);
     const Tiling t = tiling_of(rec.w0);
     double v[8];
     load_cell(vol, g, z, y, x, level, v);
-    unsigned id = (unsigned)(group_base[blockIdx.x >> 10] >> 32) + vert_ofs[blockIdx.x] + (rec.w1 >> 16);
+    unsigned id = (unsigned)(group_base[b >> 10] >> 32) + vert_ofs[b] + (rec.w1 >> 16);
     unsigned seen = 0;
     for (int i = 0; i < t.len; ++i) {
         const int e = tiling_entry(t, i);
@@ -673,27 +725,29 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
         verts[3 * (size_t)id + 2] = o2;
         ++id;
     }
+  }
 }
 
 // Pass 3, active cells only: triangles through the lattice-edge -> id map (no volume reads at all).
 template <typename IdxT>
-__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(Grid g, const CellRec *__restrict__ recs,
-                                                            const int *__restrict__ block_nact,
+__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(Grid g, const CellRec *__restrict__ recs, ActiveIndex ai,
+                                                            const McHeader *__restrict__ hdr,
                                                             const unsigned *__restrict__ tri_ofs,
                                                             const unsigned *__restrict__ vert_ofs,
                                                             const unsigned long long *__restrict__ group_base,
                                                             const int *__restrict__ edge_map, IdxT *__restrict__ faces,
                                                             int ref_order) {
-    const int nact = block_nact[blockIdx.x];
-    if ((int)threadIdx.x >= nact) return;
-    int x, y, z;
-    cell_of_block(g, x, y, z);
-    const CellRec rec = recs[(long)blockIdx.x * MC_BLOCK + threadIdx.x];
-    x = x - (int)threadIdx.x + (int)(rec.w0 & 0xffu);
+  const unsigned total_active = hdr->total_active;
+  for (unsigned ci = blockIdx.x * MC_BLOCK + threadIdx.x; ci < total_active; ci += gridDim.x * MC_BLOCK) {
+    int b, k, x, y, z;
+    locate_active(ai, ci, b, k);
+    origin_of_block(g, b, x, y, z);
+    const CellRec rec = recs[(long)b * MC_BLOCK + k];
+    x += (int)(rec.w0 & 0xffu);
     const Tiling t = tiling_of(rec.w0);
-    const unsigned long long gb = group_base[blockIdx.x >> 10];
-    const unsigned tri0 = (unsigned)(gb & 0xffffffffull) + tri_ofs[blockIdx.x] + (rec.w1 & 0xffffu);
-    const unsigned vown0 = (unsigned)(gb >> 32) + vert_ofs[blockIdx.x] + (rec.w1 >> 16);
+    const unsigned long long gb = group_base[b >> 10];
+    const unsigned tri0 = (unsigned)(gb & 0xffffffffull) + tri_ofs[b] + (rec.w1 & 0xffffu);
+    const unsigned vown0 = (unsigned)(gb >> 32) + vert_ofs[b] + (rec.w1 >> 16);
     // id of the centre vertex = own base + rank among owned vertices in first-appearance order
     int centre_id = -1;
     {
@@ -726,6 +780,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(Grid g, const CellRe
         if (ref_order) { f[0] = (IdxT)id[1]; f[1] = (IdxT)id[2]; f[2] = (IdxT)id[0]; }
         else { f[0] = (IdxT)id[2]; f[1] = (IdxT)id[1]; f[2] = (IdxT)id[0]; }
     }
+  }
 }
 
 // lattice-edge -> vertex-id map of the LAST lattice plane (x and y edges), -1 where the edge has no crossing
@@ -758,7 +813,7 @@ static int make_grid(int n0, int n1, int n2, Grid *g) {
 }
 
 struct WsLayout {
-    size_t off_counts, off_nact, off_minmax, off_tri, off_vert, off_gtot, off_gmm, off_recs, off_map, total;
+    size_t off_counts, off_nact, off_minmax, off_tri, off_vert, off_gtot, off_gmm, off_recs, off_map, off_aofs, off_gact, total;
     int ngroups;
     int nblocks;
 };
@@ -777,6 +832,8 @@ static WsLayout ws_layout(const Grid &g) {
     w.off_tri = o;    o = al(o + sizeof(unsigned) * w.nblocks);
     w.off_vert = o;   o = al(o + sizeof(unsigned) * w.nblocks);
     w.off_map = o;    o = al(o + sizeof(int) * 3 * (size_t)g.n0 * g.n1 * g.n2);
+    w.off_aofs = o;   o = al(o + sizeof(unsigned) * w.nblocks);
+    w.off_gact = o;   o = al(o + sizeof(unsigned) * w.ngroups);
     w.total = o;
     return w;
 }
@@ -820,10 +877,13 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsi
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(w.ngroups), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
                        reinterpret_cast<const float2 *>(ws + w.off_minmax), w.nblocks,
                        reinterpret_cast<unsigned *>(ws + w.off_tri), reinterpret_cast<unsigned *>(ws + w.off_vert),
-                       reinterpret_cast<unsigned long long *>(ws + w.off_gtot), reinterpret_cast<float2 *>(ws + w.off_gmm));
+                       reinterpret_cast<unsigned long long *>(ws + w.off_gtot), reinterpret_cast<float2 *>(ws + w.off_gmm),
+                       reinterpret_cast<const int *>(ws + w.off_nact), reinterpret_cast<unsigned *>(ws + w.off_aofs),
+                       reinterpret_cast<unsigned *>(ws + w.off_gact));
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan2_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<unsigned long long *>(ws + w.off_gtot),
-                       reinterpret_cast<const float2 *>(ws + w.off_gmm), w.ngroups, hdr);
+                       reinterpret_cast<const float2 *>(ws + w.off_gmm), w.ngroups, hdr,
+                       reinterpret_cast<unsigned *>(ws + w.off_gact));
     SC_LAUNCH_CHECK();
     McHeader res;
     SC_HIP(hipMemcpyAsync(&res, hdr, sizeof(res), hipMemcpyDeviceToHost, st));
@@ -867,16 +927,20 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsig
     const unsigned *vrt = reinterpret_cast<const unsigned *>(ws + w.off_vert);
     int *emap = reinterpret_cast<int *>(ws + w.off_map);
     const CellRec *recs = reinterpret_cast<const CellRec *>(ws + w.off_recs);
-    const int *nact = reinterpret_cast<const int *>(ws + w.off_nact);
+    const McHeader *hdr = reinterpret_cast<const McHeader *>(ws);
+    const ActiveIndex ai{reinterpret_cast<const unsigned *>(ws + w.off_aofs), reinterpret_cast<const unsigned *>(ws + w.off_gact),
+                         w.nblocks, w.ngroups};
     const unsigned long long *gbase = reinterpret_cast<const unsigned long long *>(ws + w.off_gtot);
-    hipLaunchKernelGGL(mc_verts_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, (double)level, recs, nact, vrt,
+    // packed active cells, grid-stride (the count lives in the workspace header: no second read-back)
+    const int egrid = std::min(w.nblocks, num_cus() * 16);
+    hipLaunchKernelGGL(mc_verts_kernel, dim3(egrid), dim3(MC_BLOCK), 0, st, vol, g, (double)level, recs, ai, hdr, vrt,
                        gbase, emap, verts, vert_div, vert_mul, vert_add, ref);
     SC_LAUNCH_CHECK();
     if (flags & SCULPT_MC_FACES_I64)
-        hipLaunchKernelGGL(mc_faces_kernel<long long>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, g, recs, nact, tri, vrt,
+        hipLaunchKernelGGL(mc_faces_kernel<long long>, dim3(egrid), dim3(MC_BLOCK), 0, st, g, recs, ai, hdr, tri, vrt,
                            gbase, emap, reinterpret_cast<long long *>(faces), ref);
     else
-        hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, g, recs, nact, tri, vrt, gbase,
+        hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(egrid), dim3(MC_BLOCK), 0, st, g, recs, ai, hdr, tri, vrt, gbase,
                            emap, reinterpret_cast<int *>(faces), ref);
     SC_LAUNCH_CHECK();
     if (top_plane_map) {
