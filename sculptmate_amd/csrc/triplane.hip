@@ -364,33 +364,54 @@ __global__ __launch_bounds__(512) void query_points_kernel(
 // Separable dense grid, step 1: per lattice pair (a -> W axis, b -> H axis) and plane k,
 //   F_k[a][b][j] = sum_c W0[n(j)][k*C + c] * bilinear(P_k; a, b)[c]   (+ b0 on plane 0)
 // stored in accumulator order j = h*32 + t*16 + r  <->  neuron nrow(t,r,h).
-// One 64-thread wave per pair; 4 pairs per 256-thread block.
 //   table 0 (FA): a = ix (local), b = iy     rows nx x R
 //   table 1 (FB): a = ix (local), b = iz     rows nx x R
 //   table 2 (FC): a = iy,         b = iz     rows R  x R
 // ---------------------------------------------------------------------------------------------
+// A wave takes 64 consecutive a (the coordinate along W, contiguous in memory) at one b: the four bilinear taps of a
+// channel are then coalesced loads from the channel-first planes (64 lanes cover ~17 neighbouring pixels of one row) instead
+// of one cache line per lane.  A lane keeps its pair's 64 pre-activations in registers and runs, channel by channel, the
+// same fmaf chain (c ascending) one thread per (pair, neuron) would run; the weights of the workgroup's table sit in LDS
+// (wl[c][j], j in accumulator order) and are read as broadcasts.  Four waves = four consecutive b.
 template <int C>
 __global__ __launch_bounds__(256) void plane_features_kernel(
     const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
     const float *__restrict__ axis, int R, int x_begin, int nx, float radius, float span,
     float *__restrict__ FA, float *__restrict__ FB, float *__restrict__ FC) {
-    __shared__ float smp[4][C];
+    __shared__ __attribute__((aligned(16))) float wl[C][64];
+    __shared__ __attribute__((aligned(16))) float bl[64];
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int K0 = hd.K0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long nA = (long)nx * R, nC = (long)R * R;
-    const long total = 2 * nA + nC;
-    long pair = (long)blockIdx.x * 4 + w;
-    const bool live = pair < total;
-    if (!live) pair = total - 1;
-    int k;
-    long rem;
+    // workgroup -> (table k, chunk of 64 a, group of 4 b)
+    const int bgroups = (R + 3) / 4;
+    const long perA = (long)((nx + 63) / 64) * bgroups, perC = (long)((R + 63) / 64) * bgroups;
+    int k, na;
+    long rest;
     float *dst;
-    if (pair < nA) { k = 0; rem = pair; dst = FA; }
-    else if (pair < 2 * nA) { k = 1; rem = pair - nA; dst = FB; }
-    else { k = 2; rem = pair - 2 * nA; dst = FC; }
-    const int a = (int)(rem / R), b = (int)(rem % R);
-    const int ia = (k == 2) ? a : a + x_begin;
+    {
+        const long blk = blockIdx.x;
+        if (blk < perA) { k = 0; rest = blk; na = nx; dst = FA; }
+        else if (blk < 2 * perA) { k = 1; rest = blk - perA; na = nx; dst = FB; }
+        else { k = 2; rest = blk - 2 * perA; na = R; dst = FC; }
+    }
+    (void)perC;
+    const int a = (int)(rest / bgroups) * 64 + lane;
+    const int b = (int)(rest % bgroups) * 4 + w;
+    for (int i = threadIdx.x; i < C * 64; i += 256) {
+        const int c = i >> 6, jj = i & 63;
+        const int hh = jj >> 5, tt = (jj >> 4) & 1, rr = jj & 15;
+        wl[c][jj] = blob[hd.off_w0raw + (long)nrow(tt, rr, hh) * K0 + k * C + c];
+    }
+    if (threadIdx.x < 64) {
+        const int jj = threadIdx.x, hh = jj >> 5, tt = (jj >> 4) & 1, rr = jj & 15;
+        bl[jj] = (k == 0) ? blob[hd.off_b0raw + nrow(tt, rr, hh)] : 0.f;
+    }
+    __syncthreads();
+    if (b >= R) return;                                           // wave-uniform
+    const bool live = a < na;
+    const int ac = live ? a : na - 1;
+    const int ia = (k == 2) ? ac : ac + x_begin;
     const float gx = to_unit(axis[ia], radius, span), gy = to_unit(axis[b], radius, span);
     Tap1 tx = tap_of(gx, W), ty = tap_of(gy, H);
     const float wx = tx.w1, ex = 1.0f - wx, wy = ty.w1, ey = 1.0f - wy;
@@ -401,23 +422,32 @@ __global__ __launch_bounds__(256) void plane_features_kernel(
     const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
     const float wnw = (vy0 && vx0) ? ey * ex : 0.f, wne = (vy0 && vx1) ? ey * wx : 0.f;
     const float wsw = (vy1 && vx0) ? wy * ex : 0.f, wse = (vy1 && vx1) ? wy * wx : 0.f;
-    if (lane < C) {
-        const float *P = planes + ((long)k * C + lane) * H * W;
-        float v = P[cy0 * W + cx0] * wnw;
-        v += P[cy0 * W + cx1] * wne;
-        v += P[cy1 * W + cx0] * wsw;
-        v += P[cy1 * W + cx1] * wse;
-        smp[w][lane] = v;
+    const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+    float s[64];
+#pragma unroll
+    for (int jj = 0; jj < 64; ++jj) s[jj] = bl[jj];
+    const float *P = planes + (long)k * C * H * W;
+#pragma unroll 2
+    for (int c = 0; c < C; ++c, P += (long)H * W) {
+        float v = P[o00] * wnw;
+        v += P[o01] * wne;
+        v += P[o10] * wsw;
+        v += P[o11] * wse;
+        const f32x4 *wr = reinterpret_cast<const f32x4 *>(&wl[c][0]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 ww = wr[q];
+            s[4 * q] = fmaf(ww[0], v, s[4 * q]);
+            s[4 * q + 1] = fmaf(ww[1], v, s[4 * q + 1]);
+            s[4 * q + 2] = fmaf(ww[2], v, s[4 * q + 2]);
+            s[4 * q + 3] = fmaf(ww[3], v, s[4 * q + 3]);
+        }
     }
-    __syncthreads();
-    // lane j -> (h,t,r) -> neuron
-    const int hh = lane >> 5, tt = (lane >> 4) & 1, rr = lane & 15;
-    const int neuron = nrow(tt, rr, hh);
-    const float *w0 = blob + hd.off_w0raw + (long)neuron * K0 + k * C;
-    float s = (k == 0) ? blob[hd.off_b0raw + neuron] : 0.f;
-#pragma unroll 8
-    for (int c = 0; c < C; ++c) s = fmaf(w0[c], smp[w][c], s);
-    if (live) dst[rem * 64 + lane] = s;
+    if (live) {
+        f32x4 *o = reinterpret_cast<f32x4 *>(dst + ((long)a * R + b) * 64);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[q] = f32x4{s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -799,7 +829,10 @@ int sculpt_plane_features(const float *planes, int C, int H, int W, const void *
     float *FC = FB + (size_t)nx * R * 64;
     const float span = (float)((double)radius - (double)(-radius));
     const long pairs = 2L * nx * R + (long)R * R;
-    hipLaunchKernelGGL(plane_features_kernel<40>, dim3(cdiv(pairs, 4)), dim3(256), 0, st, planes, H, W,
+    (void)pairs;
+    const long pf_bg = (R + 3) / 4;
+    const long pf_blocks = 2 * (long)((nx + 63) / 64) * pf_bg + (long)((R + 63) / 64) * pf_bg;
+    hipLaunchKernelGGL(plane_features_kernel<40>, dim3((unsigned)pf_blocks), dim3(256), 0, st, planes, H, W,
                        reinterpret_cast<const float *>(mlp_packed), axis_coords, R, x_begin, nx, radius,
                        span, FA, FB, FC);
     SC_LAUNCH_CHECK();
