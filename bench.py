@@ -51,8 +51,13 @@ def calibrate(model, sd, img_dev, inside=0.015):
     ctx, _ = model.image_tokens(img_dev)
     _, outb = model.backbone_tokens(ctx)
     planes = model.scene_code(outb)
-    probe = ops.density_grid(planes, model.decoder, 64)
-    pre = torch.log(probe).cpu().numpy().astype(np.float64) + 1.0  # density before the -1 bias
+    # 64^3 lattice probe through the point-query kernel (query_triplane's path): keeps the rocprof row of the dense-grid kernel
+    # to full-size launches only
+    g = ops.grid_axis_coords(64, model.renderer.cfg.radius).to(planes.device)
+    pts = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    probe = ops.triplane_query(planes, model.decoder, pts, radius=model.renderer.cfg.radius,
+                               density_bias=model.renderer.cfg.density_bias, want=("density",))["density"].reshape(-1)
+    pre = probe.cpu().numpy().astype(np.float64)                    # density before the -1 bias
     shift = synth.calibrate_density_bias(pre, inside_fraction=inside, threshold=THRESHOLD)
     k = "decoder.layers.18.bias"
     b = sd[k].copy()
@@ -179,6 +184,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optional-modes", action="store_true",
+                    help="skip the informational split-operand rates (profiling runs: keeps the kernel rows to the default path)")
     ap.add_argument("--decoder-precision", choices=("fp32", "fp16x3", "bf16x3"), default="fp32",
                     help="fp32 (default, exact-fp32 MFMA density MLP) or an optional split-operand 16-bit MFMA mode")
     args = ap.parse_args()
@@ -264,7 +271,7 @@ def main():
         }
         with torch.no_grad():
             out["stages_ms"] = stage_split(model, imgs[0])  # outside the timed region
-            if args.gpus == 1 and DECODER_PRECISION == "fp32":
+            if args.gpus == 1 and DECODER_PRECISION == "fp32" and not args.no_optional_modes:
                 out["optional_modes"] = optional_mode_rates(model, imgs, args.steps)  # informational, not `value`
         if args.gpus == 1 and not args.no_cpu_baseline:
             with torch.no_grad():
