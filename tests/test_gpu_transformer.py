@@ -431,3 +431,33 @@ def test_encode_image_two_stream_overlap_is_bit_identical(cuda):
     # forward() goes through the same path
     codes = m([synth.composite_rgb(synth.image_rgba(seed=40, size=S))], device=cuda)
     assert torch.equal(codes[0], m.scene_code(want[0][1]))
+
+
+def test_image_file_to_glb_chain(cuda, tmp_path):
+    """The add-on's whole chain headless: image file -> preprocess_image (U^2-Net cut-out on the GPU, the reference's framing)
+    -> TSR.run -> Mesh.export('.glb') -> read back."""
+    from PIL import Image
+
+    from sculptmate_amd import meshio, ops, preprocessing
+    from sculptmate_amd.rembg import session
+
+    path = str(tmp_path / "photo.png")
+    Image.fromarray(synth.image_rgba(seed=70, size=384)[..., :3], mode="RGB").save(path)
+    sess = session.U2netSession(device=cuda, state_dict=synth.u2net_state(0))
+    framed = preprocessing.preprocess_image(path, ratio=0.75, session=sess)
+    assert framed is not None and framed.size == (1024, 1024) and framed.mode == "RGB"
+    m, sd = _small_model(cuda, seed=71)
+    codes = m([framed], device=cuda)                       # PIL 1024^2 in, resized on the GPU like the add-on's input
+    dens = ops.density_grid(codes[0].contiguous(), m.decoder, 40)
+    mesh = m.run([framed], mc_resolution=40, threshold=float(dens.median()), enable_texture=True)[0]
+    out = str(tmp_path / "mesh.glb")
+    mesh.export(out)
+    back = meshio.read_glb(out)
+    assert np.array_equal(back["vertices"], mesh.vertices) and np.array_equal(back["faces"], mesh.faces)
+    assert np.array_equal(back["vertex_colors"], mesh.vertex_colors)
+    mesh.export(str(tmp_path / "mesh.obj"))
+    mesh.export(str(tmp_path / "mesh.ply"))
+    v2, f2, c2 = meshio.read_ply(str(tmp_path / "mesh.ply"))
+    assert np.array_equal(v2, mesh.vertices) and np.array_equal(f2, mesh.faces)
+    with pytest.raises(ValueError):
+        mesh.export(str(tmp_path / "mesh.stl"))
