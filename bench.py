@@ -195,8 +195,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d needs %d ranks (WORLD_SIZE=%d): launch with python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus, world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

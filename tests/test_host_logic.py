@@ -222,3 +222,15 @@ def test_ply_round_trip(tmp_path):
     meshio.write_ply(str(tmp_path / "n.ply"), v, f)
     v3, f3, c3 = meshio.read_ply(str(tmp_path / "n.ply"))
     assert np.array_equal(v3, v) and np.array_equal(f3, f) and c3 is None
+
+
+def test_bench_refuses_rank_count_mismatch():
+    """bench.py --gpus N is launched by torch.distributed.run with N ranks; a lone process must not report an N-GPU number."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "needs 2 ranks" in (p.stderr + p.stdout)
+    assert p.stdout.strip() == ""            # no JSON line
