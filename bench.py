@@ -4,8 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one image -> mesh: TSR.forward (ViT-B/16 + 16-block triplane transformer, bf16 MFMA)
-+ extract_mesh at 256^3 (fused triplane sample + NeRF-MLP on fp32 MFMA, Lewiner marching cubes).
+A "step" = one image -> mesh through the reference's own entry points (TripoSR/generate.py:32-43 ->
+tsr/system.py:82-115,171-200): TSR.forward (ViT-B/16 + 16-block triplane transformer, bf16 MFMA)
++ TSR.extract_meshes at 256^3 (fused triplane sample + NeRF-MLP on fp32 MFMA, Lewiner marching cubes).
+`value` times those two calls with the image resident in HBM and the mesh left in HBM (the contract's
+definition); the extra key "boundary" times TSR.run_async(host image) -> host mesh (H2D of the image,
+pinned D2H of vertices / faces on a copy stream under the next image's kernels).
 Workload = BASELINE.json configs[1] "TripoSR single image, mc_resolution=256, bf16 on 1xMI355X";
 with N GPUs each rank runs the same per-GPU workload on its own images (configs[2]: one image per
 GPU, no collectives on the data path) -> "scaling": "weak".
@@ -71,16 +75,38 @@ DECODER_PRECISION = "fp32"  # --decoder-precision bf16x3 selects the optional sp
 
 
 def one_step(model, img_dev, events=None):
-    _, outb = model.encode_image(img_dev)   # ViT + backbone (its image-independent head on a second stream under the ViT)
-    planes = model.scene_code(outb)
-    from sculptmate_amd import ops
+    """TSR.forward + TSR.extract_meshes (the two calls TripoGenerator.generate_mesh makes, generate.py:36-40), image
+    resident in HBM, mesh left in HBM."""
+    codes = model([img_dev], device=model.device)
+    mesh = model.extract_meshes(codes, False, MC_RES, THRESHOLD, density_events=events)[0]
+    return mesh.vertices, mesh.faces
 
-    r = model.renderer.cfg.radius
-    vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
-                           out_add=-THRESHOLD, events=events, precision=DECODER_PRECISION)
-    v, f = ops.marching_cubes(vol.view(MC_RES, MC_RES, MC_RES), 0.0, reference_order=True, vert_div=MC_RES - 1.0,
-                              vert_mul=r - (-r), vert_add=-r)
-    return v, f
+
+def boundary_rate(model, imgs_host, steps):
+    """The same work through the host boundary: TSR.run_async(host fp32 HWC image) -> PendingMesh -> host arrays.
+    Steady state: the pinned device->host copy of mesh i runs on a copy stream under the kernels of image i+1."""
+    prev = model.run_async(imgs_host[0], MC_RES, THRESHOLD)
+    prev.result()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbytes = 0
+    for i in range(steps):
+        cur = model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD)
+        m = prev.result()
+        nbytes = m.vertices.nbytes + m.faces.nbytes
+        prev = cur
+    m = prev.result()
+    dt = time.perf_counter() - t0
+    # latency of ONE image with nothing to overlap: host image in -> host mesh out
+    lat = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD).result()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    return {"entry": "TSR.run_async(host fp32 HWC 512x512 image) -> host (pinned) vertices + int64 faces",
+            "meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "latency_ms_single_image": float(np.median(lat)),
+            "h2d_bytes_per_image": int(imgs_host[0].nbytes), "d2h_bytes_per_mesh": int(nbytes)}
 
 
 def stage_split(model, img_dev, n=5):
@@ -125,12 +151,11 @@ def density_deviation(model, img_dev, mode, R=96):
 
 def optional_mode_rates(model, imgs, steps):
     """Whole-step rate with the optional split-operand density modes, measured after the timed region."""
-    global DECODER_PRECISION
     res = {}
-    keep = DECODER_PRECISION
+    keep = model.decoder_precision
     try:
         for mode in ("fp16x3", "bf16x3"):
-            DECODER_PRECISION = mode
+            model.decoder_precision = mode
             one_step(model, imgs[0])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -141,41 +166,153 @@ def optional_mode_rates(model, imgs, steps):
             res[mode] = {"meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
                          "density_max_rel_dev_vs_fp32_kernel": density_deviation(model, imgs[0], mode)}
     finally:
-        DECODER_PRECISION = keep
+        model.decoder_precision = keep
     return res
 
 
-def cpu_baseline(sd, img_np, planes_np):
-    """The oracle (CPU restatement of the reference) timed on this box's host cores on a bounded
-    sample of the same workload: full TSR.forward for one image (torch fp32, all cores), the dense
-    query on 8 of the 256 lattice planes (1/32 of the grid, C oracle with OpenMP), and marching
-    cubes on the full 256^3 volume (C oracle, single thread like scikit-image)."""
+def _median_time(fn, warm=1, n=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def cpu_baseline(sd, img_np):
+    """the oracle (CPU restatement of the reference, kind "port") on this box's host cores,
+    configured like BASELINE config 1 -- ONE 512x512 image, mc_resolution=128, fp32 -- every stage measured whole
+    (1 warm-up + 3 timed runs, median), all cores.  The single-thread figure and the 256^3 figure are bounded samples,
+    labelled as extrapolations."""
     from oracle import capi, tsr_ref
     from sculptmate_amd import synth
     from sculptmate_amd.tsr.spec import DEFAULT_CFG
 
-    cores = min(os.cpu_count() or 1, 32)  # more threads than this only oversubscribes torch's CPU GEMMs
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 32)  # more threads than this only oversubscribes torch's CPU GEMMs
+    R = 128
+    Ws, bs = synth.decoder_lists(sd)
     torch.set_num_threads(cores)
     capi.set_threads(cores)
-    t0 = time.time()
-    tsr_ref.tsr_forward(sd, img_np, DEFAULT_CFG, pos_mode="scale_factor")
-    t_fwd = time.time() - t0
-    Ws, bs = synth.decoder_lists(sd)
-    R = MC_RES
-    planes_sub = 8
-    t0 = time.time()
-    capi.density_grid(planes_np, Ws, bs, R, begin=0, end=planes_sub * R * R)
-    t_q = (time.time() - t0) * (R / planes_sub)
-    g = np.linspace(-0.87, 0.87, R, dtype=np.float32)
-    x, y, z = np.meshgrid(g, g, g, indexing="ij")
-    vol = (25.0 * np.exp(9.0 * (0.5 - np.sqrt(x * x + 1.3 * y * y + 0.8 * z * z))) - 25.0).astype(np.float32)
-    t0 = time.time()
-    capi.marching_cubes(vol, 0.0)
-    t_mc = time.time() - t0
+    ref = {}
+
+    def fwd():
+        ref["code"] = tsr_ref.tsr_forward(sd, img_np, DEFAULT_CFG, pos_mode="scale_factor")
+
+    t_fwd = _median_time(fwd)
+    planes = ref["code"].numpy()
+    dens = {}
+
+    def query():
+        dens["d"] = capi.density_grid(planes, Ws, bs, R)
+
+    t_q = _median_time(query)
+    thr = np.float32(np.quantile(dens["d"], 0.985))
+    level = -(dens["d"] - thr)
+    t_mc = _median_time(lambda: capi.reference_isosurface(level, R))
     total = t_fwd + t_q + t_mc
+    # single thread: bounded sample (one of 12 ViT layers incl. patch embedding, one of 16 backbone blocks, 1/16 of the
+    # 128^3 lattice), extrapolated by the layer / lattice counts
+    torch.set_num_threads(1)
+    capi.set_threads(1)
+    cfg1 = dict(DEFAULT_CFG, image_tokenizer=dict(DEFAULT_CFG["image_tokenizer"], num_hidden_layers=1))
+    ctx = {}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ctx["c"] = tsr_ref.vit_forward(sd, img_np, cfg1, "scale_factor")
+    t_vit1 = time.perf_counter() - t0
+    h = torch.zeros(3 * 32 * 32, 1024)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        tsr_ref.block_forward(sd, "backbone.transformer_blocks.0.", h, ctx["c"], 16)
+    t_blk1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    capi.density_grid(planes, Ws, bs, R, begin=0, end=R ** 3 // 16)
+    t_q1 = (time.perf_counter() - t0) * 16
+    total_1t = t_vit1 * 12 + t_blk1 * 16 + t_q1 + t_mc
+    torch.set_num_threads(cores)
+    capi.set_threads(cores)
     return {"value": 1.0 / total, "unit": "meshes/s", "cores": cores, "kind": "port",
-            "sample": "1 image: full TSR.forward %.1fs + dense query on 8/256 lattice planes scaled x32 = %.1fs "
-                      "+ marching cubes 256^3 %.2fs" % (t_fwd, t_q, t_mc)}
+            "sample": "BASELINE config 1 exactly: one 512x512 image, mc_resolution=128, fp32, all stages whole, 1 warm-up + 3 timed "
+                      "(median): TSR.forward %.2fs + query_triplane 128^3 %.2fs + marching cubes %.3fs (single thread, like "
+                      "scikit-image) = %.2fs on %d threads" % (t_fwd, t_q, t_mc, total, cores),
+            "lscpu_logical_cpus": ncpu, "ms_per_image": total * 1e3,
+            "stages_s": {"forward": t_fwd, "query_128": t_q, "marching_cubes_128": t_mc},
+            "single_thread": {"value": 1.0 / total_1t, "unit": "meshes/s", "cores": 1, "extrapolated": True,
+                              "sample": "1 of 12 ViT layers %.2fs x12 + 1 of 16 backbone blocks %.2fs x16 + 1/16 of the 128^3 query "
+                                        "x16 = %.2fs + marching cubes %.3fs" % (t_vit1, t_blk1, t_q1, t_mc)},
+            "at_256": {"value": 1.0 / (t_fwd + 8 * t_q + 8 * t_mc), "unit": "meshes/s", "cores": cores, "extrapolated": True,
+                       "sample": "the 128^3 query and marching-cubes times x8 (lattice points / cells), forward unchanged"}}
+
+
+def slab512_extra(model, img_dev, world=8, iters=2):
+    """BASELINE config 5 on ONE GPU: the 512^3 grid of the bench's own scene code cut into `world` slabs evaluated one after the
+    other here and assembled (what the ranks + the RCCL gather produce; tests/test_gpu_slab.py checks bit equality)."""
+    from sculptmate_amd import slab
+
+    codes = model([img_dev], device=model.device)
+    planes = codes[0].contiguous()
+    cfg = model.renderer.cfg
+    kw = dict(radius=cfg.radius, density_bias=cfg.density_bias, threshold=THRESHOLD)
+    res = {}
+    for w in (1, world):
+        v, f = slab.extract_mesh_slabs_local(planes, model.decoder, 512, w, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            v, f = slab.extract_mesh_slabs_local(planes, model.decoder, 512, w, **kw)
+        torch.cuda.synchronize()
+        res["slabs_%d_ms" % w] = (time.perf_counter() - t0) / iters * 1e3
+        res["vertices"], res["faces"] = int(v.shape[0]), int(f.shape[0])
+        del v, f
+    res["what"] = ("extract_mesh at 512^3 (density grid + marching cubes) on 1 GPU: single pass vs %d slabs one after the other + "
+                   "assemble (the per-rank work and the assembly of config 5; the RCCL gather itself needs %d GPUs)" % (world, world))
+    torch.cuda.empty_cache()
+    return res
+
+
+def sf3d_extra(device, n=5):
+    """BASELINE config 4: StableFast-3D single image, full-size networks (random init, 834.8 M parameters), stage times by HIP
+    events (median of n).  The shipped 160_tets.npz is absent: a Kuhn 6-tets-per-cube grid of the same resolution stands in
+    (4.17 M vertices / 24.6 M tets -- denser than the shipped grid, so the mesh stage is an upper bound).  Estimators skipped."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.sf3d.spec import DEFAULT_CFG as SF_CFG
+    from sculptmate_amd.sf3d.system import SF3D
+
+    cfg = dict(SF_CFG)
+    sd = synth.sf3d_state(0, cfg)
+    m = SF3D(cfg)
+    m.load_state_dict(sd)
+    m.to(device)
+    img = torch.from_numpy(synth.composite_rgb(synth.image_rgba(0, 512))).to(device)
+    codes = m.scene_code(img)
+    q = m.query_triplane(m._grid_world, codes)
+    pre = m.decoder(q, include=["density"])["density"].reshape(-1).log().cpu().numpy()
+    shift = np.log(cfg["isosurface_threshold"]) - np.quantile(pre.astype(np.float64), 0.9)
+    sd["decoder.heads.density.4.bias"] = (sd["decoder.heads.density.4.bias"] + np.float32(shift)).astype(np.float32)
+    m.load_state_dict(sd)
+    rows, mesh = [], None
+    for it in range(n + 2):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        e[0].record()
+        tok = m.image_tokens(img); e[1].record()
+        direct = m.backbone_tokens(tok); e[2].record()
+        planes = m.post_process(direct); e[3].record()
+        mesh = m.triplane_to_meshes(planes[None])[0]; e[4].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            rows.append([e[i].elapsed_time(e[i + 1]) for i in range(4)])
+    t = np.median(np.array(rows), 0)
+    out = {"stages_ms": dict(zip(("dinov2", "backbone", "upsampler", "query_mtet"), [round(float(x), 3) for x in t])),
+           "ms_per_image": float(t.sum()), "meshes_per_s": 1e3 / float(t.sum()),
+           "mesh": {"vertices": int(mesh.v_pos.shape[0]), "faces": int(mesh.t_pos_idx.shape[0])},
+           "what": "SF3D image -> mesh (DINOv2-L + two-stream backbone + pixel-shuffle upsampler + density / deformation query + "
+                   "marching tetrahedra), bf16 networks, Kuhn tet grid (160_tets.npz absent), estimators / unwrap / bake not included"}
+    del m, sd
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -186,6 +323,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional-modes", action="store_true",
                     help="skip the informational split-operand rates (profiling runs: keeps the kernel rows to the default path)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys measured after the timed region (boundary, slab512, sf3d)")
     ap.add_argument("--decoder-precision", choices=("fp32", "fp16x3", "bf16x3"), default="fp32",
                     help="fp32 (default, exact-fp32 MFMA density MLP) or an optional split-operand 16-bit MFMA mode")
     args = ap.parse_args()
@@ -210,6 +349,7 @@ def main():
     dist = parallel.init("nccl", device) if (world > 1 or os.environ.get("SCULPT_FORCE_DIST")) else None
 
     model, sd = build_model(device, seed=0)  # every rank holds a full replica (no weight sharding)
+    model.decoder_precision = DECODER_PRECISION
     imgs_np = [synth.composite_rgb(synth.image_rgba(seed=100 + rank * 8 + i)) for i in range(4)]
     imgs = [torch.from_numpy(a).to(device).contiguous() for a in imgs_np]
     with torch.no_grad():
@@ -238,11 +378,12 @@ def main():
         achieved = FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12
         x3 = DECODER_PRECISION != "fp32"
         peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_density_grid.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                traffic, traffic_src = j.get("hbm_bytes_per_launch"), "profiles/pmc_density_grid.json (%s)" % j.get("source", "rocprofv3 --pmc passes")
             except Exception:
                 traffic = None
         out = {
@@ -261,6 +402,8 @@ def main():
                      "f32 (density MLP + marching cubes) / bf16 (transformer)",
             "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
             "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
+                       "entry_points_timed": "TSR.forward([image resident in HBM]) + TSR.extract_meshes(codes, resolution=256): mesh "
+                                             "left in HBM; the host-boundary rate is the extra key 'boundary'",
                        "mc_resolution": MC_RES, "threshold": THRESHOLD, "images_per_gpu_per_step": 1,
                        "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
             "roofline": {"kernel": ("density_grid_x3_kernel (fused triplane-sum + NeRF-MLP, %s MFMA: 3 MFMA flops per "
@@ -268,18 +411,33 @@ def main():
                                    "density_grid_kernel (fused triplane-sum + NeRF-MLP, fp32 MFMA)",
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None if x3 else traffic,
+                         "traffic_source": None if x3 else traffic_src,
                          "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3},
+            "latency_ms_per_image": elapsed / args.steps * 1e3,  # steps run back to back, one image in flight: step time = latency
         }
         with torch.no_grad():
-            out["stages_ms"] = stage_split(model, imgs[0])  # outside the timed region
-            if args.gpus == 1 and DECODER_PRECISION == "fp32" and not args.no_optional_modes:
+            st = stage_split(model, imgs[0])  # outside the timed region
+            out["stages_ms"] = st
+            out["transformer_ms"] = round(st["image_tokenizer"] + st["backbone"], 3)
+            # bf16 MFMA fraction of the transformer stack: 2.96 TFLOP / image over the two stage times
+            out["transformer_roofline"] = {"bound": "mfma", "achieved": 2.96 / (out["transformer_ms"] * 1e-3), "peak": PEAK_BF16_MFMA_TFLOPS,
+                                           "unit": "TFLOP/s", "frac": 2.96 / (out["transformer_ms"] * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
+            single = args.gpus == 1 and DECODER_PRECISION == "fp32"
+            if single and not args.no_extras:
+                out["boundary"] = boundary_rate(model, imgs_np, args.steps)
+            if single and not args.no_optional_modes:
                 out["optional_modes"] = optional_mode_rates(model, imgs, args.steps)  # informational, not `value`
+            if single and not args.no_extras:
+                for key, fn in (("slab512", lambda: slab512_extra(model, imgs[0])), ("sf3d", lambda: sf3d_extra(device))):
+                    t0 = time.perf_counter()
+                    try:
+                        out[key] = fn()
+                        out[key]["bench_wall_s"] = round(time.perf_counter() - t0, 1)
+                    except Exception as e:  # an extra must never take the headline line down
+                        out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.empty_cache()
         if args.gpus == 1 and not args.no_cpu_baseline:
-            with torch.no_grad():
-                ctx, _ = model.image_tokens(imgs[0])
-                _, outb = model.backbone_tokens(ctx)
-                planes_np = model.scene_code(outb).cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(sd, imgs_np[0], planes_np)
+            out["cpu_baseline"] = cpu_baseline(sd, imgs_np[0])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

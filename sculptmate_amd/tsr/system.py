@@ -55,6 +55,22 @@ class Mesh:
         writer(str(path), self.vertices, self.faces, vertex_colors=self.vertex_colors)
 
 
+class PendingMesh:
+    """A mesh whose device -> pinned-host copy is in flight (TSR.run_async)."""
+
+    def __init__(self, host_tensors, done_event):
+        self._host = host_tensors
+        self._done = done_event
+
+    def done(self) -> bool:
+        return self._done.query()
+
+    def result(self) -> Mesh:
+        self._done.synchronize()
+        v, f, c = self._host
+        return Mesh(v.numpy(), f.numpy(), None if c is None else c.numpy())  # views of the pinned buffers (kept alive by NumPy)
+
+
 class MarchingCubeHelper:
     """tsr/models/isosurface.py:17-54 on the GPU (sculpt_mc_*)."""
 
@@ -434,8 +450,10 @@ class TSR(KernelEngine):
         self.isosurface_helper = MarchingCubeHelper(resolution)
 
     def extract_meshes(self, scene_codes, enable_texture=False, resolution: int = 256, threshold: float = 25.0,
-                       x_range=None) -> List[Mesh]:
-        """The arithmetic of system.py:171-200 without the Blender sink: returns device tensors."""
+                       x_range=None, density_events=None) -> List[Mesh]:
+        """The arithmetic of system.py:171-200 without the Blender sink: returns device tensors.
+        density_events: optional (start, stop) torch events recorded around the dense-grid launch (bench.py's live
+        per-launch timing of the dominant kernel, on the stream it is launched on)."""
         self.set_marching_cubes_resolution(resolution)
         r = self.renderer.cfg.radius
         R = resolution
@@ -444,7 +462,7 @@ class TSR(KernelEngine):
             planes = scene_code.contiguous()
             # density_act - threshold == -(-(density_act - threshold))  (system.py:184, isosurface.py:45)
             vol = ops.density_grid(planes, self.decoder, R, radius=r, density_bias=self.renderer.cfg.density_bias,
-                                   out_add=-threshold, precision=self.decoder_precision)
+                                   out_add=-threshold, precision=self.decoder_precision, events=density_events)
             try:
                 v_pos, t_pos_idx = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
                                                       vert_mul=r - (-r), vert_add=-r)
@@ -496,13 +514,40 @@ class TSR(KernelEngine):
                      None if m.vertex_colors is None else m.vertex_colors.cpu().numpy(), mesh_name)
         return meshes
 
-    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False) -> List[Mesh]:
-        """Headless entry point: images -> list of Mesh with host (NumPy) arrays."""
+    def run_async(self, image, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
+        """One host image -> PendingMesh.  The image goes host -> HBM, the forward and the mesh extraction are queued on
+        the current stream, and the mesh (the reference's `.cpu().numpy()` at system.py:200) is copied device -> pinned
+        host memory on a separate copy stream, so the copy of mesh i runs under the kernels of image i + 1.
+        PendingMesh.result() waits for that copy only."""
         with torch.no_grad():
-            codes = self.forward(images, self.device)
-            meshes = self.extract_meshes(codes, enable_texture, mc_resolution, threshold)
-        return [Mesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(),
-                     None if m.vertex_colors is None else m.vertex_colors.cpu().numpy()) for m in meshes]
+            codes = self.forward([image], self.device)
+            m = self.extract_meshes(codes, enable_texture, mc_resolution, threshold)[0]
+        main = torch.cuda.current_stream(self.device)
+        copy = getattr(self, "_copy_stream", None)
+        if copy is None:
+            copy = self._copy_stream = torch.cuda.Stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        host = []
+        with torch.cuda.stream(copy):
+            copy.wait_event(ready)
+            for t in (m.vertices, m.faces, m.vertex_colors):
+                if t is None:
+                    host.append(None)
+                    continue
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)  # torch's caching host allocator recycles these
+                h.copy_(t, non_blocking=True)
+                t.record_stream(copy)  # the device block must not be reused before the copy has read it
+                host.append(h)
+            done = torch.cuda.Event()
+            done.record(copy)
+        return PendingMesh(host, done)
+
+    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False) -> List[Mesh]:
+        """Headless entry point: images -> list of Mesh with host (NumPy) arrays.  With several images the device -> host
+        copy of mesh i overlaps the kernels of image i + 1 (run_async)."""
+        pending = [self.run_async(im, mc_resolution, threshold, enable_texture) for im in _as_image_list(images)]
+        return [p.result() for p in pending]
 
 
 def _as_image_list(image):

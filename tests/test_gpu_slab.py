@@ -66,3 +66,31 @@ def test_empty_slabs_and_errors(cuda):
         slab._check_range(1.0, 2.0, 0)
     with pytest.raises(RuntimeError):
         slab._check_range(-1.0, 0.0, 0)
+
+
+def test_config5_at_512_cubed_slabs_equal_single_pass_and_oracle(cuda):
+    """BASELINE config 5 at its real size: one scene code at 512^3, 8 slabs (the per-rank work of the 8-GPU split,
+    evaluated one after the other here) assembled == the single 512^3 pass, bit for bit; one slab's marching cubes is
+    also checked against the C oracle (pinned to scikit-image).  Exercises the int32 lattice-edge -> vertex-id map at
+    3 * 512^3 = 402 653 184 entries."""
+    from sculptmate_amd import ops, slab
+
+    R, world = 512, 8
+    Ws, bs = synth.decoder_lists(synth.decoder_state(seed=61))
+    mlp = ops.PackedMLP(Ws, bs, cuda)
+    planes = torch.from_numpy(synth.smooth_triplane(seed=62, scale=3.0)).to(cuda)
+    thr = float(ops.density_grid(planes, mlp, 64).quantile(0.97))
+    fv, ff = slab.extract_mesh_slabs_local(planes, mlp, R, 1, threshold=thr)
+    assert fv.shape[0] > 100_000 and ff.shape[0] > 200_000
+    assert int(ff.max()) == fv.shape[0] - 1 and int(ff.min()) == 0
+    v, f = slab.extract_mesh_slabs_local(planes, mlp, R, world, threshold=thr)
+    assert torch.equal(f, ff) and torch.equal(v, fv)
+    del v, f
+    # rank 3's slab as a stand-alone volume against the oracle (vertices in index units, skimage's face order)
+    c0, c1 = slab.slab_ranges(R, world)[3]
+    vol = ops.density_grid(planes, mlp, R, x_begin=c0, x_end=c1 + 1, out_add=-thr).view(c1 - c0 + 1, R, R)
+    sv, sf = ops.marching_cubes(vol, 0.0, reference_order=True, vert_div=1.0)
+    rv, rf = capi.marching_cubes(vol.cpu().numpy(), 0.0)
+    assert np.array_equal(sf.cpu().numpy(), rf[:, [1, 0, 2]].astype(np.int64))
+    assert np.array_equal(sv.cpu().numpy().view(np.uint32), rv.view(np.uint32))
+    torch.cuda.empty_cache()

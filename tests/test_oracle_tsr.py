@@ -59,6 +59,25 @@ def test_pos_embedding_host_interpolation_matches_torch_bicubic():
             np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
 
 
+def test_pos_embedding_438_form_matches_reference_vendored_code():
+    """The transformers-4.38 `scale_factor` (+0.1) form -- what the reference's pinned transformers runs for TripoSR's ViT
+    and what StableFast vendors at sf3d/models/tokenizers/dinov2.py:89-133 -- pinned by outputs of that vendored code
+    (tests/golden/make_posemb_goldens.py): the oracle and the product's host interpolation both reproduce it."""
+    from sculptmate_amd.tsr.posemb import interpolate_pos_embedding
+
+    g = np.load(os.path.join(GOLDEN, "posemb_438.npz"))
+    for name in ("tsr", "sf3d"):
+        table, n, want = g[name + ".table"], int(g[name + ".n_side"]), g[name + ".out"]
+        a = tsr_ref.interpolate_pos(table, n, "scale_factor").numpy()
+        np.testing.assert_allclose(a, want, rtol=0, atol=1e-6)
+        b = interpolate_pos_embedding(table, n, "scale_factor")
+        # fp32 rounding of the cubic coefficients: the reference's own fp32 result is 8e-6 from the exact (fp64) interpolation
+        np.testing.assert_allclose(b, want, rtol=0, atol=1e-5)
+        # and it is NOT the `size=` form: the two differ by far more than the tolerance above
+        c = interpolate_pos_embedding(table, n, "size")
+        assert np.abs(c - want).max() > 1e-3
+
+
 def test_preprocessor_matches_reference():
     from sculptmate_amd.tsr.utils import ImagePreprocessor
 
