@@ -183,6 +183,31 @@ int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W, int ldw, 
                         uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
                         sculpt_stream_t stream);
 
+/* The same GEMM with a LayerNorm folded in (nn.LayerNorm in front of every Linear of the two transformers:
+ * basic_transformer_block.py:98,114,132 / HF ViT layernorm_before, layernorm_after).
+ *   Producer side (ln->stats_out): besides out_f32 (and its bf16 copy out_bf16) the launch writes, per row, the (mean, M2 =
+ *     sum of squared deviations) of every 64-column slice of the fp32 result: stats_out [N/64][stats_ld][2].
+ *   Consumer side (ln->stats_in): A holds those UN-normalised rows x in bf16, W = W0 * diag(gamma) (gamma folded in),
+ *     bias = bias0 + W0 . beta, colsum[n] = sum_k W[n][k]; the slice statistics are combined per row (parallel-variance
+ *     formula) into (mean, rstd) and   out[m][n] = epi(rstd[m] * (acc[m][n] - mean[m] * colsum[n]) + bias[n])
+ *     == epi(LayerNorm(x)[m] . W0[n] + bias0[n]) -- no LayerNorm launch, no normalised copy of x in HBM. */
+typedef struct sculpt_ln_fold {
+    const float *stats_in; /* [slots_in][stats_ld][2] (slice-major: the rows of one slice are contiguous) or NULL */
+    int slots_in;          /* K / 64 */
+    const float *colsum;   /* [N] (GEGLU: [2N]) */
+    float eps;
+    float *stats_out;      /* [N/64][stats_ld][2] or NULL */
+    int stats_ld;          /* rows per slice plane of stats_in / stats_out, >= M */
+} sculpt_ln_fold_t;
+int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
+                        const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
+                        uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
+                        const sculpt_ln_fold_t *ln /* or NULL */, sculpt_stream_t stream);
+/* (mean, M2) of every 64-column slice of x [rows][cols] fp32 -> stats [cols/64][stats_ld][2], and the bf16 copy of x: the
+ * producer side of the fold for rows that do not come out of a GEMM (the ViT's embedding output). cols % 64 == 0. */
+int sculpt_row_slice_stats(const float *x, int ldx, int rows, int cols, float *stats, int stats_ld, uint16_t *x_bf16, int ldb,
+                           sculpt_stream_t stream);
+
 /* fp32 "parity mode" of the same stack (exact-fp32 MFMA, ~5x slower; not timed by bench.py):
  *   out[m][n] = epi(alpha * A[m][:].W[n][:] + bias[n]) (+ residual); A, W, out fp32; K % 16 == 0; N % 4 == 0
  *   (w_rows = valid rows of W when N is padded; 0 = N); n_split / out_t as in sculpt_gemm_bf16. */

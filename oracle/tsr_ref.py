@@ -19,8 +19,12 @@ modules (and the installed `transformers` ViT, "size" position-embedding mode) i
 container -- tests/golden/make_reference_goldens.py tiny / block.
 
 `bf16=True` rounds tensors to bfloat16 at the points where the HIP pipeline stores bf16 (weights,
-LayerNorm outputs, q/k/v, softmax probabilities, attention output, GEGLU output): the GPU tests
+GEMM operands, q/k/v, softmax probabilities, attention output, GEGLU output): the GPU tests
 compare against that variant tightly and against the fp32 variant with the documented bf16 tolerance.
+Since round 2 the HIP pipeline folds every LayerNorm into the GEMM that consumes it: the GEMM's
+operand is bf16(x) -- the UN-normalised residual row -- against bf16(W * gamma), and mean / rstd (from the fp32 x)
+are applied to the fp32 accumulator; `_ln_linear` restates exactly that for bf16=True and is the plain
+F.linear(F.layer_norm(x)) of the reference for bf16=False.
 """
 import math
 
@@ -41,6 +45,22 @@ class _Q:
 
     def __call__(self, x):
         return x.to(torch.bfloat16).to(torch.float32) if self.on else x
+
+
+def _ln_linear(h, gamma, beta, eps, W, bias, Q):
+    """Linear(LayerNorm(h)).  fp32 (Q off): the reference's two calls.  bf16 emulation: the folded form the HIP
+    GEMM computes -- rstd * (bf16(h) . bf16(W*gamma)^T - mean * colsum) + (bias + W . beta)."""
+    D = h.shape[-1]
+    if not Q.on:
+        return F.linear(F.layer_norm(h, (D,), gamma, beta, eps), W, bias)
+    Wp = Q(W * gamma[None, :])
+    bp = (W.double() @ beta.double()).float()
+    if bias is not None:
+        bp = bp + bias
+    mean = h.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(h.var(-1, unbiased=False, keepdim=True) + eps)
+    acc = F.linear(Q(h), Wp)
+    return rstd * (acc - mean * Wp.sum(1)[None, :]) + bp
 
 
 def interpolate_pos(pos, n_side, mode):
@@ -98,14 +118,14 @@ def vit_forward(sd, image_hwc, cfg, pos_mode="scale_factor", bf16=False, collect
     h = h + interpolate_pos(sd[p + "embeddings.position_embeddings"], n_side, pos_mode)
     for i in range(v["num_hidden_layers"]):
         q = "encoder.layer.%d." % i
-        xn = Q(F.layer_norm(h, (H,), g(q + "layernorm_before.weight"), g(q + "layernorm_before.bias"), eps))
-        qq = Q(F.linear(xn, Q(g(q + "attention.attention.query.weight")), g(q + "attention.attention.query.bias")))
-        kk = Q(F.linear(xn, Q(g(q + "attention.attention.key.weight")), g(q + "attention.attention.key.bias")))
-        vv = Q(F.linear(xn, Q(g(q + "attention.attention.value.weight")), g(q + "attention.attention.value.bias")))
+        l1 = (g(q + "layernorm_before.weight"), g(q + "layernorm_before.bias"), eps)
+        qq = Q(_ln_linear(h, *l1, g(q + "attention.attention.query.weight"), g(q + "attention.attention.query.bias"), Q))
+        kk = Q(_ln_linear(h, *l1, g(q + "attention.attention.key.weight"), g(q + "attention.attention.key.bias"), Q))
+        vv = Q(_ln_linear(h, *l1, g(q + "attention.attention.value.weight"), g(q + "attention.attention.value.bias"), Q))
         a = Q(_attn(qq, kk, vv, nh, Q))
         h = F.linear(a, Q(g(q + "attention.output.dense.weight")), g(q + "attention.output.dense.bias")) + h
-        xn = Q(F.layer_norm(h, (H,), g(q + "layernorm_after.weight"), g(q + "layernorm_after.bias"), eps))
-        f = Q(F.gelu(F.linear(xn, Q(g(q + "intermediate.dense.weight")), g(q + "intermediate.dense.bias"))))
+        f = Q(F.gelu(_ln_linear(h, g(q + "layernorm_after.weight"), g(q + "layernorm_after.bias"), eps,
+                                g(q + "intermediate.dense.weight"), g(q + "intermediate.dense.bias"), Q)))
         h = F.linear(f, Q(g(q + "output.dense.weight")), g(q + "output.dense.bias")) + h
         if collect is not None:
             collect["vit_layer%d" % i] = h.clone()
@@ -117,17 +137,15 @@ def block_forward(sd, prefix, h, ctx, heads, bf16=False):
     Q = _Q(bf16)
     g = lambda k: _t(sd[prefix + k]).float()  # noqa: E731
     D = h.shape[1]
-    xn = Q(F.layer_norm(h, (D,), g("norm1.weight"), g("norm1.bias"), 1e-5))
-    a = Q(_attn(Q(F.linear(xn, Q(g("attn1.to_q.weight")))), Q(F.linear(xn, Q(g("attn1.to_k.weight")))),
-                Q(F.linear(xn, Q(g("attn1.to_v.weight")))), heads, Q))
+    n1 = (g("norm1.weight"), g("norm1.bias"), 1e-5)
+    a = Q(_attn(Q(_ln_linear(h, *n1, g("attn1.to_q.weight"), None, Q)), Q(_ln_linear(h, *n1, g("attn1.to_k.weight"), None, Q)),
+                Q(_ln_linear(h, *n1, g("attn1.to_v.weight"), None, Q)), heads, Q))
     h = F.linear(a, Q(g("attn1.to_out.0.weight")), g("attn1.to_out.0.bias")) + h
-    xn = Q(F.layer_norm(h, (D,), g("norm2.weight"), g("norm2.bias"), 1e-5))
     c = Q(ctx)
-    a = Q(_attn(Q(F.linear(xn, Q(g("attn2.to_q.weight")))), Q(F.linear(c, Q(g("attn2.to_k.weight")))),
-                Q(F.linear(c, Q(g("attn2.to_v.weight")))), heads, Q))
+    a = Q(_attn(Q(_ln_linear(h, g("norm2.weight"), g("norm2.bias"), 1e-5, g("attn2.to_q.weight"), None, Q)),
+                Q(F.linear(c, Q(g("attn2.to_k.weight")))), Q(F.linear(c, Q(g("attn2.to_v.weight")))), heads, Q))
     h = F.linear(a, Q(g("attn2.to_out.0.weight")), g("attn2.to_out.0.bias")) + h
-    xn = Q(F.layer_norm(h, (D,), g("norm3.weight"), g("norm3.bias"), 1e-5))
-    pr = F.linear(xn, Q(g("ff.net.0.proj.weight")), g("ff.net.0.proj.bias"))
+    pr = _ln_linear(h, g("norm3.weight"), g("norm3.bias"), 1e-5, g("ff.net.0.proj.weight"), g("ff.net.0.proj.bias"), Q)
     val, gate = pr.chunk(2, dim=-1)
     f = Q(val * F.gelu(gate))
     h = F.linear(f, Q(g("ff.net.2.weight")), g("ff.net.2.bias")) + h

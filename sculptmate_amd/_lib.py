@@ -50,6 +50,8 @@ SIGNATURES = {
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_bf16_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sculpt_gemm_bf16_ln": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sculpt_row_slice_stats": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "sculpt_conv3x3_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sculpt_im2col3x3_dilated": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sculpt_maxpool2x2_ceil": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -102,6 +104,11 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
     _fn.restype = _res
     _fn.argtypes = _args
+
+class LnFold(ctypes.Structure):
+    """sculpt_ln_fold_t (include/sculpt_hip.h)."""
+    _fields_ = [("stats_in", _vp), ("slots_in", _i), ("colsum", _vp), ("eps", _f), ("stats_out", _vp), ("stats_ld", _i)]
+
 
 MC_FACES_I64 = 1
 MC_REFERENCE_ORDER = 2

@@ -35,14 +35,43 @@ def is_fresh():
     return os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in _deps())
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "sculpt_hip.h")]
+
+
 def build(force=False, verbose=False):
+    """One object file per .hip source (recompiled only when it or a header changed, up to 8 hipcc processes at a time),
+    then one link.  Objects live in csrc/_obj/ (git-ignored, not needed on the GPU box: the linked .so travels)."""
     if not force and is_fresh():
         return SO
-    cmd = [hipcc(), "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", SO + ".tmp"] + os.environ.get("SCULPT_EXTRA_HIPCC_FLAGS", "").split() + sources()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    extra = os.environ.get("SCULPT_EXTRA_HIPCC_FLAGS", "").split()
+    flags = ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wno-unused-result"] + extra
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
+    jobs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc()] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
+    objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in sources()]
+    link = [hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", SO + ".tmp"] + objs
+    run(link)
     os.replace(SO + ".tmp", SO)
     return SO
 

@@ -69,7 +69,18 @@ struct GemmArgs {
     // 64 channels cc of tap (ky, kx): source pixel (y + (ky-1) d, x + (kx-1) d) or a zero page outside the image
     int cv_H, cv_W, cv_c64, cv_dil;
     const uint16_t *cv_zero;
+    // LayerNorm folded into this GEMM (sculpt_gemm_bf16_ln): A holds the UN-normalised rows x, W has gamma folded in, bias has
+    // beta folded in; ln_stats = per-row (mean, M2) of the 32-column slices of x written by the GEMM that produced x:
+    //   out = rstd[m] * (acc[m][n] - mean[m] * ln_colsum[n]) + bias[n]
+    const float *ln_stats; int ln_slots;  // [ln_slots][stats_ld][2], slot-major
+    const float *ln_colsum;
+    float ln_eps;
+    float *stats_out;  // producer side: per-row (mean, M2) of every 32-column slice of the fp32 result, [N/32][stats_ld][2]
+    int stats_ld;      // rows per slice plane of both statistics arrays (>= M)
+    const float *zeros;  // >= 2N zero floats: stands in for a missing bias / colsum so the epilogue loads are unconditional
 };
+
+static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 tile; one wave of a BW=128 tile)
 
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
 // NW: waves per workgroup.  4 = 2x2 waves of 64 activation x BW/2 weight rows; 8 = 2 (weight) x 4 (activation)
@@ -83,7 +94,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // workgroup per CU leaves the epilogue and the ramp-up uncovered).
     constexpr int NSTAGE = (BW == 64) ? 3 : 2;
     constexpr int DIST = NSTAGE - 1;  // prefetch distance in K-tiles
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * (WT + AT)];  // [stage][W | A]
+    // [stage][W | A], then 2 KiB of exchange space for the LayerNorm statistics (ONE shared array: a second __shared__ object
+    // beside the LDS-DMA ring can make hipcc drain the DMA queue before every fragment read)
+    constexpr int XCH = NSTAGE * (WT + AT);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XCH + 2 * BM * 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NWC = NW / 2;          // waves along the activation rows
@@ -190,6 +204,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TJ; ++j) boff[j] = lds_off(wc * (16 * TJ) + j * 16 + fr, fq);
 
+    // LayerNorm fold: the row's slice statistics (every slice has LN_SLOT columns) are combined into (mean, rstd) with Chan's
+    // parallel-variance formula.  Row m of sub-tile j sits on the four lanes fr, fr+16, fr+32, fr+48: lane fq takes slices fq,
+    // fq+4, ...  Statistics are slot-major [slot][row]: the 16 rows of a sub-tile are 128 contiguous bytes per slice (row-major
+    // cost 16 partial cache lines per wave instruction and 3x the time).
+    // The loads are issued HERE, ahead of everything, and consumed only AFTER the K loop: under a saturated L2 -> LDS stream a
+    // load takes 2-3 us to come back, and consumed in front of the loop that latency was paid by every workgroup round
+    // (+3 / +4 / +7 us on the 384 / 576 / 1536-workgroup launches).  Register loads and LDS-DMA were observed to retire out of
+    // issue order relative to each other (a counted `s_waitcnt vmcnt(LPT)` behind these loads let wrong rows through in ~1 of
+    // 3 launches), so the first K-tile is waited for with vmcnt(0) while they may still be in flight (below).  Slices beyond
+    // ln_slots are read clamped and masked out.
+    constexpr int MAXU = 4;  // up to 16 slices = 1024 normalised columns
+    float2 sv[TJ][MAXU];
+    // the two waves (wr = 0, 1) that share these rows would load the same statistics: only wr = 0 loads and computes, and
+    // hands (mean, rstd) to its partner through LDS after the K loop -- these launches are bound by L2 -> CU bytes, and the
+    // statistics re-read by every column tile were +17 % of them with 32-column slices loaded by both waves
+    const bool ln_load = g.ln_stats && wr == 0;
+    if (ln_load) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = min(m0 + wc * (16 * TJ) + j * 16 + fr, g.M - 1);
+            const float2 *sp = reinterpret_cast<const float2 *>(g.ln_stats) + m;
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) sv[j][u] = sp[(long)min(fq + 4 * u, g.ln_slots - 1) * g.stats_ld];
+        }
+    }
+
     // 3-stage ring, two K-tiles in flight: wait for tile kt only (counted vmcnt), one raw barrier per
     // K-tile (a __syncthreads() here would drain the LDS-DMA queue: guide "Pipelining across barriers").
     constexpr int LPT = WI + AI;  // LDS-DMA instructions per thread per K-tile
@@ -198,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % NSTAGE;
         // wait until tile kt has landed; tiles kt+1 .. kt+DIST-1 (if issued) stay in flight
-        if (DIST > 1 && kt + 1 < nk) {
+        if (DIST > 1 && kt + 1 < nk && !(kt == 0 && g.ln_stats)) {
             static_assert(LPT == 3 || LPT == 4 || LPT == 6 || LPT == 8, "counted wait needs an immediate");
             if (LPT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -228,7 +268,103 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     }
 #undef STAGE
 
+    float ln_mean[TJ], ln_rstd[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) { ln_mean[j] = 0.f; ln_rstd[j] = 1.f; }
+    float2 *xch = reinterpret_cast<float2 *>(smem + XCH);  // [wr][BM rows]
+    if (g.ln_stats) {
+        if (ln_load) {
+            const float inv_slots = 1.0f / (float)g.ln_slots;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float sm = 0.f;
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) sm += (fq + 4 * u < g.ln_slots) ? sv[j][u].x : 0.f;
+                sm += __shfl_xor(sm, 16, 64);
+                sm += __shfl_xor(sm, 32, 64);
+                const float mean = sm * inv_slots;
+                float m2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) {
+                    const float d = sv[j][u].x - mean;
+                    m2 += (fq + 4 * u < g.ln_slots) ? fmaf((float)LN_SLOT * d, d, sv[j][u].y) : 0.f;
+                }
+                m2 += __shfl_xor(m2, 16, 64);
+                m2 += __shfl_xor(m2, 32, 64);
+                ln_mean[j] = mean;
+                ln_rstd[j] = rsqrtf(m2 * inv_slots * (1.0f / LN_SLOT) + g.ln_eps);
+                if (fq == 0) xch[wc * (16 * TJ) + j * 16 + fr] = make_float2(ln_mean[j], ln_rstd[j]);
+            }
+        }
+        // (the exchange space is not part of the staging ring: no barrier needed before the writes; raw barrier -- a
+        // __syncthreads() would also wait for vector memory)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!ln_load) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const float2 v = xch[wc * (16 * TJ) + j * 16 + fr];
+                ln_mean[j] = v.x;
+                ln_rstd[j] = v.y;
+            }
+        }
+    }
+
     // epilogue: acc[i][j][r] = out[m = m0 + wc*16*TJ + j*16 + fr][tile row = wr*(BW/2) + i*16 + fq*4 + r]
+    // Per-column vectors (bias, LayerNorm column sums) depend on i only: ONE unconditional float4 load each per sub-tile, all
+    // issued together (a per-element `ptr ? ptr[n] : 0` makes hipcc branch around every load and wait for it: 32 dependent
+    // L2 round trips per lane).  A missing vector reads the zero page.
+    const float *biasp = g.bias ? g.bias : g.zeros;
+    const float *csp = g.ln_stats ? g.ln_colsum : g.zeros;
+    float4 b4[TI], c4[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int wrow = (EPI == SCULPT_EPI_GEGLU) ? ((i & 1) ? g.N : 0) + n0 + (wr * (TI / 2) + (i >> 1)) * 16 + fq * 4
+                                                   : n0 + wr * (BW / 2) + i * 16 + fq * 4;
+        b4[i] = *reinterpret_cast<const float4 *>(biasp + wrow);
+        c4[i] = *reinterpret_cast<const float4 *>(csp + wrow);
+    }
+    auto f4 = [](const float4 &v, int r) -> float { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
+    // ... and every residual tile of this lane before the first store: vmcnt counts stores too, so a load issued after a
+    // store would wait for that store's completion as well (one L2 round trip per sub-tile, serialised)
+    float4 rs[TI][TJ];
+    if (EPI != SCULPT_EPI_GEGLU && g.residual) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = min(m0 + wc * (16 * TJ) + j * 16 + fr, g.M - 1);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                rs[i][j] = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n0 + wr * (BW / 2) + i * 16 + fq * 4);
+        }
+    }
+    // phase 1: the whole tile in registers (acc is overwritten by the results): every loaded value is consumed here, so the
+    // loads are waited for once, before the first store
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        if (EPI == SCULPT_EPI_GEGLU) {
+#pragma unroll
+            for (int ip = 0; ip < TI / 2; ++ip)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // mean = 0, rstd = 1, colsum = 0 without the fold: exactly acc + bias
+                    const float v = ln_rstd[j] * (acc[2 * ip][j][r] - ln_mean[j] * f4(c4[2 * ip], r)) + f4(b4[2 * ip], r);
+                    const float gt = ln_rstd[j] * (acc[2 * ip + 1][j][r] - ln_mean[j] * f4(c4[2 * ip + 1], r)) + f4(b4[2 * ip + 1], r);
+                    acc[2 * ip][j][r] = v * gelu_erf(gt);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = ln_rstd[j] * (acc[i][j][r] - ln_mean[j] * f4(c4[i], r)) + f4(b4[i], r);
+                    if (EPI == SCULPT_EPI_GELU) v = gelu_erf(v);
+                    if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
+                    if (g.residual) v += f4(rs[i][j], r);
+                    acc[i][j][r] = v;
+                }
+        }
+    }
+    // phase 2: stores (and the slice statistics of the fp32 result)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
@@ -237,13 +373,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int ip = 0; ip < TI / 2; ++ip) {
                 const int n = n0 + (wr * (TI / 2) + ip) * 16 + fq * 4;  // output column of r = 0
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[2 * ip][j][r] + (g.bias ? g.bias[n + r] : 0.f);
-                    const float gt = acc[2 * ip + 1][j][r] + (g.bias ? g.bias[g.N + n + r] : 0.f);
-                    o[r] = v * gelu_erf(gt);
-                }
+                const f32x4 o = acc[2 * ip][j];
                 if (g.out_bf16) {
                     uint2 pk;
                     pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
@@ -257,18 +387,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             for (int i = 0; i < TI; ++i) {
                 const int n = n0 + wr * (BW / 2) + i * 16 + fq * 4;
                 if (n >= g.n_store) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + (g.bias ? g.bias[n + r] : 0.f);
-                    if (EPI == SCULPT_EPI_GELU) v = gelu_erf(v);
-                    if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
-                    o[r] = v;
-                }
-                if (g.residual) {
-                    const float4 rs = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n);
-                    o[0] += rs.x; o[1] += rs.y; o[2] += rs.z; o[3] += rs.w;
-                }
+                const f32x4 o = acc[i][j];
+                // (statistics of the fp32 result: after the store loops, below)
                 const bool tpart = n >= g.n_split;  // wave-uniform per sub-tile (n_split is a multiple of 16)
                 if (!tpart) {
                     if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
@@ -287,6 +407,57 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             }
         }
     }
+    // phase 3 (producer side of the LayerNorm fold): per row the (mean, M2) of every LN_SLOT = 64 columns of the fp32 result.
+    // A wave holds BW/2 columns of 16 * TJ rows: row m's values sit on the 4 lanes fr + 16 {0..3}, 4 * TI each.
+    //   BW = 128: the wave's 64 columns are one slice.   BW = 64: the two waves (wr = 0, 1) that share the rows each reduce
+    //   their 32 columns and wr = 0 merges the pair through LDS (Chan: M2 = M2a + M2b + n/2 (mean_a - mean_b)^2).
+    if (EPI == SCULPT_EPI_NONE && g.stats_out) {
+        constexpr int WCOLS = BW / 2;  // columns of this wave
+        float pm[TJ], pq[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * (1.0f / WCOLS);
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean; m2 = fmaf(d, d, m2); }
+            m2 += __shfl_xor(m2, 16, 64);
+            m2 += __shfl_xor(m2, 32, 64);
+            pm[j] = mean;
+            pq[j] = m2;
+        }
+        float2 *so = reinterpret_cast<float2 *>(g.stats_out);
+        if (WCOLS == LN_SLOT) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
+                if (fq == 0 && m < g.M) so[(long)((n0 + wr * WCOLS) / LN_SLOT) * g.stats_ld + m] = make_float2(pm[j], pq[j]);
+            }
+        } else {
+            static_assert(WCOLS == LN_SLOT || 2 * WCOLS == LN_SLOT, "statistics slice = one or two waves' columns");
+            if (wr == 1 && fq == 0) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) xch[wc * (16 * TJ) + j * 16 + fr] = make_float2(pm[j], pq[j]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw barrier: the output stores above stay in flight
+            __builtin_amdgcn_s_barrier();
+            if (wr == 0 && fq == 0) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
+                    const float2 o = xch[wc * (16 * TJ) + j * 16 + fr];
+                    const float d = pm[j] - o.x;
+                    if (m < g.M) so[(long)(n0 / LN_SLOT) * g.stats_ld + m] = make_float2(0.5f * (pm[j] + o.x), pq[j] + o.y + (0.5f * WCOLS) * d * d);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace sculpt
@@ -301,14 +472,16 @@ extern "C" int sculpt_gemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
                                epilogue, stream);
 }
 
+static constexpr long ZERO_FLOATS = 65536;  // a missing bias / colsum vector reads from here: N (GEGLU: 2N) <= 65536
 static const uint16_t *zero_page() {
-    // 256 zero bytes per device for the out-of-image taps of the implicit convolution (allocated once, never freed)
+    // 256 KiB of zeros per device: the out-of-image taps of the implicit convolution and the stand-in for a missing per-column
+    // vector (allocated once, never freed)
     static const uint16_t *pages[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!pages[dev]) {
         void *p = nullptr;
-        if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        if (hipMalloc(&p, ZERO_FLOATS * 4) != hipSuccess || hipMemset(p, 0, ZERO_FLOATS * 4) != hipSuccess) return nullptr;
         pages[dev] = reinterpret_cast<const uint16_t *>(p);
     }
     return pages[dev];
@@ -329,7 +502,8 @@ extern "C" int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, 
     const long M = (long)n_images * H * W;
     const int K = 9 * C_pad;
     GemmArgs g{in, ld_in, Wt, K, bias, nullptr, 0, out_f32, out_bf16, ldo, nullptr, 0, (int)M, N, K, N, (long)N > M ? 1 : 0,
-               n_store, H, W, C_pad / 64, dilation, zp};
+               n_store, H, W, C_pad / 64, dilation, zp, nullptr, 0, nullptr, 0.f, nullptr, 0, reinterpret_cast<const float *>(zp)};
+    SC_REQUIRE((long)N <= ZERO_FLOATS, "conv3x3_bf16: N=%d too large", N);
     const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
@@ -348,6 +522,14 @@ extern "C" int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W
                                    const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
                                    uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
                                    sculpt_stream_t stream) {
+    return sculpt_gemm_bf16_ln(A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, n_split, n_store, M, N,
+                               K, epilogue, nullptr, stream);
+}
+
+extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
+                                   const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,
+                                   uint16_t *out_bf16_t, int ldt, int n_split, int n_store, int M, int N, int K, int epilogue,
+                                   const sculpt_ln_fold_t *ln, sculpt_stream_t stream) {
     SC_REQUIRE(A && W, "gemm_bf16: null operand");
     SC_REQUIRE(out_f32 || out_bf16 || out_bf16_t, "gemm_bf16: no output");
     SC_REQUIRE(M >= 1 && N >= 1 && K >= BK, "gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
@@ -362,7 +544,26 @@ extern "C" int sculpt_gemm_bf16_ex(const uint16_t *A, int lda, const uint16_t *W
     SC_REQUIRE(n_store % 4 == 0, "gemm_bf16: n_store=%d must be a multiple of 4", n_store);
     SC_REQUIRE(n_store == N || (epilogue != SCULPT_EPI_GEGLU && !out_bf16_t), "gemm_bf16: n_store is for plain outputs only");
     GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
-               w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr};
+               w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
+    SC_REQUIRE(w_rows <= ZERO_FLOATS, "gemm_bf16: N=%d too large", N);
+    g.zeros = reinterpret_cast<const float *>(zero_page());
+    SC_REQUIRE(g.zeros, "gemm_bf16: could not allocate the zero page");
+    SC_REQUIRE((!bias || ((uintptr_t)bias & 15) == 0) && (!ln || !ln->colsum || ((uintptr_t)ln->colsum & 15) == 0),
+               "gemm_bf16: bias / colsum must be 16-byte aligned");
+    if (ln && ln->stats_in) {
+        SC_REQUIRE(ln->colsum && ln->slots_in >= 1 && ln->slots_in <= 16, "gemm_bf16_ln: stats_in needs colsum and 1 <= slots_in <= 16 (K <= 1024)");
+        SC_REQUIRE(ln->slots_in * LN_SLOT == K, "gemm_bf16_ln: slots_in=%d x %d columns must cover the K=%d normalised columns", ln->slots_in, LN_SLOT, K);
+        g.ln_stats = ln->stats_in; g.ln_slots = ln->slots_in; g.ln_colsum = ln->colsum; g.ln_eps = ln->eps;
+    }
+    if (ln && (ln->stats_in || ln->stats_out)) {
+        SC_REQUIRE(ln->stats_ld >= M, "gemm_bf16_ln: stats_ld=%d must be >= M=%d", ln->stats_ld, M);
+        g.stats_ld = ln->stats_ld;
+    }
+    if (ln && ln->stats_out) {
+        SC_REQUIRE(epilogue == SCULPT_EPI_NONE && out_f32 && n_store == N && n_split == N,
+                   "gemm_bf16_ln: stats_out is for the plain fp32 output (no activation, no column split / n_store)");
+        g.stats_out = ln->stats_out;
+    }
     const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of

@@ -219,11 +219,55 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict_
 
 static inline int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 2048); }
 
+// one thread per (row, 64-column slice): 16 float4 loads (256 contiguous bytes), two-pass (mean, M2), bf16 copy
+__global__ __launch_bounds__(256) void row_slice_stats_kernel(const float *__restrict__ x, int ldx, int rows, int slots,
+                                                              float *__restrict__ stats, int stats_ld,
+                                                              uint16_t *__restrict__ xb, int ldb) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)rows * slots) return;
+    const int slot = (int)(t / rows), row = (int)(t % rows);  // row fastest: the slice-major stores are coalesced
+    const float4 *src = reinterpret_cast<const float4 *>(x + (long)row * ldx + slot * 64);
+    float4 v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = src[i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    const float mean = s * (1.0f / 64.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
+    }
+    reinterpret_cast<float2 *>(stats)[(long)slot * stats_ld + row] = make_float2(mean, m2);
+    if (xb) {
+        uint2 *dst = reinterpret_cast<uint2 *>(xb + (long)row * ldb + slot * 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[i].x) | ((uint32_t)f32_to_bf16(v[i].y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[i].z) | ((uint32_t)f32_to_bf16(v[i].w) << 16);
+            dst[i] = pk;
+        }
+    }
+}
+
 }  // namespace sculpt
 
 using namespace sculpt;
 
 extern "C" {
+
+int sculpt_row_slice_stats(const float *x, int ldx, int rows, int cols, float *stats, int stats_ld, uint16_t *x_bf16, int ldb,
+                           sculpt_stream_t stream) {
+    SC_REQUIRE(x && stats && stats_ld >= rows, "row_slice_stats: null argument or stats_ld < rows");
+    SC_REQUIRE(cols >= 64 && cols % 64 == 0 && ldx % 4 == 0 && (!x_bf16 || ldb % 4 == 0), "row_slice_stats: cols=%d must be a multiple of 64", cols);
+    if (rows <= 0) return 0;
+    const int slots = cols / 64;
+    hipLaunchKernelGGL(row_slice_stats_kernel, dim3(cdiv((long)rows * slots, 256)), dim3(256), 0, as_stream(stream), x, ldx, rows,
+                       slots, stats, stats_ld, x_bf16, ldb);
+    SC_LAUNCH_CHECK();
+    return 0;
+}
 
 int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const float *gamma, const float *beta,
                      float eps, uint16_t *y, int ldy, float *y_f32, int rows, int cols, sculpt_stream_t stream) {

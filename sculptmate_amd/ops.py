@@ -208,21 +208,55 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
 # transformer primitives (bf16 storage as torch.bfloat16 tensors; fp32 accumulate)
 # ----------------------------------------------------------------------------------------------
 BF16 = torch.bfloat16
+LN_SLOT = 64  # columns per LayerNorm statistics slice (csrc/gemm.hip)
 
 
-def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0, n_split=0):
+def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0, n_split=0,
+         ln_stats=None, ln_colsum=None, ln_eps=1e-5, stats_out=None):
     """out[m][n] = epi(A[m][:] . W[n][:] + bias[n]) (+ residual[m][n]); see sculpt_gemm_bf16.
-    A [>=M][K] bf16, W [N or 2N][K] bf16 (row stride = K).  Outputs are caller-allocated."""
+    A [>=M][K] bf16, W [N or 2N][K] bf16 (row stride = K).  Outputs are caller-allocated.
+    LayerNorm fold (sculpt_gemm_bf16_ln): ln_stats [K/64][rows][2] + ln_colsum [N] -> A holds the un-normalised rows, W / bias
+    have gamma / beta folded in (fold_layernorm); stats_out [N/64][rows][2] receives the slice statistics of out_f32."""
     K = A.shape[1]
     N = W.shape[0] // 2 if epilogue == _lib.EPI_GEGLU else W.shape[0]
     M = A.shape[0] if M is None else M
     ldo = (out_f32 if out_f32 is not None else out_bf16).stride(0) if (out_f32 is not None or out_bf16 is not None) else 0
     if out_f32 is not None and out_bf16 is not None:
         assert out_f32.stride(0) == out_bf16.stride(0)
-    check(lib.sculpt_gemm_bf16(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
-                               residual.stride(0) if residual is not None else 0, _ptr(out_f32), _ptr(out_bf16),
-                               ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, int(n_split), M, N, K,
-                               epilogue, _stream()))
+    ln = None
+    if ln_stats is not None or stats_out is not None:
+        # statistics arrays are slice-major: [K/64 or N/64][rows][2]
+        ref = ln_stats if ln_stats is not None else stats_out
+        ld = ref.shape[1]
+        ln = _lib.LnFold(_ptr(ln_stats), K // LN_SLOT if ln_stats is not None else 0, _ptr(ln_colsum), float(ln_eps), _ptr(stats_out), ld)
+        if ln_stats is not None:
+            assert ln_stats.dtype == torch.float32 and ln_stats.shape[0] >= K // LN_SLOT and ln_stats.shape[1] == ld and ln_colsum is not None
+        if stats_out is not None:
+            assert stats_out.dtype == torch.float32 and stats_out.shape[0] >= N // LN_SLOT and stats_out.shape[1] == ld
+    check(lib.sculpt_gemm_bf16_ln(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                                  residual.stride(0) if residual is not None else 0, _ptr(out_f32), _ptr(out_bf16),
+                                  ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, int(n_split), 0, M, N, K,
+                                  epilogue, ctypes.byref(ln) if ln is not None else None, _stream()))
+
+
+def fold_layernorm(W, bias, gamma, beta):
+    """Host-side (load-time) fold of y = LayerNorm(x) * gamma + beta into the Linear that consumes it (fp32 tensors):
+       W' = W * gamma (rounded to bf16 by the caller's upload), bias' = bias + W . beta, colsum = sum_k bf16(W')[n][k].
+    Returns (W' fp32, bias' fp32, colsum fp32)."""
+    W = W.detach().to(torch.float32).cpu()
+    Wp = W * gamma.detach().to(torch.float32).cpu()[None, :]
+    bp = (W.double() @ beta.detach().double().cpu())
+    if bias is not None:
+        bp = bp + bias.detach().double().cpu()
+    colsum = Wp.to(BF16).double().sum(1)  # of the values the GEMM really multiplies by: the mean term cancels exactly
+    return Wp, bp.to(torch.float32), colsum.to(torch.float32)
+
+
+def row_slice_stats(x, stats, x_bf16=None, rows=None):
+    """(mean, M2) of every 64-column slice of the fp32 rows x -> stats [cols/64][rows][2] (+ the bf16 copy of x)."""
+    rows = x.shape[0] if rows is None else rows
+    check(lib.sculpt_row_slice_stats(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(stats), stats.shape[1], _ptr(x_bf16),
+                                     x_bf16.stride(0) if x_bf16 is not None else 0, _stream()))
 
 
 def attention(Q, K, Vt, O, Tq, Tk, heads, scale):

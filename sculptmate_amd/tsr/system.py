@@ -208,16 +208,29 @@ class TSR(KernelEngine):
         w["patch_w"] = wt(sd[p + "embeddings.patch_embeddings.projection.weight"].reshape(H, -1), dev)
         w["patch_b"] = _f32(sd[p + "embeddings.patch_embeddings.projection.bias"], dev)
         w["cls"] = _f32(sd[p + "embeddings.cls_token"].reshape(H), dev)
+        fold = self.precision == "bf16"
+
+        def ln_linear(L, key, W, bias, gamma, beta):
+            """A Linear fed by a LayerNorm.  bf16 mode: the LayerNorm is folded into the GEMM (ops.fold_layernorm):
+            L[key] = bf16(W * gamma), L[key_b] = bias + W . beta, L[key_cs] = column sums.  fp32 mode: plain weights + the
+            LayerNorm's own parameters for the stand-alone kernel."""
+            if fold:
+                Wp, bp, cs = ops.fold_layernorm(W, bias, gamma, beta)
+                L[key], L[key + "_b"], L[key + "_cs"] = wt(Wp, dev), _f32(bp, dev), _f32(cs, dev)
+            else:
+                L[key], L[key + "_b"] = wt(W, dev), (None if bias is None else _f32(bias, dev))
+                L[key + "_ln"] = (_f32(gamma, dev), _f32(beta, dev))
+
         w["vit"] = []
         for i in range(v["num_hidden_layers"]):
             q = p + "encoder.layer.%d." % i
             L = {}
-            L["ln1_w"], L["ln1_b"] = _f32(sd[q + "layernorm_before.weight"], dev), _f32(sd[q + "layernorm_before.bias"], dev)
-            L["ln2_w"], L["ln2_b"] = _f32(sd[q + "layernorm_after.weight"], dev), _f32(sd[q + "layernorm_after.bias"], dev)
-            L["qkv_w"] = wt(torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0), dev)
-            L["qkv_b"] = _f32(torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0), dev)
+            ln_linear(L, "qkv_w", torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0),
+                      torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0),
+                      sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"])
             L["o_w"], L["o_b"] = wt(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
-            L["f1_w"], L["f1_b"] = wt(sd[q + "intermediate.dense.weight"], dev), _f32(sd[q + "intermediate.dense.bias"], dev)
+            ln_linear(L, "f1_w", sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"],
+                      sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"])
             L["f2_w"], L["f2_b"] = wt(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
             w["vit"].append(L)
         w["vit_ln_w"], w["vit_ln_b"] = _f32(sd[p + "layernorm.weight"], dev), _f32(sd[p + "layernorm.bias"], dev)
@@ -235,14 +248,13 @@ class TSR(KernelEngine):
         for i in range(b["num_layers"]):
             q = "backbone.transformer_blocks.%d." % i
             L = {}
-            for j, ln in enumerate(("norm1", "norm2", "norm3")):
-                L["n%d_w" % (j + 1)], L["n%d_b" % (j + 1)] = _f32(sd[q + ln + ".weight"], dev), _f32(sd[q + ln + ".bias"], dev)
-            L["sa_qkv"] = wt(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), dev)
+            ln_linear(L, "sa_qkv", torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0),
+                      None, sd[q + "norm1.weight"], sd[q + "norm1.bias"])
             L["sa_o"], L["sa_ob"] = wt(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
-            L["ca_q"] = wt(sd[q + "attn2.to_q.weight"], dev)
+            ln_linear(L, "ca_q", sd[q + "attn2.to_q.weight"], None, sd[q + "norm2.weight"], sd[q + "norm2.bias"])
             L["_ca_k"], L["_ca_v"] = sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]
             L["ca_o"], L["ca_ob"] = wt(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
-            L["ff1"], L["ff1_b"] = wt(sd[q + "ff.net.0.proj.weight"], dev), _f32(sd[q + "ff.net.0.proj.bias"], dev)
+            ln_linear(L, "ff1", sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], sd[q + "norm3.weight"], sd[q + "norm3.bias"])
             L["ff2"], L["ff2_b"] = wt(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
             w["blocks"].append(L)
         # the cross-attention K/V projections of ALL layers depend only on the image tokens: one GEMM
@@ -287,20 +299,19 @@ class TSR(KernelEngine):
         self._gemm(patches, w["patch_w"], bias=w["patch_b"], out_f32=pout)
         h = self._b("vit_h", (T, H), torch.float32)
         ops.vit_assemble(pout, w["cls"], self._pos(n_side, image_hwc.device), h)
-        xn = self._b("vit_xn", (T, H), self.adt)
+        st = self._stream_state("vit", h)     # the residual stream + its bf16 copy + slice statistics (LayerNorm fold)
+        self._stats_of(st)                    # rows that do not come out of a GEMM: one small kernel
         qk = self._b("vit_qk", (T, 2 * H), self.adt)
         vt = self._b("vit_vt", (H, Tp), self.adt, zero=True)
         att = self._b("vit_att", (T, H), self.adt)
         ff = self._b("vit_ff", (T, v["intermediate_size"]), self.adt)
         eps = v["layer_norm_eps"]
         for L in w["vit"]:
-            self._ln(h, L["ln1_w"], L["ln1_b"], eps, xn)
-            self._gemm(xn, L["qkv_w"], bias=L["qkv_b"], out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
+            self._ln_gemm(st, L, "qkv_w", eps, out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
             self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
-            self._gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
-            self._ln(h, L["ln2_w"], L["ln2_b"], eps, xn)
-            self._gemm(xn, L["f1_w"], bias=L["f1_b"], out_bf16=ff, epilogue=_lib.EPI_GELU)
-            self._gemm(ff, L["f2_w"], bias=L["f2_b"], residual=h, out_f32=h)
+            self._res_gemm(st, att, L["o_w"], L["o_b"])
+            self._ln_gemm(st, L, "f1_w", eps, out_bf16=ff, epilogue=_lib.EPI_GELU)
+            self._res_gemm(st, ff, L["f2_w"], L["f2_b"])
         ctx32 = self._b("ctx32", (T, H), torch.float32)
         if self.precision == "bf16":
             ctx = self._b("ctx", (T, H), BF16)
@@ -310,29 +321,66 @@ class TSR(KernelEngine):
             ctx = ctx32
         return ctx, ctx32
 
-    def _self_attention(self, h: torch.Tensor, L):
+    # ---- residual stream with the LayerNorm fold (bf16 mode) ------------------------------------------------------
+    # Every LayerNorm of the two transformers sits between a GEMM that writes the residual stream h and a GEMM that
+    # consumes LN(h).  In bf16 mode the producer also writes bf16(h) and per-row statistics of 32-column slices, and the
+    # consumer applies mean / rstd in its epilogue with gamma / beta folded into its weights (sculpt_gemm_bf16_ln): no
+    # LayerNorm launch, no normalised copy.  fp32 parity mode keeps the stand-alone LayerNorm kernel.
+    def _stream_state(self, name, h):
+        T, D = h.shape
+        st = {"h": h, "name": name}
+        if self.precision == "bf16":
+            st["hb"] = self._b(name + "_hb", (T, D), BF16)
+            st["stats"] = self._b(name + "_stats", (D // ops.LN_SLOT, T, 2), torch.float32)  # slice-major
+        else:
+            st["xn"] = self._b(name + "_xn", (T, D), torch.float32)
+        return st
+
+    def _state_from(self, h, name="bb"):
+        """Stream state for a residual stream given as a plain fp32 tensor (tests, external callers)."""
+        st = self._stream_state(name, h)
+        self._stats_of(st)
+        return st
+
+    def _stats_of(self, st):
+        if self.precision == "bf16":
+            ops.row_slice_stats(st["h"], st["stats"], st["hb"])
+
+    def _ln_gemm(self, st, L, key, eps, **kw):
+        """Linear(LayerNorm(h)) with the weights prepared by ln_linear()."""
+        if self.precision == "bf16":
+            return ops.gemm(st["hb"], L[key], bias=L[key + "_b"], ln_stats=st["stats"], ln_colsum=L[key + "_cs"], ln_eps=eps, **kw)
+        g, b = L[key + "_ln"]
+        ops.layernorm(st["h"], g, b, eps, y_f32=st["xn"])
+        return self._gemm(st["xn"], L[key], bias=L[key + "_b"], **kw)
+
+    def _res_gemm(self, st, A, W, bias):
+        """h += A . W^T + bias (in place); bf16 mode also refreshes bf16(h) and the slice statistics."""
+        h = st["h"]
+        if self.precision == "bf16":
+            return ops.gemm(A, W, bias=bias, residual=h, out_f32=h, out_bf16=st["hb"], stats_out=st["stats"])
+        return self._gemm(A, W, bias=bias, residual=h, out_f32=h)
+
+    def _self_attention(self, st, L):
         """h += attn1(LN1(h)) of one BasicTransformerBlock (basic_transformer_block.py:149-167)."""
         b = self.cfg["backbone"]
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
-        D, T = nh * hd, h.shape[0]
+        D, T = nh * hd, st["h"].shape[0]
         Tp = ((T + 63) // 64) * 64
-        xn = self._b("bb_xn", (T, D), self.adt)
         qk = self._b("bb_qk", (T, 2 * D), self.adt)
         vt = self._b("bb_vt", (D, Tp), self.adt, zero=True)
         att = self._b("bb_att", (T, D), self.adt)
-        self._ln(h, L["n1_w"], L["n1_b"], 1e-5, xn)
-        self._gemm(xn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
+        self._ln_gemm(st, L, "sa_qkv", 1e-5, out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
         self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, 1.0 / math.sqrt(hd))
-        self._gemm(att, L["sa_o"], bias=L["sa_ob"], residual=h, out_f32=h)
+        self._res_gemm(st, att, L["sa_o"], L["sa_ob"])
 
-    def _run_blocks(self, h: torch.Tensor, ctx: torch.Tensor, first_self_attention_done: bool = False):
+    def _run_blocks(self, st, ctx: torch.Tensor, first_self_attention_done: bool = False):
         """All BasicTransformerBlocks on the fp32 residual stream h [T, D] (updated in place)."""
         b, w = self.cfg["backbone"], self._w
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
         D = nh * hd
-        T, Tc = h.shape[0], ctx.shape[0]
+        T, Tc = st["h"].shape[0], ctx.shape[0]
         Tcp = ((Tc + 63) // 64) * 64
-        xn = self._b("bb_xn", (T, D), self.adt)
         q = self._b("bb_q", (T, D), self.adt)
         nL = len(w["blocks"])
         ck_all = self._b("bb_ck", (Tc, nL * D), self.adt)
@@ -344,15 +392,13 @@ class TSR(KernelEngine):
         for li, L in enumerate(w["blocks"]):
             ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
             if li > 0 or not first_self_attention_done:
-                self._self_attention(h, L)
-            self._ln(h, L["n2_w"], L["n2_b"], 1e-5, xn)
-            self._gemm(xn, L["ca_q"], out_bf16=q)
+                self._self_attention(st, L)
+            self._ln_gemm(st, L, "ca_q", 1e-5, out_bf16=q)
             self._attn(q, ck, cvt, att, T, Tc, nh, scale)
-            self._gemm(att, L["ca_o"], bias=L["ca_ob"], residual=h, out_f32=h)
-            self._ln(h, L["n3_w"], L["n3_b"], 1e-5, xn)
-            self._gemm(xn, L["ff1"], bias=L["ff1_b"], out_bf16=ff, epilogue=_lib.EPI_GEGLU)
-            self._gemm(ff, L["ff2"], bias=L["ff2_b"], residual=h, out_f32=h)
-        return h
+            self._res_gemm(st, att, L["ca_o"], L["ca_ob"])
+            self._ln_gemm(st, L, "ff1", 1e-5, out_bf16=ff, epilogue=_lib.EPI_GEGLU)
+            self._res_gemm(st, ff, L["ff2"], L["ff2_b"])
+        return st
 
     def _backbone_head(self):
         """The part of Transformer1D.forward that does not depend on the image: GroupNorm of the learned triplane tokens,
@@ -360,23 +406,26 @@ class TSR(KernelEngine):
         b, w = self.cfg["backbone"], self._w
         D = b["num_attention_heads"] * b["attention_head_dim"]
         T = w["emb_ct"].shape[1]
-        xn = self._b("bb_xn", (T, D), self.adt)
+        xn = self._b("bb_xn", (T, w["emb_ct"].shape[0]), self.adt)
         stats = self._b("gn_stats", (2 * b["norm_num_groups"],), torch.float32)
         ops.groupnorm_tokens(w["emb_ct"], b["norm_num_groups"], w["gn_w"], w["gn_b"], 1e-6, xn, stats)
         h = self._b("bb_h", (T, D), torch.float32)
-        self._gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
-        return h
+        st = self._stream_state("bb", h)
+        if self.precision == "bf16":
+            ops.gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h, out_bf16=st["hb"], stats_out=st["stats"])
+        else:
+            self._gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
+        return st
 
-    def _backbone_tail(self, h: torch.Tensor):
+    def _backbone_tail(self, st):
         w = self._w
         C = self.cfg["tokenizer"]["num_channels"]
+        h = st["h"]
         T, D = h.shape
         out = self._b("bb_out", (T, C), torch.float32)
         if self.precision == "bf16":
-            hb = self._b("bb_hb", (T, D), BF16)
-            ops.cast_bf16(h, hb)
             outb = self._b("bb_outb", (T, C), BF16)
-            ops.gemm(hb, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out_f32=out, out_bf16=outb)
+            ops.gemm(st["hb"], w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out_f32=out, out_bf16=outb)  # hb = bf16(h)
         else:
             ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out=out)
             outb = out
@@ -385,8 +434,8 @@ class TSR(KernelEngine):
     def backbone_tokens(self, ctx: torch.Tensor):
         """Triplane1DTokenizer + Transformer1D for one image; ctx bf16 [Tc, cross_dim].
         Returns the output tokens token-major: fp32 [3*S*S, C] (+ bf16 copy)."""
-        h = self._run_blocks(self._backbone_head(), ctx)
-        return self._backbone_tail(h)
+        st = self._run_blocks(self._backbone_head(), ctx)
+        return self._backbone_tail(st)
 
     def encode_image(self, image_hwc: torch.Tensor):
         """image_tokens + backbone_tokens for one [S,S,3] fp32 device image, with the image-independent head of the backbone
@@ -401,13 +450,13 @@ class TSR(KernelEngine):
         fork.record(main)               # everything queued so far (the previous image's readers of these buffers) comes first
         with torch.cuda.stream(side):
             side.wait_event(fork)
-            h = self._backbone_head()
-            self._self_attention(h, self._w["blocks"][0])
+            st = self._backbone_head()
+            self._self_attention(st, self._w["blocks"][0])
             join.record(side)
         ctx, _ = self.image_tokens(image_hwc)
         main.wait_event(join)
-        h = self._run_blocks(h, ctx, first_self_attention_done=True)
-        return self._backbone_tail(h)
+        st = self._run_blocks(st, ctx, first_self_attention_done=True)
+        return self._backbone_tail(st)
 
     def scene_code(self, tokens_bf16: torch.Tensor):
         """detokenize + TriplaneUpsampleNetwork: tokens [3*S*S, C] -> planes fp32 [3, Co, 2S, 2S]."""

@@ -43,6 +43,67 @@ def test_gemm_bias_residual_vs_fp32_reference(cuda, M, N, K):
     assert (outt[:, M:] == 0).all()
 
 
+@pytest.mark.parametrize("M,D,N,epi", [(3072, 1024, 1024, 0), (1025, 768, 2304, 0), (1025, 768, 3072, 1), (3072, 1024, 4096, 2),
+                                       (77, 256, 128, 0)])
+def test_gemm_layernorm_fold_vs_fp32_reference(cuda, M, D, N, epi):
+    """sculpt_gemm_bf16_ln: a residual GEMM writes h (fp32), bf16(h) and the 32-column slice statistics; the next GEMM
+    consumes bf16(h) with LayerNorm folded in == Linear(LayerNorm(h)) of the reference (basic_transformer_block.py:149-206),
+    within bf16 operand rounding.  Rows get a large common offset (|mean| ~ 3 sigma) to exercise the mean term."""
+    import torch.nn.functional as F
+
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M + D + N + epi)
+    K0 = 256
+    A0 = torch.randn(M, K0, generator=g).to(BF)
+    W0 = (torch.randn(D, K0, generator=g) / math.sqrt(K0)).to(BF)
+    b0 = torch.randn(D, generator=g)
+    res = torch.randn(M, D, generator=g) + 3.0 * torch.randn(M, 1, generator=g)
+    h_ref = A0.float() @ W0.float().t() + b0 + res
+    h = torch.empty(M, D, device=cuda)
+    hb = torch.empty(M, D, dtype=BF, device=cuda)
+    stats = torch.zeros(D // 64, M, 2, device=cuda)
+    ops.gemm(A0.to(cuda), W0.to(cuda), bias=b0.to(cuda), residual=res.to(cuda), out_f32=h, out_bf16=hb, stats_out=stats)
+    assert _rel(h, h_ref)[0] < 1e-5
+    sl = h.cpu().view(M, D // 64, 64)
+    mean_ref = sl.mean(-1)
+    m2_ref = ((sl - mean_ref[..., None]) ** 2).sum(-1)
+    assert (stats[..., 0].cpu().t() - mean_ref).abs().max() < 1e-5 and _rel(stats[..., 1].t(), m2_ref)[0] < 1e-5
+    # the same statistics from the stand-alone kernel (rows that do not come out of a GEMM)
+    stats2 = torch.zeros_like(stats)
+    hb2 = torch.empty_like(hb)
+    ops.row_slice_stats(h, stats2, hb2)
+    assert torch.equal(hb2, hb) and _rel(stats2, stats)[0] < 1e-6  # same numbers, different summation order
+    # consumer
+    gamma = 1.0 + 0.3 * torch.randn(D, generator=g)
+    beta = 0.2 * torch.randn(D, generator=g)
+    rows = 2 * N if epi == 2 else N
+    W = torch.randn(rows, D, generator=g) / math.sqrt(D)
+    bias = torch.randn(rows, generator=g)
+    eps = 1e-5
+    pre = F.linear(F.layer_norm(h.cpu(), (D,), gamma, beta, eps), W, bias)
+    ref = pre if epi == 0 else (F.gelu(pre) if epi == 1 else pre[:, :N] * F.gelu(pre[:, N:]))
+    Wp, bp, cs = ops.fold_layernorm(W, bias, gamma, beta)
+    out = torch.empty(M, N, device=cuda)
+    ops.gemm(hb, Wp.to(BF).to(cuda), bias=bp.to(cuda), out_f32=out, epilogue=epi, ln_stats=stats, ln_colsum=cs.to(cuda), ln_eps=eps)
+    rel, mx = _rel(out, ref)
+    assert rel < 6e-3, (rel, mx)  # bf16 rounding of both operands (2^-9 each), fp32 accumulate
+    # tight: against the same arithmetic on the host (bf16 operands, fp32 everything else)
+    hq, Wq = hb.float().cpu(), Wp.to(BF).float()
+    mu = h.cpu().mean(-1, keepdim=True)
+    rstd = torch.rsqrt(h.cpu().var(-1, unbiased=False, keepdim=True) + eps)
+    pre2 = rstd * (hq @ Wq.t() - mu * cs[None, :]) + bp
+    ref2 = pre2 if epi == 0 else (F.gelu(pre2) if epi == 1 else pre2[:, :N] * F.gelu(pre2[:, N:]))
+    assert _rel(out, ref2)[0] < 2e-5, _rel(out, ref2)
+    if epi == 0 and N % 256 == 0:  # fused [Q|K|V] form: column split + transposed output
+        Mp = ((M + 63) // 64) * 64
+        o1 = torch.empty(M, N // 2, dtype=BF, device=cuda)
+        ot = torch.zeros(N // 2, Mp, dtype=BF, device=cuda)
+        ops.gemm(hb, Wp.to(BF).to(cuda), bias=bp.to(cuda), out_bf16=o1, out_t=ot, n_split=N // 2, ln_stats=stats,
+                 ln_colsum=cs.to(cuda), ln_eps=eps)
+        assert _rel(o1, ref2[:, :N // 2])[0] < 4e-3 and _rel(ot[:, :M].t(), ref2[:, N // 2:])[0] < 4e-3
+
+
 def test_gemm_gelu_and_geglu_epilogues(cuda):
     from sculptmate_amd import _lib, ops
 
@@ -212,7 +273,7 @@ def test_full_size_block_vs_reference_golden(cuda):
     m.to(cuda)
     h = torch.from_numpy(np.random.default_rng(24).standard_normal((3072, 1024), dtype=np.float32)).to(cuda)
     ctx = torch.from_numpy(np.random.default_rng(25).standard_normal((1025, 768), dtype=np.float32)).to(BF).to(cuda)
-    y = m._run_blocks(h.clone(), ctx).cpu().numpy()
+    y = m._run_blocks(m._state_from(h.clone()), ctx)["h"].cpu().numpy()
     got = y.reshape(-1)[g["idx"]]
     rel = np.linalg.norm(got - g["y"]) / np.linalg.norm(g["y"])
     assert rel < 1e-2, rel
