@@ -23,6 +23,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "mc_luts.h"
 
@@ -57,6 +59,13 @@ __constant__ signed char d_cases_classic[256 * 16];
 __constant__ signed char d_test3[24], d_test4[8], d_test6[48 * 3], d_test7[16 * 5], d_test10[6 * 3],
     d_test12[24 * 4], d_test13[2 * 7], d_subconfig13[64];
 
+enum {
+    LUT_CASES = 0, LUT_TEST3 = 512, LUT_TEST4 = 536, LUT_TEST6 = 544, LUT_TEST7 = 688, LUT_TEST10 = 768, LUT_TEST12 = 786,
+    LUT_TEST13 = 882, LUT_SUB13 = 896, LUT_ROWLEN = 960, LUT_INNER = 998, LUT_T1351 = 1036, LUT_BASE = 1048,
+    LUT_ROWBASE = 1124, LUT_ROWMASK = 1200, LUT_MAX_ROWS = 768, LUT_BYTES = LUT_ROWMASK + 2 * LUT_MAX_ROWS
+};
+__device__ __attribute__((aligned(16))) unsigned char d_lut_blob[LUT_BYTES];
+
 static bool g_tables_uploaded[64] = {false};
 
 static int upload_tables() {
@@ -79,9 +88,86 @@ static int upload_tables() {
     UP(d_test13, mc_test13);
     UP(d_subconfig13, mc_subconfig13);
 #undef UP
+    {   // the LDS blob of the classify pass: small tables + per-row edge masks (bit e = the row's triangles use edge e)
+        static unsigned char blob[LUT_BYTES];
+        memset(blob, 0, sizeof(blob));
+        memcpy(blob + LUT_CASES, mc_cases, 512);
+        memcpy(blob + LUT_TEST3, mc_test3, sizeof(mc_test3));
+        memcpy(blob + LUT_TEST4, mc_test4, sizeof(mc_test4));
+        memcpy(blob + LUT_TEST6, mc_test6, sizeof(mc_test6));
+        memcpy(blob + LUT_TEST7, mc_test7, sizeof(mc_test7));
+        memcpy(blob + LUT_TEST10, mc_test10, sizeof(mc_test10));
+        memcpy(blob + LUT_TEST12, mc_test12, sizeof(mc_test12));
+        memcpy(blob + LUT_TEST13, mc_test13, sizeof(mc_test13));
+        memcpy(blob + LUT_SUB13, mc_subconfig13, sizeof(mc_subconfig13));
+        static_assert(sizeof(mc_test3) == 24 && sizeof(mc_test4) == 8 && sizeof(mc_test6) == 144 && sizeof(mc_test7) == 80 &&
+                          sizeof(mc_test10) == 18 && sizeof(mc_test12) == 96 && sizeof(mc_test13) == 14 && sizeof(mc_subconfig13) == 64,
+                      "LUT blob layout");
+        unsigned short *base = reinterpret_cast<unsigned short *>(blob + LUT_BASE);
+        unsigned short *rowbase = reinterpret_cast<unsigned short *>(blob + LUT_ROWBASE);
+        unsigned short *rowmask = reinterpret_cast<unsigned short *>(blob + LUT_ROWMASK);
+        int nrows = 0;
+        for (int t = 0; t < MC_NUM_TILINGS; ++t) {
+            blob[LUT_ROWLEN + t] = mc_tiling_rowlen[t];
+            blob[LUT_INNER + t] = mc_tiling_inner[t];
+            base[t] = mc_tiling_base[t];
+            rowbase[t] = (unsigned short)nrows;
+            const int end = (t + 1 < MC_NUM_TILINGS) ? mc_tiling_base[t + 1] : MC_TILING_FLAT_SIZE;
+            const int rows = (end - mc_tiling_base[t]) / mc_tiling_rowlen[t];
+            for (int r = 0; r < rows; ++r) {
+                unsigned m = 0;
+                for (int i = 0; i < mc_tiling_rowlen[t]; ++i) m |= 1u << mc_tiling_flat[mc_tiling_base[t] + r * mc_tiling_rowlen[t] + i];
+                SC_REQUIRE(nrows < LUT_MAX_ROWS && m < 0x2000u, "marching_cubes: tiling tables do not fit the LUT blob");
+                rowmask[nrows++] = (unsigned short)m;
+            }
+        }
+        for (int i = 0; i < 8; ++i) blob[LUT_T1351 + i] = (unsigned char)mc_tiling_flat[mc_tiling_base[MC_T_13_5_1] + i * 18];
+        SC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_lut_blob), blob, sizeof(blob)));
+    }
     if (dev >= 0 && dev < 64) g_tables_uploaded[dev] = true;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The small look-up tables of the classification, two ways: straight from __constant__ memory (TabConst), or from a
+// 2.7 KiB blob staged in LDS (TabLds, the classify pass): lanes index the tables with different cells' cases, so a
+// __constant__ access is a per-lane vector load with an L2 round trip, and a cell walks through 5-10 DEPENDENT ones.
+// Blob layout (bytes): the tables back to back + per-tiling-row edge masks (see build_lut_blob).
+// ---------------------------------------------------------------------------------------------
+struct TabConst {
+    __device__ int cases(int i) const { return d_cases[i]; }
+    __device__ int test3(int i) const { return d_test3[i]; }
+    __device__ int test4(int i) const { return d_test4[i]; }
+    __device__ int test6(int i) const { return d_test6[i]; }
+    __device__ int test7(int i) const { return d_test7[i]; }
+    __device__ int test10(int i) const { return d_test10[i]; }
+    __device__ int test12(int i) const { return d_test12[i]; }
+    __device__ int test13(int i) const { return d_test13[i]; }
+    __device__ int sub13(int i) const { return d_subconfig13[i]; }
+    __device__ int rowlen(int t) const { return d_tiling_rowlen[t]; }
+    __device__ int inner(int t) const { return d_tiling_inner[t]; }
+    __device__ int base(int t) const { return d_tiling_base[t]; }
+    __device__ int t1351(int i) const { return d_tiling_flat[d_tiling_base[MC_T_13_5_1] + i * 18]; }
+};
+struct TabLds {
+    const unsigned char *b;  // LDS copy of d_lut_blob
+    __device__ int sc(int o) const { return (int)(signed char)b[o]; }
+    __device__ int cases(int i) const { return sc(LUT_CASES + i); }
+    __device__ int test3(int i) const { return sc(LUT_TEST3 + i); }
+    __device__ int test4(int i) const { return sc(LUT_TEST4 + i); }
+    __device__ int test6(int i) const { return sc(LUT_TEST6 + i); }
+    __device__ int test7(int i) const { return sc(LUT_TEST7 + i); }
+    __device__ int test10(int i) const { return sc(LUT_TEST10 + i); }
+    __device__ int test12(int i) const { return sc(LUT_TEST12 + i); }
+    __device__ int test13(int i) const { return sc(LUT_TEST13 + i); }
+    __device__ int sub13(int i) const { return sc(LUT_SUB13 + i); }
+    __device__ int rowlen(int t) const { return b[LUT_ROWLEN + t]; }
+    __device__ int inner(int t) const { return b[LUT_INNER + t]; }
+    __device__ int base(int t) const { return reinterpret_cast<const unsigned short *>(b + LUT_BASE)[t]; }
+    __device__ int t1351(int i) const { return sc(LUT_T1351 + i); }
+    __device__ int rowbase(int t) const { return reinterpret_cast<const unsigned short *>(b + LUT_ROWBASE)[t]; }
+    __device__ unsigned rowmask(int row) const { return reinterpret_cast<const unsigned short *>(b + LUT_ROWMASK)[row]; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // classification (per cell); v[8] = corner values minus level (double), Lewiner corner order
@@ -104,7 +190,8 @@ __device__ bool test_face(const double *v, int face) {
     return rounded(rounded((double)face * A) * acbd) >= 0;
 }
 
-__device__ bool test_internal(const double *v, int mc_case, int config, int subconfig, int s) {
+template <class TAB>
+__device__ bool test_internal(const TAB &T, const double *v, int mc_case, int config, int subconfig, int s) {
     double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
     int test = 0;
 #define MUL(a, b) rounded((a) * (b))
@@ -123,31 +210,36 @@ __device__ bool test_internal(const double *v, int mc_case, int config, int subc
         Dt = ADD(v[1], MUL(SUB(v[5], v[1]), t));
     } else {
         int edge;
-        if (mc_case == 6) edge = d_test6[config * 3 + 2];
-        else if (mc_case == 7) edge = d_test7[config * 5 + 4];
-        else if (mc_case == 12) edge = d_test12[config * 4 + 3];
-        else edge = d_tiling_flat[d_tiling_base[MC_T_13_5_1] + (config * 4 + subconfig) * 18];
-        // reference edge e from corner a to corner b; the three "parallel" edges (p0,p1),(q0,q1),(r0,r1)
-        int ea, eb, p0, p1, q0, q1, r0, r1;
+        if (mc_case == 6) edge = T.test6(config * 3 + 2);
+        else if (mc_case == 7) edge = T.test7(config * 5 + 4);
+        else if (mc_case == 12) edge = T.test12(config * 4 + 3);
+        else edge = T.t1351(config * 4 + subconfig);
+        // reference edge e from corner a to corner b; the three "parallel" edges (p0,p1),(q0,q1),(r0,r1).
+        // The corner VALUES are picked inside the switch (static indices only): with v[ea] ... v[r1] indexed by run-time
+        // corner numbers the compiler keeps v[] in scratch memory, and every access of the classification -- the static
+        // ones too -- becomes a ~1 us scratch round trip (the classify pass spent 100 of its 190 us there).
+        double Ea, Eb, P0, P1, Q0, Q1, R0, R1;
+#define PICK(a, b, c, d, e, f, gq, h) Ea = v[a]; Eb = v[b]; P0 = v[c]; P1 = v[d]; Q0 = v[e]; Q1 = v[f]; R0 = v[gq]; R1 = v[h]
         switch (edge) {
-            case 0: ea = 0; eb = 1; p0 = 3; p1 = 2; q0 = 7; q1 = 6; r0 = 4; r1 = 5; break;
-            case 1: ea = 1; eb = 2; p0 = 0; p1 = 3; q0 = 4; q1 = 7; r0 = 5; r1 = 6; break;
-            case 2: ea = 2; eb = 3; p0 = 1; p1 = 0; q0 = 5; q1 = 4; r0 = 6; r1 = 7; break;
-            case 3: ea = 3; eb = 0; p0 = 2; p1 = 1; q0 = 6; q1 = 5; r0 = 7; r1 = 4; break;
-            case 4: ea = 4; eb = 5; p0 = 7; p1 = 6; q0 = 3; q1 = 2; r0 = 0; r1 = 1; break;
-            case 5: ea = 5; eb = 6; p0 = 4; p1 = 7; q0 = 0; q1 = 3; r0 = 1; r1 = 2; break;
-            case 6: ea = 6; eb = 7; p0 = 5; p1 = 4; q0 = 1; q1 = 0; r0 = 2; r1 = 3; break;
-            case 7: ea = 7; eb = 4; p0 = 6; p1 = 5; q0 = 2; q1 = 1; r0 = 3; r1 = 0; break;
-            case 8: ea = 0; eb = 4; p0 = 3; p1 = 7; q0 = 2; q1 = 6; r0 = 1; r1 = 5; break;
-            case 9: ea = 1; eb = 5; p0 = 0; p1 = 4; q0 = 3; q1 = 7; r0 = 2; r1 = 6; break;
-            case 10: ea = 2; eb = 6; p0 = 1; p1 = 5; q0 = 0; q1 = 4; r0 = 3; r1 = 7; break;
-            default: ea = 3; eb = 7; p0 = 2; p1 = 6; q0 = 1; q1 = 5; r0 = 0; r1 = 4; break;  // 11
+            case 0: PICK(0, 1, 3, 2, 7, 6, 4, 5); break;
+            case 1: PICK(1, 2, 0, 3, 4, 7, 5, 6); break;
+            case 2: PICK(2, 3, 1, 0, 5, 4, 6, 7); break;
+            case 3: PICK(3, 0, 2, 1, 6, 5, 7, 4); break;
+            case 4: PICK(4, 5, 7, 6, 3, 2, 0, 1); break;
+            case 5: PICK(5, 6, 4, 7, 0, 3, 1, 2); break;
+            case 6: PICK(6, 7, 5, 4, 1, 0, 2, 3); break;
+            case 7: PICK(7, 4, 6, 5, 2, 1, 3, 0); break;
+            case 8: PICK(0, 4, 3, 7, 2, 6, 1, 5); break;
+            case 9: PICK(1, 5, 0, 4, 3, 7, 2, 6); break;
+            case 10: PICK(2, 6, 1, 5, 0, 4, 3, 7); break;
+            default: PICK(3, 7, 2, 6, 1, 5, 0, 4); break;  // 11
         }
-        t = v[ea] / ADD(SUB(v[ea], v[eb]), MC_EPS);
+#undef PICK
+        t = Ea / ADD(SUB(Ea, Eb), MC_EPS);
         At = 0;
-        Bt = ADD(v[p0], MUL(SUB(v[p1], v[p0]), t));
-        Ct = ADD(v[q0], MUL(SUB(v[q1], v[q0]), t));
-        Dt = ADD(v[r0], MUL(SUB(v[r1], v[r0]), t));
+        Bt = ADD(P0, MUL(SUB(P1, P0), t));
+        Ct = ADD(Q0, MUL(SUB(Q1, Q0), t));
+        Dt = ADD(R0, MUL(SUB(R1, R0), t));
     }
     if (At >= 0) test += 1;
     if (Bt >= 0) test += 2;
@@ -172,7 +264,9 @@ struct Tiling {
     int len;
 };
 
-__device__ Tiling classify(const double *v, bool classic) {
+// row_out (optional): index of the chosen tiling row among all rows of all tables (TabLds::rowmask), -1 for classic
+template <class TAB>
+__device__ Tiling classify(const TAB &T, const double *v, bool classic, int *row_out = nullptr) {
     int index = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) index |= (v[k] > 0.0) ? (1 << k) : 0;
@@ -186,24 +280,25 @@ __device__ Tiling classify(const double *v, bool classic) {
         while (n < 16 && d_cases_classic[16 * index + n] != -1) ++n;
         out.ofs = -(16 * index) - 1;
         out.len = n;
+        if (row_out) *row_out = -1;
         return out;
     }
-    const int c = d_cases[2 * index], cfg = d_cases[2 * index + 1];
+    const int c = T.cases(2 * index), cfg = T.cases(2 * index + 1);
     int table = -1, sub = 0, sc = 0;
     switch (c) {
         case 1: table = MC_T_1; break;
         case 2: table = MC_T_2; break;
-        case 3: table = test_face(v, d_test3[cfg]) ? MC_T_3_2 : MC_T_3_1; break;
-        case 4: table = test_internal(v, c, cfg, 0, d_test4[cfg]) ? MC_T_4_1 : MC_T_4_2; break;
+        case 3: table = test_face(v, T.test3(cfg)) ? MC_T_3_2 : MC_T_3_1; break;
+        case 4: table = test_internal(T, v, c, cfg, 0, T.test4(cfg)) ? MC_T_4_1 : MC_T_4_2; break;
         case 5: table = MC_T_5; break;
         case 6:
-            if (test_face(v, d_test6[cfg * 3 + 0])) table = MC_T_6_2;
-            else table = test_internal(v, c, cfg, 0, d_test6[cfg * 3 + 1]) ? MC_T_6_1_1 : MC_T_6_1_2;
+            if (test_face(v, T.test6(cfg * 3 + 0))) table = MC_T_6_2;
+            else table = test_internal(T, v, c, cfg, 0, T.test6(cfg * 3 + 1)) ? MC_T_6_1_1 : MC_T_6_1_2;
             break;
         case 7:
-            if (test_face(v, d_test7[cfg * 5 + 0])) sc += 1;
-            if (test_face(v, d_test7[cfg * 5 + 1])) sc += 2;
-            if (test_face(v, d_test7[cfg * 5 + 2])) sc += 4;
+            if (test_face(v, T.test7(cfg * 5 + 0))) sc += 1;
+            if (test_face(v, T.test7(cfg * 5 + 1))) sc += 2;
+            if (test_face(v, T.test7(cfg * 5 + 2))) sc += 4;
             switch (sc) {
                 case 0: table = MC_T_7_1; break;
                 case 1: table = MC_T_7_2; sub = 0; break;
@@ -212,33 +307,33 @@ __device__ Tiling classify(const double *v, bool classic) {
                 case 4: table = MC_T_7_2; sub = 2; break;
                 case 5: table = MC_T_7_3; sub = 1; break;
                 case 6: table = MC_T_7_3; sub = 2; break;
-                default: table = test_internal(v, c, cfg, sc, d_test7[cfg * 5 + 3]) ? MC_T_7_4_2 : MC_T_7_4_1; break;
+                default: table = test_internal(T, v, c, cfg, sc, T.test7(cfg * 5 + 3)) ? MC_T_7_4_2 : MC_T_7_4_1; break;
             }
             break;
         case 8: table = MC_T_8; break;
         case 9: table = MC_T_9; break;
         case 10:
-            if (test_face(v, d_test10[cfg * 3 + 0])) table = test_face(v, d_test10[cfg * 3 + 1]) ? MC_T_10_1_1_ : MC_T_10_2;
-            else if (test_face(v, d_test10[cfg * 3 + 1])) table = MC_T_10_2_;
-            else table = test_internal(v, c, cfg, 0, d_test10[cfg * 3 + 2]) ? MC_T_10_1_1 : MC_T_10_1_2;
+            if (test_face(v, T.test10(cfg * 3 + 0))) table = test_face(v, T.test10(cfg * 3 + 1)) ? MC_T_10_1_1_ : MC_T_10_2;
+            else if (test_face(v, T.test10(cfg * 3 + 1))) table = MC_T_10_2_;
+            else table = test_internal(T, v, c, cfg, 0, T.test10(cfg * 3 + 2)) ? MC_T_10_1_1 : MC_T_10_1_2;
             break;
         case 11: table = MC_T_11; break;
         case 12:
-            if (test_face(v, d_test12[cfg * 4 + 0])) table = test_face(v, d_test12[cfg * 4 + 1]) ? MC_T_12_1_1_ : MC_T_12_2;
-            else if (test_face(v, d_test12[cfg * 4 + 1])) table = MC_T_12_2_;
-            else table = test_internal(v, c, cfg, 0, d_test12[cfg * 4 + 2]) ? MC_T_12_1_1 : MC_T_12_1_2;
+            if (test_face(v, T.test12(cfg * 4 + 0))) table = test_face(v, T.test12(cfg * 4 + 1)) ? MC_T_12_1_1_ : MC_T_12_2;
+            else if (test_face(v, T.test12(cfg * 4 + 1))) table = MC_T_12_2_;
+            else table = test_internal(T, v, c, cfg, 0, T.test12(cfg * 4 + 2)) ? MC_T_12_1_1 : MC_T_12_1_2;
             break;
         case 13:
             for (int k = 0; k < 6; ++k)
-                if (test_face(v, d_test13[cfg * 7 + k])) sc += 1 << k;
-            sc = d_subconfig13[sc];
+                if (test_face(v, T.test13(cfg * 7 + k))) sc += 1 << k;
+            sc = T.sub13(sc);
             if (sc == 0) table = MC_T_13_1;
             else if (sc <= 6) { table = MC_T_13_2; sub = sc - 1; }
             else if (sc <= 18) { table = MC_T_13_3; sub = sc - 7; }
             else if (sc <= 22) { table = MC_T_13_4; sub = sc - 19; }
             else if (sc <= 26) {
                 sub = sc - 23;
-                table = test_internal(v, c, cfg, sub, d_test13[cfg * 7 + 6]) ? MC_T_13_5_1 : MC_T_13_5_2;
+                table = test_internal(T, v, c, cfg, sub, T.test13(cfg * 7 + 6)) ? MC_T_13_5_1 : MC_T_13_5_2;
             } else if (sc <= 38) { table = MC_T_13_3_; sub = sc - 27; }
             else if (sc <= 44) { table = MC_T_13_2_; sub = sc - 39; }
             else if (sc == 45) table = MC_T_13_1_;
@@ -247,9 +342,11 @@ __device__ Tiling classify(const double *v, bool classic) {
         default: break;
     }
     if (table < 0) return out;
-    const int rowlen = d_tiling_rowlen[table];
-    out.ofs = d_tiling_base[table] + (cfg * d_tiling_inner[table] + sub) * rowlen;
+    const int rowlen = T.rowlen(table);
+    const int r = cfg * T.inner(table) + sub;
+    out.ofs = T.base(table) + r * rowlen;
     out.len = rowlen;
+    if (row_out) *row_out = table * 1024 + r;  // (table, row in table); TabLds turns it into a global row index
     return out;
 }
 
@@ -498,7 +595,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
         const int cx = x - (int)threadIdx.x + xl;  // same row segment
         double v[8];
         load_cell(vol, g, z, y, cx, level, v);
-        const Tiling t = classify(v, classic != 0);
+        const Tiling t = classify(TabConst(), v, classic != 0);
         packed = cell_counts(t, cx, y, z, g.halo_low);
         const unsigned ofs = t.ofs < 0 ? (unsigned)(-t.ofs - 1) : (unsigned)t.ofs;
         w0 = (unsigned)xl | ((unsigned)t.len << 8) | ((t.ofs < 0 ? 1u : 0u) << 15) | (ofs << 16);
@@ -515,6 +612,210 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_kernel(const float *__re
         block_counts[blockIdx.x] = total;
         block_nact[blockIdx.x] = nact;
         block_minmax[blockIdx.x] = make_float2(mn, mx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pass 1, brick form (round 2).  One workgroup classifies a BRICK of MC_TZ x MC_TY rows of cells (16 "virtual
+// blocks" of the row-per-workgroup scheme above: same records, same per-row counts, so the scans and the emit
+// passes are unchanged):
+//   1. the (MC_TZ+1) x (MC_TY+1) lattice rows the brick touches are staged ONCE into LDS with coalesced 1-KiB row
+//      loads (the row-per-workgroup form issued 8 loads per cell and fetched every row from 4 workgroups on up to
+//      4 XCDs: 3x the volume in L2 misses); workgroups of one XCD take a contiguous range of bricks, so the rows two
+//      neighbouring bricks share along y hit that XCD's L2;
+//   2. sign patterns from LDS, one wave per row (no cross-wave exchange): ballot + popcount append the active
+//      cells of the row to its list;
+//   3. the expensive part -- Lewiner face / interior tests in fp64, triangle and owned-vertex counts -- runs over
+//      the active cells of the WHOLE brick packed onto consecutive lanes (a row segment has ~13 active cells on a
+//      typical surface: 1/20 of a workgroup; a brick ~200), corners read from LDS;
+//   4. per-row exclusive prefix of the counts (one wave per row) and the record stores.
+static constexpr int MC_TZ = 4, MC_TY = 4, MC_ROWS = MC_TZ * MC_TY;
+static constexpr int MC_SRC_LD = 260;  // floats per staged lattice row (257 used)
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float *__restrict__ vol, Grid g, float levelf,
+                                                                     double level, int classic, int nby, int bpr, int dbg,
+                                                                     CellRec *__restrict__ recs,
+                                                                     int *__restrict__ block_counts,
+                                                                     int *__restrict__ block_nact,
+                                                                     float2 *__restrict__ block_minmax,
+                                                                     McHeader *__restrict__ hdr) {
+    constexpr int NSRC = (MC_TZ + 1) * (MC_TY + 1);
+    constexpr int NCH = MC_BLOCK / 64;  // 64-value chunks of a row (= waves of the workgroup)
+    // 38 KiB in all: four workgroups per CU
+    __shared__ float s_src[NSRC * MC_SRC_LD];
+    __shared__ unsigned long long s_mask[NSRC][NCH + 1];  // bit-planes "value > level" of the staged rows (+ the 257th value)
+    __shared__ unsigned char s_list[MC_ROWS][MC_BLOCK];
+    __shared__ unsigned char s_pk[MC_ROWS * MC_BLOCK];    // triangles | owned vertices << 4 of the packed active cells
+    __shared__ int s_cnt[MC_ROWS];
+    __shared__ float s_mn[MC_BLOCK / 64], s_mx[MC_BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) unsigned char s_lut[LUT_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static_assert(LUT_BYTES % 16 == 0 && LUT_BYTES / 16 <= MC_BLOCK, "one 16-byte piece of the LUT blob per thread");
+    if (tid < LUT_BYTES / 16) reinterpret_cast<uint4 *>(s_lut)[tid] = reinterpret_cast<const uint4 *>(d_lut_blob)[tid];
+    // brick of this workgroup (XCD-contiguous order; bricks run seg fastest, then y, then z)
+    const int brick = xcd_tile(blockIdx.x, gridDim.x);
+    const int seg = brick % bpr, by = (brick / bpr) % nby, bz = brick / (bpr * nby);
+    const int z0 = bz * MC_TZ, y0 = by * MC_TY, x0 = seg * MC_BLOCK;
+    const int nz = min(MC_TZ, g.c0 - z0), ny = min(MC_TY, g.c1 - y0), nx = min(MC_BLOCK, g.c2 - x0);  // cells
+    // ---- 1. stage the lattice rows: row (dz, dy), dz <= nz, dy <= ny, values x0 .. x0 + nx; the compare "value > level"
+    // of a wave's 64 values IS its ballot, so the sign pass below works on 64-bit planes instead of on floats
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    bool nan = false;
+    {
+        float val[NSRC], edge = 0.f;
+        const long sy = g.n2, sz = (long)g.n1 * g.n2;
+        const float *base = vol + z0 * sz + y0 * sy + x0;
+#pragma unroll
+        for (int r = 0; r < NSRC; ++r) {
+            const int dz = r / (MC_TY + 1), dy = r % (MC_TY + 1);
+            const bool in = dz <= nz && dy <= ny;  // workgroup-uniform
+            // lanes beyond the row read its last value again (finite, in range): min / max / NaN need no extra mask
+            val[r] = in ? base[dz * sz + dy * sy + min(tid, nx)] : 0.f;
+        }
+        if (tid < NSRC) {  // the 257th value of every row (only present when the segment is full)
+            const int dz = tid / (MC_TY + 1), dy = tid % (MC_TY + 1);
+            if (dz <= nz && dy <= ny) edge = base[dz * sz + dy * sy + nx];
+        }
+#pragma unroll
+        for (int r = 0; r < NSRC; ++r) {
+            const int dz = r / (MC_TY + 1), dy = r % (MC_TY + 1);
+            if (dz <= nz && dy <= ny) {
+                mn = fminf(mn, val[r]);
+                mx = fmaxf(mx, val[r]);
+                nan |= val[r] != val[r];
+            }
+            s_src[r * MC_SRC_LD + tid] = val[r];
+            const unsigned long long bal = __ballot(val[r] > levelf);  // == ((double)f - level > 0): levelf = largest float <= level
+            if (lane == 0) s_mask[r][wave] = bal;
+        }
+        if (tid < NSRC) {
+            const int dz = tid / (MC_TY + 1), dy = tid % (MC_TY + 1);
+            if (dz <= nz && dy <= ny) {
+                mn = fminf(mn, edge);
+                mx = fmaxf(mx, edge);
+                nan |= edge != edge;
+            }
+            s_src[tid * MC_SRC_LD + nx] = edge;  // nx == 256: the extra column; nx < 256: rewrites the same value
+            s_mask[tid][NCH] = (edge > levelf) ? 1ull : 0ull;
+        }
+    }
+    if (nan) hdr->nan_seen = 1u;  // fminf/fmaxf drop NaN silently; a plain racing store of 1 is enough
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, d, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    }
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
+    // ---- 2. active cells, one wave per row of cells: a cell is active unless its 8 corner bits are equal.  Corner bits of
+    // the 64 cells of a chunk = the planes of the 4 lattice rows at x (m) and at x + 1 (m shifted, bit 63 from the next chunk)
+    for (int lr = wave; lr < MC_ROWS; lr += MC_BLOCK / 64) {
+        const int dz = lr / MC_TY, dy = lr % MC_TY;
+        int n = 0;
+        if (dz < nz && dy < ny && !(dbg & 4)) {
+            const int r00 = dz * (MC_TY + 1) + dy;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                unsigned long long any = 0ull, all = ~0ull;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r00 + (q & 1) + (q >> 1) * (MC_TY + 1);
+                    const unsigned long long m = s_mask[r][c], m1 = (m >> 1) | (s_mask[r][c + 1] << 63);
+                    any |= m | m1;
+                    all &= m & m1;
+                }
+                const int left = nx - c * 64;  // cells of this chunk inside the grid
+                const unsigned long long valid = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
+                const unsigned long long act = any & ~all & valid;
+                if ((act >> lane) & 1ull) s_list[lr][n + __popcll(act & ((1ull << lane) - 1ull))] = (unsigned char)(c * 64 + lane);
+                n += __popcll(act);
+            }
+        }
+        if (lane == 0) s_cnt[lr] = n;
+    }
+    __syncthreads();
+    // ---- 3. dense classification over the packed active cells of the brick
+    int pre[MC_ROWS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < MC_ROWS; ++r) pre[r + 1] = pre[r] + s_cnt[r];
+    const int total_active = pre[MC_ROWS];
+    const TabLds T{s_lut};
+    for (int p = tid; p < total_active; p += MC_BLOCK) {
+        int lr = 0;
+#pragma unroll
+        for (int r = 1; r < MC_ROWS; ++r) lr += (p >= pre[r]) ? 1 : 0;
+        int start = 0;
+#pragma unroll
+        for (int r = 0; r < MC_ROWS; ++r) start = (r == lr) ? pre[r] : start;
+        const int dz = lr / MC_TY, dy = lr % MC_TY;
+        const int xl = s_list[lr][p - start];
+        const float *r00 = s_src + (dz * (MC_TY + 1) + dy) * MC_SRC_LD + xl, *r01 = r00 + MC_SRC_LD;
+        const float *r10 = r00 + (MC_TY + 1) * MC_SRC_LD, *r11 = r10 + MC_SRC_LD;
+        // Lewiner corner order (load_cell): 0 (z,y,x) 1 (z,y,x+1) 2 (z,y+1,x+1) 3 (z,y+1,x) 4..7 the same at z+1
+        double v[8];
+        v[0] = (double)r00[0] - level; v[1] = (double)r00[1] - level; v[2] = (double)r01[1] - level; v[3] = (double)r01[0] - level;
+        v[4] = (double)r10[0] - level; v[5] = (double)r10[1] - level; v[6] = (double)r11[1] - level; v[7] = (double)r11[0] - level;
+        Tiling t;
+        t.ofs = 0; t.len = 0;
+        int row = -1;
+        if (!(dbg & 1)) t = classify(T, v, classic != 0, &row);
+        const int cx = x0 + xl, cy = y0 + dy, cz = z0 + dz;
+        int counts;
+        if (row < 0) {
+            counts = cell_counts(t, cx, cy, cz, g.halo_low);  // classic tables (or inactive): the entry walk
+        } else {
+            // owned vertices = edges of the row's triangles (bit mask) that no earlier cell of the sweep touches (owns_edge)
+            unsigned own = 0x1460u;                               // edges 5, 6, 10 and the centre vertex 12: always
+            if (cx == 0) own |= 0x0880u;                          // 7, 11
+            if (cy == 0) own |= 0x0210u;                          // 4, 9
+            if (cz == 0) own |= 0x0006u;                          // 1, 2
+            if (cy == 0 && cz == 0) own |= 0x0001u;               // 0
+            if (cx == 0 && cz == 0) own |= 0x0008u;               // 3
+            if (cx == 0 && cy == 0) own |= 0x0100u;               // 8
+            if (g.halo_low && cz == 0) own &= ~0x000fu;           // slab mode: plane 0's x/y edges belong to the previous slab
+            const unsigned used = T.rowmask(T.rowbase(row >> 10) + (row & 1023));
+            counts = (t.len / 3) | (__popc(used & own) << 16);
+        }
+        if (dbg & 2) counts = 0;
+        s_pk[p] = (unsigned char)((counts & 15) | ((counts >> 16) << 4));  // <= 12 triangles, <= 13 owned vertices
+        const unsigned ofs = t.ofs < 0 ? (unsigned)(-t.ofs - 1) : (unsigned)t.ofs;
+        const long blk = ((long)cz * g.c1 + cy) * bpr + seg;
+        recs[blk * MC_BLOCK + (p - start)].w0 = (unsigned)xl | ((unsigned)t.len << 8) | ((t.ofs < 0 ? 1u : 0u) << 15) | (ofs << 16);
+    }
+    __syncthreads();
+    // ---- 4. per-row exclusive prefix (one wave per row) and the records of the row's virtual block
+    float bmn = FLT_MAX, bmx = -FLT_MAX;
+#pragma unroll
+    for (int w = 0; w < MC_BLOCK / 64; ++w) { bmn = fminf(bmn, s_mn[w]); bmx = fmaxf(bmx, s_mx[w]); }
+    for (int lr = wave; lr < MC_ROWS; lr += MC_BLOCK / 64) {
+        const int dz = lr / MC_TY, dy = lr % MC_TY;
+        if (dz >= nz || dy >= ny) continue;
+        const long blk = ((long)(z0 + dz) * g.c1 + (y0 + dy)) * bpr + seg;
+        int start = 0;
+#pragma unroll
+        for (int r = 0; r < MC_ROWS; ++r) start = (r == lr) ? pre[r] : start;
+        const int n = s_cnt[lr];
+        int carry = 0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            const int b = k < n ? s_pk[start + k] : 0;
+            const int val = (b & 15) | ((b >> 4) << 16);
+            int inc = val;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += up;
+            }
+            if (k < n) recs[blk * MC_BLOCK + k].w1 = (unsigned)(carry + inc - val);
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) {
+            block_counts[blk] = carry;
+            block_nact[blk] = n;
+            // the brick's min / max on its first row, neutral elements on the others (the scans only reduce them)
+            block_minmax[blk] = lr == 0 ? make_float2(bmn, bmx) : make_float2(FLT_MAX, -FLT_MAX);
+        }
     }
 }
 
@@ -870,9 +1171,18 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsi
     // float f > double level  <=>  f > (largest float <= level): the sign pass needs no fp64
     float levelf = (float)level;
     if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
-    hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
-                       reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
-                       reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr);
+    static const int old_classify = [] { const char *e = getenv("SCULPT_MC_CLASSIFY_ROWS"); return e ? atoi(e) : 0; }();
+    if (old_classify) {
+        hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
+                           reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
+                           reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr);
+    } else {
+        const int bpr = cdiv(g.c2, MC_BLOCK), nby = cdiv(g.c1, MC_TY), nbz = cdiv(g.c0, MC_TZ);
+        static const int dbg = [] { const char *e = getenv("SCULPT_MC_DBG"); return e ? atoi(e) : 0; }();  // timing ablations only
+        hipLaunchKernelGGL(mc_classify_brick_kernel, dim3(bpr * nby * nbz), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
+                           nby, bpr, dbg, reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
+                           reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr);
+    }
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(w.ngroups), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
                        reinterpret_cast<const float2 *>(ws + w.off_minmax), w.nblocks,

@@ -34,7 +34,8 @@ def attn_case(name, Tq, Tk, heads, count):
     return us * count
 
 tot = 0
-tot += gemm_case("bb self qk", 3072, 2048, 1024, 0, 16)
+tot += gemm_case("bb self qkv", 3072, 3072, 1024, 0, 16)
+tot += gemm_case("bb cross kv all", 1025, 32768, 768, 0, 1)
 tot += gemm_case("bb self v / q / o (x5)", 3072, 1024, 1024, 0, 16 * 5)
 tot += gemm_case("bb cross k,v", 1025, 1024, 768, 0, 32)
 tot += gemm_case("bb ff1 geglu", 3072, 4096, 1024, 2, 16)
