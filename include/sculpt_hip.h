@@ -50,6 +50,12 @@ int sculpt_version(void);
 const char *sculpt_last_error(void);
 /* number of visible HIP devices (0 if none); never fails */
 int sculpt_device_count(void);
+/* A HIP stream whose kernels run only on CUs [first_cu, first_cu + n_cus) of the current device (hipExtStreamCreateWithCUMask;
+ * the driver stripes the CU numbering over the 8 XCDs, so a contiguous range takes the same share of every XCD): lets the
+ * MFMA-bound density grid of image i and the latency-bound transformer of image i+1 run side by side on disjoint CUs
+ * (tools/try_cumask.py).  Destroy with sculpt_stream_destroy. */
+int sculpt_stream_create_cu_mask(int first_cu, int n_cus, sculpt_stream_t *stream_out);
+int sculpt_stream_destroy(sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * NeRF decoder weights.  The reference MLP is Linear(3*C,64)+SiLU, NH x [Linear(64,64)+SiLU],

@@ -36,6 +36,8 @@ SIGNATURES = {
     "sculpt_version": (_i, []),
     "sculpt_last_error": (ctypes.c_char_p, []),
     "sculpt_device_count": (_i, []),
+    "sculpt_stream_create_cu_mask": (_i, [_i, _i, _pp]),
+    "sculpt_stream_destroy": (_i, [_vp]),
     "sculpt_mlp_packed_bytes": (_sz, [_i, _i]),
     "sculpt_mlp_pack": (_i, [_pp, _pp, _i, _vp, _vp, _sz]),
     "sculpt_triplane_query": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),

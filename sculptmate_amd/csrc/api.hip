@@ -43,4 +43,21 @@ int sculpt_device_count(void) {
     return n;
 }
 
+int sculpt_stream_create_cu_mask(int first_cu, int n_cus, sculpt_stream_t *stream_out) {
+    SC_REQUIRE(stream_out && first_cu >= 0 && n_cus >= 1, "stream_create_cu_mask: bad arguments");
+    const int total = sculpt::num_cus();
+    SC_REQUIRE(first_cu + n_cus <= total, "stream_create_cu_mask: CUs [%d, %d) of %d", first_cu, first_cu + n_cus, total);
+    uint32_t mask[16] = {0};  // up to 512 CUs; bit i = CU i in the driver's enumeration (striped over the XCDs)
+    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    SC_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)((total + 31) / 32), mask));
+    *stream_out = reinterpret_cast<sculpt_stream_t>(st);
+    return 0;
+}
+
+int sculpt_stream_destroy(sculpt_stream_t stream) {
+    SC_HIP(hipStreamDestroy(sculpt::as_stream(stream)));
+    return 0;
+}
+
 }  // extern "C"

@@ -1,0 +1,18 @@
+"""sanitizer run of the CPU checker (GPU AddressSanitizer is not available on the pool).
+`make -C oracle asan` compiles the three oracle sources + oracle/asan_check.c under -fsanitize=address,undefined and runs the
+driver over ragged / minimal / noisy / constant volumes, border and out-of-range query points and a tiny UV bake."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None or shutil.which("make") is None, reason="needs gcc + make")
+def test_oracle_is_clean_under_asan_and_ubsan():
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "asan_check ok" in p.stdout
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
