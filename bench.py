@@ -30,7 +30,9 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling
+FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling (ALGORITHMIC, what `roofline.achieved` uses)
+EXECUTED_FLOP_PER_POINT = 65.5e3  # on the matrix pipe: 8 hidden 64x64 layers (layer 0 is hoisted into the separable plane
+                                  # tables, the last layer is a VALU dot): what `roofline.executed_frac` uses
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (only used with --decoder-precision bf16x3)
 MC_RES = 256
@@ -412,7 +414,10 @@ def main():
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None if x3 else traffic,
                          "traffic_source": None if x3 else traffic_src,
-                         "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3},
+                         "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3,
+                         # the algorithmic count includes the layer-0 work the separable tables remove, so `frac` can pass 1;
+                         # the fraction of the fp32 matrix peak the kernel's own MFMA instructions reach:
+                         "executed_frac": None if x3 else EXECUTED_FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12 / peak},
             "latency_ms_per_image": elapsed / args.steps * 1e3,  # steps run back to back, one image in flight: step time = latency
         }
         with torch.no_grad():

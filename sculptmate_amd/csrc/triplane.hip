@@ -28,7 +28,7 @@
 namespace sculpt {
 
 static constexpr int HID = 64;          // hidden width (n_neurons)
-static constexpr uint32_t PACK_MAGIC = 0x53434d4cu;  // "SCML"
+static constexpr uint32_t PACK_MAGIC = 0x53434d32u;  // "SCM2": activations scaled by log2(e), see silu_f
 
 struct MlpPackHeader {
     uint32_t magic;
@@ -85,27 +85,33 @@ static void pack_layout(int K0, int NH, MlpPackHeader *hd) {
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float silu_f(float x) {
-    // x * sigmoid(x); exp via v_exp_f32 (exp2), reciprocal via v_rcp_f32 (1 ulp each)
-    float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+// Activations are carried SCALED by log2(e): with y = x * log2(e),
+//     silu(x) * log2(e) = y / (1 + 2^-y)
+// so v_exp_f32 (a base-2 exponential) takes -y directly (free source modifier) and the `x * -log2(e)` multiply of the
+// textbook form disappears.  The scale is folded into the weights once, at pack time (sculpt_mlp_pack): layer 0 (weights
+// and bias) x log2(e), every hidden bias x log2(e), the last layer's weights x ln(2); the hidden weights are untouched
+// (W . (silu(x) log2e) + b log2e = log2e (W . silu(x) + b)).  Operands stay full fp32; the result differs from the unscaled
+// evaluation by fp32 rounding only (tests/test_gpu_triplane.py tolerance unchanged).
+__device__ __forceinline__ float silu_f(float y) {
+    // y / (1 + 2^-y); v_exp_f32 and v_rcp_f32 are 1 ulp each
+    const float e = __builtin_amdgcn_exp2f(-y);
+    return y * __builtin_amdgcn_rcpf(1.0f + e);
 }
 typedef float tf32x2 __attribute__((ext_vector_type(2)));
-// 16 SiLUs with the three full-rate operations on PAIRS (v_pk_mul / v_pk_add / v_pk_mul: bit-identical to the scalar
-// forms): every VALU instruction, transcendental or not, takes the fp32 matrix pipe's issue slot for ~4 cycles
-// (measured: replacing v_rcp by 7 plain ops costs +8 %, sharing one v_rcp per pair at +3 plain ops costs +2 %), so
-// the lever is the instruction COUNT: 5 -> 3.5 per value (-1.7 % kernel time).
+// 16 SiLUs with the two full-rate operations on PAIRS (v_pk_add / v_pk_mul: bit-identical to the scalar forms): every VALU
+// instruction, transcendental or not, takes the fp32 matrix pipe's issue slot for ~4 cycles (measured: replacing v_rcp by 7
+// plain ops costs +8 %, sharing one v_rcp per pair at +3 plain ops costs +2 %), so the lever is the instruction COUNT:
+// 5 (scalar textbook form) -> 3.5 (pairs) -> 3 per value (log2e folded into the weights).
 __device__ __forceinline__ f32x16 silu16(f32x16 v) {
     f32x16 o;
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
-        tf32x2 x = {v[i], v[i + 1]};
-        const tf32x2 k = {-1.44269504088896340736f, -1.44269504088896340736f}, one = {1.0f, 1.0f};
-        tf32x2 t = x * k;
-        tf32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-        tf32x2 d = e + one;
-        tf32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        tf32x2 y = x * r;
+        const tf32x2 x = {v[i], v[i + 1]};
+        const tf32x2 one = {1.0f, 1.0f};
+        const tf32x2 e = {__builtin_amdgcn_exp2f(-x[0]), __builtin_amdgcn_exp2f(-x[1])};
+        const tf32x2 d = e + one;
+        const tf32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const tf32x2 y = x * r;
         o[i] = y[0]; o[i + 1] = y[1];
     }
     return o;
@@ -710,17 +716,20 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
     float *o = reinterpret_cast<float *>(packed_host);
     memset(o, 0, (size_t)hd.total_floats * 4);
     memcpy(o, &hd, sizeof(hd));
-    memcpy(o + hd.off_w0raw, Wh[0], sizeof(float) * HID * K0);
-    memcpy(o + hd.off_b0raw, bh[0], sizeof(float) * HID);
+    // activations are carried scaled by log2(e) (silu_f): fold the scale into layer 0, the hidden biases and the last layer
+    const double LOG2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
+    auto up = [&](float w) { return (float)((double)w * LOG2E); };
+    for (size_t i = 0; i < (size_t)HID * K0; ++i) o[hd.off_w0raw + i] = up(Wh[0][i]);
+    for (int i = 0; i < HID; ++i) o[hd.off_b0raw + i] = up(bh[0][i]);
     const int S0 = K0 / 2;
     for (int T = 0; T < 2; ++T)
         for (int s = 0; s < S0; ++s)
             for (int lane = 0; lane < 64; ++lane)
-                o[hd.off_a0 + (T * S0 + s) * 64 + lane] = Wh[0][(size_t)(32 * T + (lane & 31)) * K0 + (lane >> 5) * S0 + s];
+                o[hd.off_a0 + (T * S0 + s) * 64 + lane] = up(Wh[0][(size_t)(32 * T + (lane & 31)) * K0 + (lane >> 5) * S0 + s]);
     for (int l = 0; l <= NH; ++l)
         for (int h = 0; h < 2; ++h)
             for (int t = 0; t < 2; ++t)
-                for (int r = 0; r < 16; ++r) o[hd.off_bacc + ((l * 2 + h) * 2 + t) * 16 + r] = bh[l][nrow(t, r, h)];
+                for (int r = 0; r < 16; ++r) o[hd.off_bacc + ((l * 2 + h) * 2 + t) * 16 + r] = up(bh[l][nrow(t, r, h)]);
     for (int l = 0; l < NH; ++l) {
         const float *Wl = Wh[l + 1];
         for (int T = 0; T < 2; ++T)
@@ -735,7 +744,8 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
     for (int oo = 0; oo < 4; ++oo)
         for (int h = 0; h < 2; ++h)
             for (int t = 0; t < 2; ++t)
-                for (int r = 0; r < 16; ++r) o[hd.off_wlast + ((oo * 2 + h) * 2 + t) * 16 + r] = WL[(size_t)oo * HID + nrow(t, r, h)];
+                for (int r = 0; r < 16; ++r)
+                    o[hd.off_wlast + ((oo * 2 + h) * 2 + t) * 16 + r] = (float)((double)WL[(size_t)oo * HID + nrow(t, r, h)] * LN2);
     for (int oo = 0; oo < 4; ++oo) o[hd.off_blast + oo] = bh[n_layers - 1][oo];
     // bf16x3 mode: W = Wh + Wl (both bf16, round-to-nearest-even), k order = the accumulator order of the previous
     // layer seen as a 32x32x16 B operand: k(s, kg, j) = 16 s + 8 (j >> 2) + 4 kg + (j & 3)
