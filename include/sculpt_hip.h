@@ -227,7 +227,10 @@ int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, 
  *   Q [Tq][ldq], K [Tk][ldk] bf16 with head h at columns h*64 .. h*64+63;
  *   Vt [heads*64][ldvt] bf16 = V transposed (row = h*64 + d, column = key); ldvt >= round_up(Tk, 64)
  *   and the columns >= Tk must hold finite values (they are multiplied by exact zeros);
- *   O [Tq][ldo] bf16.  Head dim is 64. */
+ *   O [Tq][ldo] bf16.  Head dim is 64.
+ *   scale == 0: Q already carries softmax_scale * log2(e) (folded into the query projection before its bf16 rounding),
+ *   i.e. O = softmax_2(Q K^T) V with 2^x in place of e^x: the kernel then subtracts the running maximum inside the matrix
+ *   product and skips one VALU multiply-add per score (1.1-1.2x faster). */
 int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
                           int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, float scale,
                           sculpt_stream_t stream);

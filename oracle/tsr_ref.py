@@ -47,12 +47,21 @@ class _Q:
         return x.to(torch.bfloat16).to(torch.float32) if self.on else x
 
 
-def _ln_linear(h, gamma, beta, eps, W, bias, Q):
+LOG2E = 1.4426950408889634
+
+
+def _ln_linear(h, gamma, beta, eps, W, bias, Q, q_scale=None):
     """Linear(LayerNorm(h)).  fp32 (Q off): the reference's two calls.  bf16 emulation: the folded form the HIP
-    GEMM computes -- rstd * (bf16(h) . bf16(W*gamma)^T - mean * colsum) + (bias + W . beta)."""
+    GEMM computes -- rstd * (bf16(h) . bf16(W*gamma)^T - mean * colsum) + (bias + W . beta).
+    q_scale (bf16 emulation only): this is an attention's query projection and the HIP pipeline stores
+    bf16(softmax_scale * log2(e) * q) -- the scale goes into the weights before their bf16 rounding; _attn then takes the
+    scores as exponents of 2."""
     D = h.shape[-1]
     if not Q.on:
         return F.linear(F.layer_norm(h, (D,), gamma, beta, eps), W, bias)
+    if q_scale is not None:
+        W = W * q_scale
+        bias = None if bias is None else bias * q_scale
     Wp = Q(W * gamma[None, :])
     bp = (W.double() @ beta.double()).float()
     if bias is not None:
@@ -89,14 +98,16 @@ def _attn(q, k, v, heads, Q):
     qh = q.view(Tq, heads, hd).transpose(0, 1)
     kh = k.view(-1, heads, hd).transpose(0, 1)
     vh = v.view(-1, heads, hd).transpose(0, 1)
-    s = (qh @ kh.transpose(1, 2)) * (1.0 / math.sqrt(hd))
     if Q.on:
-        # the kernel keeps fp32 scores, rounds exp(s - max) to bf16 for the PV product, and divides
-        # by the fp32 row sum at the end
+        # q carries softmax_scale * log2(e) already (_ln_linear q_scale): the scores are exponents of 2.  The kernel keeps
+        # fp32 scores, rounds 2^(s - max) to bf16 for the PV product, and divides by the fp32 row sum at the end (its
+        # running maximum may lag the true one by a power-of-two-ish factor: bf16 rounding noise only)
+        s = qh @ kh.transpose(1, 2)
         m = s.amax(-1, keepdim=True)
-        p = torch.exp(s - m)
+        p = torch.exp2(s - m)
         o = (Q(p) @ vh) / p.sum(-1, keepdim=True)
     else:
+        s = (qh @ kh.transpose(1, 2)) * (1.0 / math.sqrt(hd))
         o = torch.softmax(s, -1) @ vh
     return o.transpose(0, 1).reshape(Tq, D)
 
@@ -119,7 +130,8 @@ def vit_forward(sd, image_hwc, cfg, pos_mode="scale_factor", bf16=False, collect
     for i in range(v["num_hidden_layers"]):
         q = "encoder.layer.%d." % i
         l1 = (g(q + "layernorm_before.weight"), g(q + "layernorm_before.bias"), eps)
-        qq = Q(_ln_linear(h, *l1, g(q + "attention.attention.query.weight"), g(q + "attention.attention.query.bias"), Q))
+        qq = Q(_ln_linear(h, *l1, g(q + "attention.attention.query.weight"), g(q + "attention.attention.query.bias"), Q,
+                          q_scale=LOG2E / math.sqrt(H // nh)))
         kk = Q(_ln_linear(h, *l1, g(q + "attention.attention.key.weight"), g(q + "attention.attention.key.bias"), Q))
         vv = Q(_ln_linear(h, *l1, g(q + "attention.attention.value.weight"), g(q + "attention.attention.value.bias"), Q))
         a = Q(_attn(qq, kk, vv, nh, Q))
@@ -138,11 +150,12 @@ def block_forward(sd, prefix, h, ctx, heads, bf16=False):
     g = lambda k: _t(sd[prefix + k]).float()  # noqa: E731
     D = h.shape[1]
     n1 = (g("norm1.weight"), g("norm1.bias"), 1e-5)
-    a = Q(_attn(Q(_ln_linear(h, *n1, g("attn1.to_q.weight"), None, Q)), Q(_ln_linear(h, *n1, g("attn1.to_k.weight"), None, Q)),
+    qs = LOG2E / math.sqrt(D // heads)
+    a = Q(_attn(Q(_ln_linear(h, *n1, g("attn1.to_q.weight"), None, Q, q_scale=qs)), Q(_ln_linear(h, *n1, g("attn1.to_k.weight"), None, Q)),
                 Q(_ln_linear(h, *n1, g("attn1.to_v.weight"), None, Q)), heads, Q))
     h = F.linear(a, Q(g("attn1.to_out.0.weight")), g("attn1.to_out.0.bias")) + h
     c = Q(ctx)
-    a = Q(_attn(Q(_ln_linear(h, g("norm2.weight"), g("norm2.bias"), 1e-5, g("attn2.to_q.weight"), None, Q)),
+    a = Q(_attn(Q(_ln_linear(h, g("norm2.weight"), g("norm2.bias"), 1e-5, g("attn2.to_q.weight"), None, Q, q_scale=qs)),
                 Q(F.linear(c, Q(g("attn2.to_k.weight")))), Q(F.linear(c, Q(g("attn2.to_v.weight")))), heads, Q))
     h = F.linear(a, Q(g("attn2.to_out.0.weight")), g("attn2.to_out.0.bias")) + h
     pr = _ln_linear(h, g("norm3.weight"), g("norm3.bias"), 1e-5, g("ff.net.0.proj.weight"), g("ff.net.0.proj.bias"), Q)

@@ -47,7 +47,17 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 
 typedef float af32x2 __attribute__((ext_vector_type(2)));
 
-template <int NQB>
+// PRE: Q already carries softmax_scale * log2(e) (folded into the projection that produced it, before its bf16 rounding), so
+// the MFMA result is the exponent of 2 directly, and the running maximum M is subtracted INSIDE the matrix product: a fifth
+// k-step multiplies a constant [1, 1, 0, ...] row fragment with (-M_hi, -M_lo, 0, ...) on the query's lane, M = M_hi + M_lo
+// split into two bf16 values (16 significant bits; M itself is kept quantised to that sum, so the rescale factors stay
+// exact).  That removes the `s * scale - m * scale` v_pk_fma of every score -- the loop is VALU-bound (640 VALU vs 512 MFMA
+// cycles per 64-key tile and wave), FMA-class VALU does not overlap the MFMAs of a co-resident wave -- for 2 more of the 16
+// MFMAs per tile.  M is allowed to lag the true maximum by up to PRE_THR (p <= 2^PRE_THR: bf16 keeps its relative precision,
+// the sums are fp32), so the rescale branch is taken on the first tile and then only on a jump of more than 2^PRE_THR.
+static constexpr float PRE_THR = 10.0f;
+
+template <int NQB, bool PRE = false>
 __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t *__restrict__ Q, int ldq,
                                                                   const uint16_t *__restrict__ K, int ldk,
                                                                   const uint16_t *__restrict__ Vt, int ldvt,
@@ -86,6 +96,11 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     const char *Kh = reinterpret_cast<const char *>(K + head * 64);
     const char *Vh = reinterpret_cast<const char *>(Vt + (long)head * 64 * ldvt);
 
+    // LDS-DMA through buffer addressing (buffer_load_dwordx4 ... offen lds): descriptor in SGPRs, a 32-bit per-lane offset
+    // and a scalar offset per instruction -- no 64-bit per-lane address exists, so nothing address-like is hoisted into
+    // VGPR pairs around the tile loop (global_load_lds with base + offset cost 2-8 VGPRs that way and spilled one pair)
+    const auto k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Kh), 0, 0x7fffffff, 0x00020000);
+    const auto v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Vh), 0, 0x7fffffff, 0x00020000);
     auto stage = [&](int buf, int tp) {
         const bool last = (tp * 128 + 128 > Tk);  // wave-uniform: only the final pair can run past the arrays
 #pragma unroll
@@ -94,20 +109,21 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
             if (j < 32) {
                 const int sub = j >> 3, rg = j & 7, half = sub & 1;
                 unsigned char *dst = smem + buf * 32768 + sub * 8192 + rg * 1024;
-                const char *src;
                 if (sub < 2) {
                     const int row0 = tp * 128 + half * 64 + 8 * rg;
                     if (!last) {
-                        src = Kh + (long)row0 * ldk * 2 + ((rg & 1) ? klane1 : klane0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (alds_ptr_t)dst, 16, (rg & 1) ? klane1 : klane0,
+                                                                 row0 * ldk * 2, 0, 0);
                     } else {
                         const int key = min(row0 + srow, Tk - 1);
-                        src = Kh + ((long)key * ldk + ((rg & 1) ? cs1 : cs0)) * 2;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (alds_ptr_t)dst, 16,
+                                                                 (unsigned)(key * ldk + ((rg & 1) ? cs1 : cs0)) * 2u, 0, 0, 0);
                     }
                 } else {
                     const int col = last ? min(tp * 128 + half * 64, ldvt - 64) : tp * 128 + half * 64;
-                    src = Vh + ((long)(8 * rg) * ldvt + col) * 2 + ((rg & 1) ? vlane1 : vlane0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (alds_ptr_t)dst, 16, (rg & 1) ? vlane1 : vlane0,
+                                                             ((8 * rg) * ldvt + col) * 2, 0, 0);
                 }
-                __builtin_amdgcn_global_load_lds((agbl_ptr_t)src, (alds_ptr_t)dst, 16, 0, 0);
             }
         }
     };
@@ -115,7 +131,11 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;  // m_run in raw score units (before the softmax scale)
+    float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;  // raw score units (before the softmax scale); PRE: log2 units, = M_hi + M_lo
+    // PRE: the extra k-step runs on v_mfma_f32_32x32x8_bf16_1k (4 bf16 = 2 VGPRs per operand): A[key][k] = 1 for k = 0, 1;
+    // B[k][query] = -M_hi, -M_lo; lane l holds k = 4 (l >> 5) + j.  Both fragments are rebuilt per tile from m_run (6 VALU):
+    // the loop sits exactly at the 128-VGPR budget and four more live registers spill a pointer into it.
+    typedef short abf16x4s __attribute__((ext_vector_type(4)));
 
     // fragment read offsets: K rows qc / 32+qc, chunk 2*ks + h  ->  base ^ (ks << 5)
     const int kbase = a_lds_off(qc, h);
@@ -135,6 +155,17 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
             f32x16 s0, s1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+            if (PRE) {  // s = -M for every key of this query (column), first: the K fragments are not live yet; m_run == hi + lo exactly
+                const __bf16 hi = (__bf16)m_run;
+                const __bf16 lo = (__bf16)(m_run - (float)hi);
+                const unsigned neg = ((unsigned)(unsigned short)__builtin_bit_cast(short, hi) |
+                                      ((unsigned)(unsigned short)__builtin_bit_cast(short, lo) << 16)) ^ 0x80008000u;
+                const unsigned w_ones = h == 0 ? 0x3f803f80u : 0u, w_mq = h == 0 ? neg : 0u;
+                const abf16x4s ones = {(short)(w_ones & 0xffffu), (short)(w_ones >> 16), 0, 0};
+                const abf16x4s mq = {(short)(w_mq & 0xffffu), (short)(w_mq >> 16), 0, 0};
+                s0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ones, mq, s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ones, mq, s1, 0, 0, 0);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const abf16x8 k0 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)));
@@ -158,29 +189,60 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
             for (int r = 2; r < 15; ++r) mx = max3f(mx, s1[r], s0[r + 1]);
             mx = max3f(mx, s1[15], __shfl_xor(mx, 32, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both halves now hold the row maximum
-            const float m_new = fmaxf(m_run, mx);
-            // rescale the running state only when some query of the wave saw a new maximum (wave-uniform branch)
-            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-                m_run = m_new;
-            }
-            const float mc = -m_run * scale_log2e;
-            const af32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
             af32x2 ps = {0.f, 0.f};
+            if (PRE) {
+                // mx = (tile maximum) - M.  Rescale when this is the wave's first tile or some query jumped by > 2^PRE_THR
+                const bool need = tp == 0 || mx > PRE_THR;  // (a wave's first tile is tile pair 0, or it has no tile at all)
+                if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
+                    float m_new = m_run;
+                    if (need && mx > -INFINITY) {
+                        const float t = m_run + mx;
+                        const __bf16 hi = (__bf16)t;
+                        const __bf16 lo = (__bf16)(t - (float)hi);
+                        m_new = (float)hi + (float)lo;  // M stays exactly representable as the two bf16 parts
+                    }
+                    const float delta = m_new - m_run;
+                    m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                af32x2 a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
-                a = a * sc2 + mc2;  // v_pk_fma_f32
-                b = b * sc2 + mc2;
-                a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
-                b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
-                s0[r] = a[0]; s0[r + 1] = a[1];
-                s1[r] = b[0]; s1[r + 1] = b[1];
-                ps += a;
-                ps += b;
+                    for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    af32x2 a = {__builtin_amdgcn_exp2f(s0[r]), __builtin_amdgcn_exp2f(s0[r + 1])};
+                    af32x2 b = {__builtin_amdgcn_exp2f(s1[r]), __builtin_amdgcn_exp2f(s1[r + 1])};
+                    s0[r] = a[0]; s0[r + 1] = a[1];
+                    s1[r] = b[0]; s1[r + 1] = b[1];
+                    ps += a;
+                    ps += b;
+                }
+            } else {
+                const float m_new = fmaxf(m_run, mx);
+                // rescale the running state only when some query of the wave saw a new maximum (wave-uniform branch)
+                if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                    m_run = m_new;
+                }
+                const float mc = -m_run * scale_log2e;
+                const af32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    af32x2 a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
+                    a = a * sc2 + mc2;  // v_pk_fma_f32
+                    b = b * sc2 + mc2;
+                    a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+                    b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
+                    s0[r] = a[0]; s0[r + 1] = a[1];
+                    s1[r] = b[0]; s1[r + 1] = b[1];
+                    ps += a;
+                    ps += b;
+                }
             }
             l_run += ps[0] + ps[1];
             // ---- O^T += V^T . P^T   (4 k-steps of 16 keys)
@@ -219,8 +281,9 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     if (kh == 0) {
         const float m1 = scr[32 * 64], l1 = scr[33 * 64];
         const float m = fmaxf(m_run, m1);
-        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * scale_log2e);
-        const float a1 = (l1 > 0.f) ? __builtin_amdgcn_exp2f((m1 - m) * scale_log2e) : 0.f;
+        const float sc = PRE ? 1.0f : scale_log2e;
+        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * sc);
+        const float a1 = (l1 > 0.f) ? __builtin_amdgcn_exp2f((m1 - m) * sc) : 0.f;
         const float inv = 1.0f / (a0 * l_tot + a1 * l1);
         if (q < Tq) {
             uint16_t *orow = O + (long)q * ldo + head * 64;
@@ -261,12 +324,15 @@ extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t 
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
     // 256-query workgroups (16 waves, one per CU) halve the K/V re-staging; worth it once they still cover 3/4 of the CUs
     const bool big = (long)cdiv(Tq, 256) * heads * 4 >= (long)num_cus() * 3;
-    if (big)
-        hipLaunchKernelGGL(attention_kernel<8>, dim3(cdiv(Tq, 256), heads), dim3(1024), 0, as_stream(stream), Q, ldq, K, ldk,
-                           Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
-    else
-    hipLaunchKernelGGL(attention_kernel<4>, dim3(cdiv(Tq, 128), heads), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk,
-                       Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
+    const float sl = scale * 1.44269504088896340736f;
+    hipStream_t st = as_stream(stream);
+    if (scale == 0.f) {  // Q carries scale * log2(e) already
+        if (big) hipLaunchKernelGGL((attention_kernel<8, true>), dim3(cdiv(Tq, 256), heads), dim3(1024), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, 1.0f);
+        else hipLaunchKernelGGL((attention_kernel<4, true>), dim3(cdiv(Tq, 128), heads), dim3(512), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, 1.0f);
+    } else {
+        if (big) hipLaunchKernelGGL((attention_kernel<8, false>), dim3(cdiv(Tq, 256), heads), dim3(1024), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, sl);
+        else hipLaunchKernelGGL((attention_kernel<4, false>), dim3(cdiv(Tq, 128), heads), dim3(512), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, sl);
+    }
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -26,6 +26,7 @@ from .posemb import interpolate_pos_embedding
 from .utils import ImagePreprocessor, scale_tensor
 
 BF16 = torch.bfloat16
+LOG2E = 1.4426950408889634
 
 from .spec import DEFAULT_CFG, IMAGE_MEAN, IMAGE_STD, param_spec  # noqa: E402,F401
 
@@ -210,11 +211,20 @@ class TSR(KernelEngine):
         w["cls"] = _f32(sd[p + "embeddings.cls_token"].reshape(H), dev)
         fold = self.precision == "bf16"
 
-        def ln_linear(L, key, W, bias, gamma, beta):
+        def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, q_scale=1.0):
             """A Linear fed by a LayerNorm.  bf16 mode: the LayerNorm is folded into the GEMM (ops.fold_layernorm):
             L[key] = bf16(W * gamma), L[key_b] = bias + W . beta, L[key_cs] = column sums.  fp32 mode: plain weights + the
-            LayerNorm's own parameters for the stand-alone kernel."""
+            LayerNorm's own parameters for the stand-alone kernel.
+            q_rows / q_scale (bf16 mode): the first q_rows output rows are an attention's query projection and carry
+            softmax_scale * log2(e) -- multiplied in BEFORE the bf16 rounding of the weights, so q is stored as bf16(c q), one
+            rounding as before -- which lets the attention kernel take its scores as exponents of 2 (scale = 0 entry)."""
             if fold:
+                if q_rows:
+                    W = W.clone().to(torch.float32)
+                    W[:q_rows] *= q_scale
+                    if bias is not None:
+                        bias = bias.clone().to(torch.float32)
+                        bias[:q_rows] *= q_scale
                 Wp, bp, cs = ops.fold_layernorm(W, bias, gamma, beta)
                 L[key], L[key + "_b"], L[key + "_cs"] = wt(Wp, dev), _f32(bp, dev), _f32(cs, dev)
             else:
@@ -227,7 +237,8 @@ class TSR(KernelEngine):
             L = {}
             ln_linear(L, "qkv_w", torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0),
                       torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0),
-                      sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"])
+                      sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"], q_rows=H,
+                      q_scale=LOG2E / math.sqrt(H // v["num_attention_heads"]))
             L["o_w"], L["o_b"] = wt(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
             ln_linear(L, "f1_w", sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"],
                       sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"])
@@ -248,10 +259,11 @@ class TSR(KernelEngine):
         for i in range(b["num_layers"]):
             q = "backbone.transformer_blocks.%d." % i
             L = {}
+            Db, qs = b["num_attention_heads"] * b["attention_head_dim"], LOG2E / math.sqrt(b["attention_head_dim"])
             ln_linear(L, "sa_qkv", torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0),
-                      None, sd[q + "norm1.weight"], sd[q + "norm1.bias"])
+                      None, sd[q + "norm1.weight"], sd[q + "norm1.bias"], q_rows=Db, q_scale=qs)
             L["sa_o"], L["sa_ob"] = wt(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
-            ln_linear(L, "ca_q", sd[q + "attn2.to_q.weight"], None, sd[q + "norm2.weight"], sd[q + "norm2.bias"])
+            ln_linear(L, "ca_q", sd[q + "attn2.to_q.weight"], None, sd[q + "norm2.weight"], sd[q + "norm2.bias"], q_rows=Db, q_scale=qs)
             L["_ca_k"], L["_ca_v"] = sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]
             L["ca_o"], L["ca_ob"] = wt(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
             ln_linear(L, "ff1", sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], sd[q + "norm3.weight"], sd[q + "norm3.bias"])
@@ -308,7 +320,7 @@ class TSR(KernelEngine):
         eps = v["layer_norm_eps"]
         for L in w["vit"]:
             self._ln_gemm(st, L, "qkv_w", eps, out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
-            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
+            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(H // nh)))
             self._res_gemm(st, att, L["o_w"], L["o_b"])
             self._ln_gemm(st, L, "f1_w", eps, out_bf16=ff, epilogue=_lib.EPI_GELU)
             self._res_gemm(st, ff, L["f2_w"], L["f2_b"])
@@ -335,6 +347,10 @@ class TSR(KernelEngine):
         else:
             st["xn"] = self._b(name + "_xn", (T, D), torch.float32)
         return st
+
+    def _attn_scale(self, scale):
+        """bf16 mode: the query projections carry scale * log2(e) (ln_linear q_scale) -> sculpt_attention_bf16's scale = 0 entry."""
+        return 0.0 if self.precision == "bf16" else scale
 
     def _state_from(self, h, name="bb"):
         """Stream state for a residual stream given as a plain fp32 tensor (tests, external callers)."""
@@ -371,7 +387,7 @@ class TSR(KernelEngine):
         vt = self._b("bb_vt", (D, Tp), self.adt, zero=True)
         att = self._b("bb_att", (T, D), self.adt)
         self._ln_gemm(st, L, "sa_qkv", 1e-5, out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
-        self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, 1.0 / math.sqrt(hd))
+        self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(hd)))
         self._res_gemm(st, att, L["sa_o"], L["sa_ob"])
 
     def _run_blocks(self, st, ctx: torch.Tensor, first_self_attention_done: bool = False):
@@ -388,7 +404,7 @@ class TSR(KernelEngine):
         self._gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Tc)
         att = self._b("bb_att", (T, D), self.adt)
         ff = self._b("bb_ff", (T, 4 * D), self.adt)
-        scale = 1.0 / math.sqrt(hd)
+        scale = self._attn_scale(1.0 / math.sqrt(hd))
         for li, L in enumerate(w["blocks"]):
             ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
             if li > 0 or not first_self_attention_done:

@@ -104,6 +104,52 @@ def test_gemm_layernorm_fold_vs_fp32_reference(cuda, M, D, N, epi):
         assert _rel(o1, ref2[:, :N // 2])[0] < 4e-3 and _rel(ot[:, :M].t(), ref2[:, N // 2:])[0] < 4e-3
 
 
+@pytest.mark.parametrize("Tq,Tk,heads", [(3072, 3072, 16), (3072, 1025, 16), (1025, 1025, 12), (200, 77, 2), (257, 640, 3)])
+def test_attention_prescaled_q_with_forced_rescales(cuda, Tq, Tk, heads):
+    """sculpt_attention_bf16's scale = 0 entry (Q carries scale * log2 e; the running maximum is subtracted inside the MFMA and
+    may lag by up to 2^10) against an fp64 softmax over the SAME bf16 operands.  The rescale branch is rare on random data,
+    so it is forced: single keys are spiked against single queries so that the row maximum jumps by far more than the
+    threshold at chosen tiles (first, middle, last, and in the ragged tail), one query sees a huge NEGATIVE first tile, and
+    the un-spiked rows keep exercising the lagging-maximum path."""
+    from sculptmate_amd import ops
+
+    D = heads * 64
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    c = 0.125 * 1.4426950408889634
+    qf = torch.randn(Tq, D, generator=g)
+    kf = torch.randn(Tk, D, generator=g)
+    vf = torch.randn(Tk, D, generator=g)
+    # spikes: key j aligned with query i in head hh -> score ~ +-|q|^2 * amp / 8 (hundreds of log2 units above the rest)
+    spikes = [(0, min(5, Tk - 1), 0, 30.0), (1, Tk // 2, heads - 1, 25.0), (2 % Tq, Tk - 1, 0, 40.0), (3 % Tq, max(Tk - 70, 0), 1 % heads, 35.0),
+              (min(130, Tq - 1), min(200, Tk - 1), 0, 30.0), (Tq - 1, 0, 0, 20.0)]
+    for (i, j, hh, amp) in spikes:
+        kf[j, hh * 64:(hh + 1) * 64] = amp * qf[i, hh * 64:(hh + 1) * 64] / qf[i, hh * 64:(hh + 1) * 64].norm() * 8.0
+    qf[min(7, Tq - 1)] *= 0.0
+    qf[min(7, Tq - 1), :64] = -kf[:64, :64].mean(0) * 50.0   # very negative scores on the first tile, head 0
+    qs = (qf * c).to(BF).to(cuda)
+    k = kf.to(BF).to(cuda)
+    vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=cuda)
+    vt[:, :Tk] = vf.to(BF).t().to(cuda)
+    o = torch.empty(Tq, D, dtype=BF, device=cuda)
+    ops.attention(qs, k, vt, o, Tq, Tk, heads, 0.0)
+    qh = qs.double().cpu().view(Tq, heads, 64).transpose(0, 1)
+    kh = k.double().cpu().view(Tk, heads, 64).transpose(0, 1)
+    vh = vt[:, :Tk].t().double().cpu().view(Tk, heads, 64).transpose(0, 1)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) * math.log(2.0), -1) @ vh).transpose(0, 1).reshape(Tq, D)
+    got = o.double().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert float(err.max()) < 0.05, float(err.max())                # |O| <= max |v| ~ 4.5: bf16 rounding of p and of O
+    assert float((got - ref).norm() / ref.norm()) < 4e-3
+    # the spiked rows are (almost) one-hot: O = v[j]
+    for (i, j, hh, amp) in spikes[:3]:
+        assert float((got[i, hh * 64:(hh + 1) * 64] - vf[j, hh * 64:(hh + 1) * 64].to(BF).double()).abs().max()) < 0.05
+    # and the same rows as the in-kernel-scale entry, within bf16 noise
+    o2 = torch.empty_like(o)
+    ops.attention((qf).to(BF).to(cuda), k, vt, o2, Tq, Tk, heads, 0.125)
+    assert float((o2.double().cpu() - ref).norm() / ref.norm()) < 8e-3
+
+
 def test_gemm_gelu_and_geglu_epilogues(cuda):
     from sculptmate_amd import _lib, ops
 
