@@ -1,0 +1,44 @@
+"""Per-kernel table of a `rocprofv3 --kernel-trace --stats` run of bench.py: calls per image, average duration, ms per image,
+and for the dominant kernels the fraction of the roofline that binds them (SURVEY.md 8d figures).
+    python tools/kernel_table.py kernel_stats.csv <bench steps incl. warm-up and stage-split passes>"""
+import csv, sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+dens = [r for r in rows if "density_grid_kernel" in r["Name"]]
+n_img = int(dens[0]["Calls"]) if dens else int(sys.argv[2])   # one dense-grid launch per image
+PEAK_BF16, PEAK_F32 = 2500.0, 157.3
+
+
+def flops(name):
+    # algorithmic TFLOP per image of the kernel families: dense grid 1.382; transformer GEMMs 2.10; attention 0.86
+    if "density_grid_kernel" in name: return 1.382, PEAK_F32
+    return None, None
+
+
+# the transformer runs once more than the dense grid (bench.py's calibration pass): images for its kernels = FF1 launches / 16
+ff1 = [r for r in rows if "gemm_bf16_kernel<2," in r["Name"]]
+n_tr = int(ff1[0]["Calls"]) // 16 if ff1 else n_img
+
+
+def images(name):
+    return n_tr if ("gemm" in name or "attention" in name or "norm" in name or "patchify" in name or "vit_" in name
+                    or "row_slice" in name or "upsample" in name) else n_img
+
+
+tot = sum(float(r["TotalDurationNs"]) / images(r["Name"]) for r in rows) / 1e6
+print("| kernel | launches / image | avg us | ms / image | share |")
+print("|---|---|---|---|---|")
+fam = {"gemm": 0.0, "attention": 0.0, "mc_": 0.0, "density": 0.0}
+for r in rows[:26]:
+    name = r["Name"].split("(")[0].replace("void ", "").replace("sculpt::", "")
+    ms = float(r["TotalDurationNs"]) / images(r["Name"]) / 1e6
+    for k in fam:
+        if k in name: fam[k] += ms
+    print("| `%s` | %.1f | %.1f | %.3f | %.1f %% |" % (name[:60], int(r["Calls"]) / images(r["Name"]), float(r["AverageNs"]) / 1e3, ms, 100 * ms / tot))
+print()
+print("images: %d (dense grid, marching cubes) / %d (transformer); all kernels: %.3f ms / image" % (n_img, n_tr, tot))
+print("bf16 GEMMs %.3f ms (2.10 TFLOP -> %.0f TFLOP/s, %.2f of the 2.5 PFLOP/s peak); attention %.3f ms (0.86 TFLOP -> %.0f TFLOP/s, %.2f);"
+      % (fam["gemm"], 2.10 / fam["gemm"] * 1e3, 2.10 / fam["gemm"] * 1e3 / PEAK_BF16, fam["attention"], 0.86 / fam["attention"] * 1e3,
+         0.86 / fam["attention"] * 1e3 / PEAK_BF16))
+print("dense grid %.3f ms (1.382 TFLOP algorithmic -> %.1f TFLOP/s, %.3f of the 157.3 TFLOP/s fp32 matrix peak); marching cubes %.3f ms"
+      % (fam["density"], 1.382 / fam["density"] * 1e3, 1.382 / fam["density"] * 1e3 / PEAK_F32, fam["mc_"]))
