@@ -602,6 +602,8 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     } else {
         SC_REQUIRE(N % 128 == 0, "gemm_bf16: N=%d must be a multiple of 128", N);
         // fill the chip: with fewer than ~1.5 tiles per CU use the 64-row weight tile
+        // (128 x 128 tiles for the N = 1024 launches -- 192 workgroups, a third fewer L2 -> LDS bytes -- measured the same at
+        // K = 1024 and 10 % slower at K = 4096: one workgroup per CU pulls ~35 GB/s through its LDS-DMA queue, two pull ~57)
         const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
         if (epilogue == SCULPT_EPI_GELU) {
             if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
