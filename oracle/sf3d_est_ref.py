@@ -109,7 +109,7 @@ def clip_visual_forward(sd, prefix, image_nchw, heads, eps=1e-5, bf16=False, ret
             p = "transformer.resblocks.%d." % i
             y = Q(F.layer_norm(h, (W,), g(p + "ln_1.weight"), g(p + "ln_1.bias"), eps))
             qkv = Q(F.linear(y, Q(g(p + "attn.in_proj_weight")), g(p + "attn.in_proj_bias")))
-            a = Q(_attn(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], heads, Q))
+            a = Q(_attn(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], heads, Q, prescaled=False))
             h = h + F.linear(a, Q(g(p + "attn.out_proj.weight")), g(p + "attn.out_proj.bias"))
             y = Q(F.layer_norm(h, (W,), g(p + "ln_2.weight"), g(p + "ln_2.bias"), eps))
             y = Q(F.gelu(F.linear(y, Q(g(p + "mlp.c_fc.weight")), g(p + "mlp.c_fc.bias"))))

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .tsr_ref import IMAGE_MEAN, IMAGE_STD, _Q, _attn, _t
+from .tsr_ref import IMAGE_MEAN, IMAGE_STD, LOG2E, _Q, _attn, _t
 
 
 # ----------------------------------------------------------------------------- camera
@@ -106,7 +106,10 @@ def dino_forward(sd, image_hwc, cond, cfg, prefix="image_tokenizer.", bf16=False
         q = "encoder.layer.%d." % i
         xn = F.layer_norm(h, (H,), g(q + "norm1.weight"), g(q + "norm1.bias"), eps)
         xn = Q(_modulate(xn, sd, p + q + "norm1_modulation.", cond))
-        qq = Q(F.linear(xn, Q(g(q + "attention.attention.query.weight")), g(q + "attention.attention.query.bias")))
+        # bf16 emulation: the HIP pipeline stores bf16(softmax_scale * log2(e) * q) (scale folded into the projection before its
+        # bf16 rounding) and _attn takes the scores as exponents of 2 (oracle/tsr_ref.py); fp32: the reference's plain q
+        qc = LOG2E / math.sqrt(H // nh) if Q.on else 1.0
+        qq = Q(F.linear(xn, Q(g(q + "attention.attention.query.weight") * qc), g(q + "attention.attention.query.bias") * qc))
         kk = Q(F.linear(xn, Q(g(q + "attention.attention.key.weight")), g(q + "attention.attention.key.bias")))
         vv = Q(F.linear(xn, Q(g(q + "attention.attention.value.weight")), g(q + "attention.attention.value.bias")))
         a = Q(_attn(qq, kk, vv, nh, Q))
@@ -123,7 +126,9 @@ def dino_forward(sd, image_hwc, cond, cfg, prefix="image_tokenizer.", bf16=False
 # ----------------------------------------------------------------------------- two-stream backbone
 def _cross_attention(sd, key, xq, xkv, heads, Q):
     g = lambda k: Q(_t(sd[key + k]).float())  # noqa: E731
-    q = Q(F.linear(xq, g("wq.weight")))
+    wq = _t(sd[key + "wq.weight"]).float()
+    qc = LOG2E / math.sqrt(wq.shape[0] // heads) if Q.on else 1.0   # see dino_forward: bf16(c q), scores = exponents of 2
+    q = Q(F.linear(xq, Q(wq * qc)))
     k = Q(F.linear(xkv, g("wk.weight")))
     v = Q(F.linear(xkv, g("wv.weight")))
     a = Q(_attn(q, k, v, heads, Q))

@@ -92,17 +92,22 @@ def interpolate_pos(pos, n_side, mode):
     return torch.cat([pos[0, :1], patch], 0)
 
 
-def _attn(q, k, v, heads, Q):
+def _attn(q, k, v, heads, Q, prescaled=None):
+    """prescaled (default: in the bf16 emulation): q already carries softmax_scale * log2(e)."""
+    if prescaled is None:
+        prescaled = Q.on
     Tq, D = q.shape
     hd = D // heads
     qh = q.view(Tq, heads, hd).transpose(0, 1)
     kh = k.view(-1, heads, hd).transpose(0, 1)
     vh = v.view(-1, heads, hd).transpose(0, 1)
     if Q.on:
-        # q carries softmax_scale * log2(e) already (_ln_linear q_scale): the scores are exponents of 2.  The kernel keeps
-        # fp32 scores, rounds 2^(s - max) to bf16 for the PV product, and divides by the fp32 row sum at the end (its
-        # running maximum may lag the true one by a power-of-two-ish factor: bf16 rounding noise only)
+        # prescaled: q carries softmax_scale * log2(e) already (_ln_linear q_scale): the scores are exponents of 2.  The
+        # kernel keeps fp32 scores, rounds 2^(s - max) to bf16 for the PV product, and divides by the fp32 row sum at the end
+        # (its running maximum may lag the true one by a power-of-two-ish factor: bf16 rounding noise only)
         s = qh @ kh.transpose(1, 2)
+        if not prescaled:
+            s = s * (LOG2E / math.sqrt(hd))
         m = s.amax(-1, keepdim=True)
         p = torch.exp2(s - m)
         o = (Q(p) @ vh) / p.sum(-1, keepdim=True)

@@ -319,12 +319,32 @@ class SF3D(KernelEngine):
         b = self._sd["camera_embedder.linear.bias"].numpy().astype(np.float64)
         return (W @ cond.astype(np.float64) + b).astype(np.float32)
 
+    def _attn_scale(self, scale):
+        """bf16 mode: the query projections carry scale * log2(e) (qscaled in _prepare) -> sculpt_attention_bf16's scale = 0 entry."""
+        return 0.0 if self.precision == "bf16" else scale
+
     def _prepare(self, dev):
         sd, cfg = self._sd, self.cfg
         for e in (self.image_estimator, self.global_estimator):
             if e is not None:
                 e.to(dev)
         wt = _bf if self.precision == "bf16" else _f32
+        pre = self.precision == "bf16"   # query projections carry softmax_scale * log2(e) (sculpt_attention_bf16, scale = 0 entry)
+
+        def qscaled(W, rows, head_dim, bias=None):
+            """bf16 mode: the first `rows` output rows (an attention's query projection) times scale * log2(e), in fp32,
+            before the bf16 rounding of the weights -- q is then stored as bf16(c q), one rounding as before."""
+            if not pre:
+                return W if bias is None else (W, bias)
+            c = 1.4426950408889634 / math.sqrt(head_dim)
+            W = torch.as_tensor(W).clone().to(torch.float32)
+            W[:rows] *= c
+            if bias is None:
+                return W
+            bias = torch.as_tensor(bias).clone().to(torch.float32)
+            bias[:rows] *= c
+            return W, bias
+
         v, b, t, pp = cfg["image_tokenizer"], cfg["backbone"], cfg["tokenizer"], cfg["post_processor"]
         H, P = v["hidden_size"], v["patch_size"]
         w = {}
@@ -352,8 +372,10 @@ class SF3D(KernelEngine):
                 be = sd[q + ln + ".bias"].numpy().astype(np.float64)
                 L["ln%d_w" % j] = _f32((g * (1 + scale)).astype(np.float32), dev)
                 L["ln%d_b" % j] = _f32((be * (1 + scale) + shift).astype(np.float32), dev)
-            L["qkv_w"] = wt(torch.cat([sd[q + "attention.attention.%s.weight" % n] for n in ("query", "key", "value")], 0), dev)
-            L["qkv_b"] = _f32(torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0), dev)
+            qkv_w, qkv_b = qscaled(torch.cat([torch.as_tensor(sd[q + "attention.attention.%s.weight" % n]) for n in ("query", "key", "value")], 0),
+                                   H, H // v["num_attention_heads"],
+                                   torch.cat([torch.as_tensor(sd[q + "attention.attention.%s.bias" % n]) for n in ("query", "key", "value")], 0))
+            L["qkv_w"], L["qkv_b"] = wt(qkv_w, dev), _f32(qkv_b, dev)
             l1, l2 = sd[q + "layer_scale1.lambda1"], sd[q + "layer_scale2.lambda1"]
             # LayerScale (dinov2.py:380-396) folded into the preceding Linear
             L["o_w"] = wt(sd[q + "attention.output.dense.weight"] * l1[:, None], dev)
@@ -388,7 +410,7 @@ class SF3D(KernelEngine):
 
         def fuse(key):
             F = {}
-            F["q"] = wt(sd[key + "attn.wq.weight"], dev)
+            F["q"] = wt(qscaled(sd[key + "attn.wq.weight"], 1 << 30, b["attention_head_dim"]), dev)
             F["kv"] = wt(torch.cat([sd[key + "attn.wk.weight"], sd[key + "attn.wv.weight"]], 0), dev)
             F["o"], F["ob"] = wt(sd[key + "attn.proj.weight"], dev), _f32(sd[key + "attn.proj.bias"], dev)
             F["nz1"] = (_f32(sd[key + "norm_z1.weight"], dev), _f32(sd[key + "norm_z1.bias"], dev))
@@ -409,9 +431,11 @@ class SF3D(KernelEngine):
                 L = {}
                 for n in (1, 2, 3):
                     L["n%d" % n] = (_f32(sd[kk + "norm%d.weight" % n], dev), _f32(sd[kk + "norm%d.bias" % n], dev))
-                L["sa_qkv"] = wt(torch.cat([sd[kk + "attn1.wq.weight"], sd[kk + "attn1.wk.weight"], sd[kk + "attn1.wv.weight"]], 0), dev)
+                Db = b["num_attention_heads"] * b["attention_head_dim"]
+                L["sa_qkv"] = wt(qscaled(torch.cat([torch.as_tensor(sd[kk + "attn1.wq.weight"]), torch.as_tensor(sd[kk + "attn1.wk.weight"]),
+                                                    torch.as_tensor(sd[kk + "attn1.wv.weight"])], 0), Db, b["attention_head_dim"]), dev)
                 L["sa_o"], L["sa_ob"] = wt(sd[kk + "attn1.proj.weight"], dev), _f32(sd[kk + "attn1.proj.bias"], dev)
-                L["ca_q"] = wt(sd[kk + "attn2.wq.weight"], dev)
+                L["ca_q"] = wt(qscaled(sd[kk + "attn2.wq.weight"], 1 << 30, b["attention_head_dim"]), dev)
                 ca_k.append(sd[kk + "attn2.wk.weight"])
                 ca_v.append(sd[kk + "attn2.wv.weight"])
                 L["ca_o"], L["ca_ob"] = wt(sd[kk + "attn2.proj.weight"], dev), _f32(sd[kk + "attn2.proj.bias"], dev)
@@ -480,7 +504,7 @@ class SF3D(KernelEngine):
         for L in w["dino"]:
             self._ln(h, L["ln1_w"], L["ln1_b"], eps, xn)
             self._gemm(xn, L["qkv_w"], bias=L["qkv_b"], out_bf16=qk, out_t=vt, n_split=2 * H)
-            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, 1.0 / math.sqrt(H // nh))
+            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(H // nh)))
             self._gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
             self._ln(h, L["ln2_w"], L["ln2_b"], eps, xn)
             self._gemm(xn, L["f1_w"], bias=L["f1_b"], out_bf16=ff, epilogue=_lib.EPI_GELU)
@@ -526,7 +550,7 @@ class SF3D(KernelEngine):
     def _fuse(self, F, z, x_act, rows_z, rows_x, D, nh, tag):
         """FuseBlock.forward (backbone.py:249-257): z += attn(LN(z), x); z += FF(LN(z)).  x_act = x in storage type
         (norm_x_input is False in the shipped config; when set, x_act is LN(x))."""
-        scale = 1.0 / math.sqrt(D // nh)
+        scale = self._attn_scale(1.0 / math.sqrt(D // nh))
         xn = self._b(tag + "_xn", (rows_z, D), self.adt)
         self._ln(z, F["nz1"][0], F["nz1"][1], 1e-5, xn)
         qb = self._b(tag + "_q", (rows_z, D), self.adt)
@@ -565,7 +589,7 @@ class SF3D(KernelEngine):
         cak = self._b("bb_cak", (Ni, nb * D), self.adt)
         cavt = self._b("bb_cavt", (nb * D, Nip), self.adt, zero=True)
         self._gemm(img_act, w["ca_kv_all"], out_bf16=cak, out_t=cavt, n_split=nb * D)
-        scale = 1.0 / math.sqrt(D // nh)
+        scale = self._attn_scale(1.0 / math.sqrt(D // nh))
         Lp = ((Lr + 63) // 64) * 64
         nxi = b.get("norm_x_input", False)
         ib = 0

@@ -15,7 +15,7 @@ def timeit(fn, n=30, warm=5):
         b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / 10)
     ts.sort(); return ts[len(ts) // 2] * 1e3
 
-for (Tq, Tk, heads, gain) in ((3072, 3072, 16, 1.0), (3072, 1025, 16, 1.0), (1025, 1025, 12, 1.0), (3072, 3072, 16, 6.0), (300, 77, 2, 1.0)):
+for (Tq, Tk, heads, gain) in ((3072, 3072, 16, 1.0), (3072, 1025, 16, 1.0), (1025, 1025, 12, 1.0), (3072, 3072, 16, 6.0), (3089, 27648, 16, 1.0), (27648, 3089, 16, 1.0), (3089, 3089, 16, 1.0), (3089, 1297, 16, 1.0), (1297, 1297, 16, 1.0)):
     D = heads * 64
     g = torch.Generator(device="cpu").manual_seed(Tq + Tk)
     qf = (gain * torch.randn(Tq, D, generator=g)).to(dev); kf = torch.randn(Tk, D, generator=g).to(dev); vf = torch.randn(Tk, D, generator=g).to(dev)
