@@ -274,7 +274,7 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     if (kh == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { scr[r * 64] = o0[r]; scr[(16 + r) * 64] = o1[r]; }
-        scr[32 * 64] = m_run;
+        scr[32 * 64] = (PRE && !(l_tot > 0.f)) ? -INFINITY : m_run;  // a half without keys has no maximum (PRE starts M at 0)
         scr[33 * 64] = l_tot;
     }
     __syncthreads();

@@ -56,20 +56,59 @@ class Mesh:
         writer(str(path), self.vertices, self.faces, vertex_colors=self.vertex_colors)
 
 
+class _PinnedPool:
+    """Pinned host buffers for the mesh hand-off, recycled by size class (next power of two of the byte count).  A pinned
+    allocation is a driver call of ~0.5 ms that can stall the device queue; mesh sizes differ from image to image, so an
+    exact-size cache never hits."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = max(n * torch.empty((), dtype=dtype).element_size(), 1)
+        cap = 1 << (nbytes - 1).bit_length()
+        lst = self.free.get(cap)
+        buf = lst.pop() if lst else torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        view = buf[:nbytes].view(dtype).view(shape)
+        return _PinnedLease(self, cap, buf), view
+
+    def give(self, cap, buf):
+        self.free.setdefault(cap, []).append(buf)
+
+
+class _PinnedLease:
+    def __init__(self, pool, cap, buf):
+        self.pool, self.cap, self.buf = pool, cap, buf
+
+    def __del__(self):
+        try:
+            self.pool.give(self.cap, self.buf)
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class PendingMesh:
     """A mesh whose device -> pinned-host copy is in flight (TSR.run_async)."""
 
-    def __init__(self, host_tensors, done_event):
+    def __init__(self, host_tensors, done_event, leases=()):
         self._host = host_tensors
         self._done = done_event
+        self._leases = leases
 
     def done(self) -> bool:
         return self._done.query()
 
     def result(self) -> Mesh:
+        """The arrays are views of pinned host buffers that belong to the returned Mesh (recycled when it is released):
+        copy them if they must outlive it."""
         self._done.synchronize()
         v, f, c = self._host
-        return Mesh(v.numpy(), f.numpy(), None if c is None else c.numpy())  # views of the pinned buffers (kept alive by NumPy)
+        m = Mesh(v.numpy(), f.numpy(), None if c is None else c.numpy())
+        m._pinned = self._leases
+        return m
 
 
 class MarchingCubeHelper:
@@ -593,20 +632,24 @@ class TSR(KernelEngine):
             copy = self._copy_stream = torch.cuda.Stream(self.device)
         ready = torch.cuda.Event()
         ready.record(main)
-        host = []
+        pool = getattr(self, "_pin_pool", None)
+        if pool is None:
+            pool = self._pin_pool = _PinnedPool()
+        host, leases = [], []
         with torch.cuda.stream(copy):
             copy.wait_event(ready)
             for t in (m.vertices, m.faces, m.vertex_colors):
                 if t is None:
                     host.append(None)
                     continue
-                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)  # torch's caching host allocator recycles these
+                lease, h = pool.take(t.shape, t.dtype)
                 h.copy_(t, non_blocking=True)
                 t.record_stream(copy)  # the device block must not be reused before the copy has read it
                 host.append(h)
+                leases.append(lease)
             done = torch.cuda.Event()
             done.record(copy)
-        return PendingMesh(host, done)
+        return PendingMesh(host, done, tuple(leases))
 
     def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False) -> List[Mesh]:
         """Headless entry point: images -> list of Mesh with host (NumPy) arrays.  With several images the device -> host
