@@ -428,6 +428,28 @@ int sculpt_vertex_tangents(const float *v_pos, const float *v_tex, const float *
 /* fp32 -> bf16 (round to nearest even), n elements */
 int sculpt_cast_bf16(const float *x, uint16_t *y, int64_t n, sculpt_stream_t stream);
 
+/* Triangle remeshing of the SF3D output mesh: the three gpytoolbox calls of Mesh.triangle_remesh
+ * (StableFast/sf3d/models/mesh.py:175-237), on the HOST like the reference's (HOST pointers; no GPU work, no stream).
+ *   sculpt_mesh_subdivide      = gpytoolbox.subdivide(v, f, iters=...)      midpoint 1 -> 4 subdivision       (mesh.py:187-191)
+ *   sculpt_mesh_decimate       = gpytoolbox.decimate(v, f, face_ratio=...)  shortest-edge collapse to the midpoint with the
+ *                                link condition, until <= target_faces faces remain (libigl's default)        (mesh.py:195-199)
+ *   sculpt_mesh_remesh_botsch  = gpytoolbox.remesh_botsch(v, f, i, h)       Botsch-Kobbelt isotropic remeshing: split > 4/3 h,
+ *                                collapse < 4/5 h, valence flips, tangential relaxation, projection onto the input surface
+ *                                (project != 0); h <= 0 = mean edge length of the input; boundary vertices stay  (mesh.py:225-230)
+ * V f64 [nv][3], F int32 [nf][3].  The result is an opaque object (its size is not known beforehand): read the counts, copy
+ * it out with sculpt_mesh_read (V f64 [num_vertices][3], F int32 [num_faces][3]) and release it with sculpt_mesh_free.
+ * gpytoolbox / libigl are absent from the reference tree and the build image: PARITY UNPINNED (csrc/remesh_host.h). */
+typedef struct sculpt_host_mesh sculpt_host_mesh_t;
+int sculpt_mesh_subdivide(const double *V, size_t nv, const int32_t *F, size_t nf, int iters, sculpt_host_mesh_t **out);
+int sculpt_mesh_decimate(const double *V, size_t nv, const int32_t *F, size_t nf, size_t target_faces,
+                         sculpt_host_mesh_t **out);
+int sculpt_mesh_remesh_botsch(const double *V, size_t nv, const int32_t *F, size_t nf, int iters, double h, int project,
+                              sculpt_host_mesh_t **out);
+size_t sculpt_mesh_num_vertices(const sculpt_host_mesh_t *m);
+size_t sculpt_mesh_num_faces(const sculpt_host_mesh_t *m);
+int sculpt_mesh_read(const sculpt_host_mesh_t *m, double *V, int32_t *F);
+void sculpt_mesh_free(sculpt_host_mesh_t *m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,13 @@ SIGNATURES = {
     "sculpt_mtet_workspace_bytes": (_sz, [_i64, _i64]),
     "sculpt_mtet_count": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _pi64, _pi64, _vp]),
     "sculpt_mtet_emit": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "sculpt_mesh_subdivide": (_i, [_vp, _sz, _vp, _sz, _i, _pp]),
+    "sculpt_mesh_decimate": (_i, [_vp, _sz, _vp, _sz, _sz, _pp]),
+    "sculpt_mesh_remesh_botsch": (_i, [_vp, _sz, _vp, _sz, _i, _d, _i, _pp]),
+    "sculpt_mesh_num_vertices": (_sz, [_vp]),
+    "sculpt_mesh_num_faces": (_sz, [_vp]),
+    "sculpt_mesh_read": (_i, [_vp, _vp, _vp]),
+    "sculpt_mesh_free": (None, [_vp]),
     "rasterize_cpu": (None, [_vp, _sz, _vp, _sz, ctypes.c_longlong, _vp]),
     "interpolate_cpu": (None, [_vp, _sz, _vp, _sz, _vp, ctypes.c_longlong, _vp]),
 }

@@ -28,8 +28,9 @@ class Fast3DGenerator(GeneratorFacade):
             return STATUS_NOT_LOADED
         torch.cuda.empty_cache()
         if remesh_option != "none" and self.model.remesher is None:
-            # the add-on always asks for 'triangle' (generate.py:33); without gpytoolbox hand over the un-remeshed mesh
-            print("[Generation Warning] gpytoolbox is not installed: remesh_option=%r ignored, the mesh keeps its "
+            # the add-on always asks for 'triangle' (generate.py:33); with the remesher switched off hand over the
+            # un-remeshed mesh
+            print("[Generation Warning] no remesher set: remesh_option=%r ignored, the mesh keeps its "
                   "marching-tetrahedra resolution" % remesh_option)
             remesh_option = "none"
         result, _global = self.model.run_image(input_image, bake_resolution=texture_resolution, remesh=remesh_option,

@@ -229,8 +229,8 @@ class SF3D(KernelEngine):
         from .unwrap import BoxProjectionUnwrapper
 
         self.unwrapper = BoxProjectionUnwrapper()
-        # callable(mesh, mode, vertex_count) -> Mesh: gpytoolbox (the reference's package, mesh.py:176-234) when it is
-        # installed, else None and run_image refuses remesh != "none"
+        # callable(mesh, mode, vertex_count) -> Mesh: Mesh.triangle_remesh (mesh.py:176-234) on the native decimate /
+        # Botsch-Kobbelt code (sf3d/remesh.py); None: run_image refuses remesh != "none"
         from .remesh import default_remesher
 
         self.remesher = default_remesher()
@@ -785,7 +785,7 @@ class SF3D(KernelEngine):
                 vertex_count = round(0.1 * mesh.v_pos.shape[0])
             if remesh in ("triangle", "quad"):
                 if self.remesher is None:
-                    raise _lib.SculptError("remesh=%r needs SF3D.remesher (gpytoolbox in the reference, mesh.py:176-234)" % remesh)
+                    raise _lib.SculptError("remesh=%r needs SF3D.remesher (sf3d/remesh.py; mesh.py:176-234)" % remesh)
                 mesh = self.remesher(mesh, remesh, vertex_count)
             uvs = None
             tex = dict(basecolor_tex=None, bump_tex=None, roughness=None, metallic=None)

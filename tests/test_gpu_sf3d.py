@@ -387,9 +387,21 @@ def test_fast3d_generator_facade(cuda, tmp_path):
     assert g.generate_mesh(img, "thing", remesh_option="none", texture_resolution=64, enable_texture=False) == 0
     assert g.last_mesh["faces"].shape[1] == 3
     nf_plain = g.last_mesh["faces"].shape[0]
-    # the add-on always asks for 'triangle' (generate.py:33): without gpytoolbox the facade hands over the un-remeshed mesh
-    # (with a printed warning), the model itself refuses
-    assert g.model.remesher is None
+    # the add-on always asks for 'triangle' (generate.py:33): native decimate + Botsch-Kobbelt remesh (sf3d/remesh.py) to
+    # 'high' = 75 % of the vertices (system.py:346-347); the remeshed surface is still an oriented manifold
+    from sculptmate_amd.sf3d.remesh import native_remesher
+
+    assert g.model.remesher is native_remesher
+    assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, enable_texture=False) == 0
+    fr = np.asarray(g.last_mesh["faces"]).reshape(-1, 3)
+    assert 0.5 * nf_plain < len(fr) < 0.95 * nf_plain, (nf_plain, len(fr))
+    # (the unwrap step splits every vertex per face corner: weld by position before looking at the connectivity)
+    _, inv = np.unique(np.asarray(g.last_mesh["vertices"]), axis=0, return_inverse=True)
+    fw = inv.reshape(-1)[fr].astype(np.int64)
+    de = np.concatenate([fw[:, [0, 1]], fw[:, [1, 2]], fw[:, [2, 0]]], 0)
+    assert len(np.unique(de[:, 0] * (int(fw.max()) + 2) + de[:, 1])) == len(de)  # every directed edge once: consistently oriented
+    # without a remesher the facade hands over the un-remeshed mesh (with a printed warning), the model itself refuses
+    g.model.remesher = None
     assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, enable_texture=False) == 0
     assert g.last_mesh["faces"].shape[0] == nf_plain
     with pytest.raises(Exception):
