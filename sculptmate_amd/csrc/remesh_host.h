@@ -27,6 +27,7 @@
 #include <limits>
 #include <queue>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -95,6 +96,7 @@ struct Mesh {
     std::vector<std::array<int, 3>> F;
     std::vector<uint8_t> valive, falive;
     std::vector<IntList> vf;  // faces incident to a vertex
+    std::vector<uint8_t> bnd;  // vertex lies on the boundary (or on a non-manifold edge): computed by build(), kept by the operations
     size_t faces_alive = 0;
 
     // ---- construction / output -------------------------------------------------------------------------------------
@@ -119,6 +121,8 @@ struct Mesh {
             vf[c].push((int)f);
         }
         faces_alive = nf;
+        bnd.resize(nv);
+        for (size_t v = 0; v < nv; ++v) bnd[v] = scan_boundary_vertex((int)v);
         return "";
     }
     // live vertices that are still referenced and live faces, both in their original relative order
@@ -169,8 +173,11 @@ struct Mesh {
                 if (w != u && std::find(out.begin(), out.end(), w) == out.end()) out.push_back(w);
             }
     }
-    // a vertex is on the boundary (or on a non-manifold edge) when one of its edges does not have exactly two faces
-    bool is_boundary_vertex(int u) const {
+    // a vertex is on the boundary (or on a non-manifold edge) when one of its edges does not have exactly two faces.
+    // Collapses, splits and flips keep this property computable locally: a collapse merges the flags (the link condition
+    // never lets a hole close), a split vertex inherits its edge's, a flip touches interior edges only.
+    bool is_boundary_vertex(int u) const { return bnd[u] != 0; }
+    bool scan_boundary_vertex(int u) const {
         // every neighbour must appear in exactly two incident faces
         int nb[64], cnt[64], n = 0;
         for (int f : vf[u])
@@ -239,6 +246,7 @@ struct Mesh {
         }
         vf[u].clear();
         valive[u] = 0;
+        bnd[v] = bnd[v] | bnd[u];
         P[v] = p;
     }
     // insert a vertex at p on edge (u, v); returns its index
@@ -249,6 +257,7 @@ struct Mesh {
         P.push_back(p);
         valive.push_back(1);
         vf.emplace_back();
+        bnd.push_back(nef != 2);
         for (int i = 0; i < nef; ++i) {
             const int f = ef[i];
             const int w = third(f, u, v);
@@ -439,8 +448,9 @@ class SurfaceGrid {
         }
         const V3 ext = hi - lo_;
         const double longest = std::max(ext.x, std::max(ext.y, ext.z));
-        // about two triangles per occupied cell: cells ~ sqrt(#faces / 2) along the longest side for a surface
-        const double per_side = std::max(1.0, std::sqrt((double)F_.size() / 2.0));
+        // cells about as wide as a triangle -- sqrt(#faces / 2) along the longest side of a surface -- but no more than
+        // ~4 cells per face in total (the dense cell table is 4 bytes per cell)
+        const double per_side = std::max(1.0, std::min(std::sqrt((double)F_.size() / 2.0), std::cbrt(4.0 * (double)F_.size())));
         cell_ = longest > 0 ? longest / per_side : 1.0;
         const double e[3] = {ext.x, ext.y, ext.z};
         for (int k = 0; k < 3; ++k) n_[k] = std::max(1, std::min(1024, (int)std::floor(e[k] / cell_) + 1));
@@ -511,9 +521,15 @@ class SurfaceGrid {
                     }
                 }
             }
-            // everything not yet visited is at least (r + dist to the cell wall) away: p lies within its own (clamped)
-            // cell or outside the grid; the bound below is conservative either way
-            const double reach = r * cell_;
+            // everything not yet visited lies outside the block of cells [c - r, c + r]: at least as far away as the nearest
+            // face of that block (p outside the grid on some axis: the block is clamped there and nothing lies beyond)
+            double reach = std::numeric_limits<double>::infinity();
+            for (int k = 0; k < 3; ++k) {
+                if (c[k] - r > 0) reach = std::min(reach, q[k] - (c[k] - r));
+                if (c[k] + r < n_[k] - 1) reach = std::min(reach, (c[k] + r + 1) - q[k]);
+            }
+            if (reach == std::numeric_limits<double>::infinity()) break;  // the block covers the whole grid
+            reach = std::max(0.0, reach) * cell_;
             if (best <= reach * reach) break;
         }
         return bp;
@@ -630,6 +646,25 @@ static inline void equalize_valences(Mesh &M, RemeshStats &st) {
     }
 }
 
+// fn(begin, end) over [0, n) on up to 32 host threads (contiguous chunks; the result does not depend on the thread count as
+// long as fn writes only its own indices)
+template <class Fn>
+static inline void parallel_ranges(size_t n, Fn fn) {
+    size_t nt = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    nt = std::min(nt, n / 4096 + 1);
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t a = t * chunk, b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back([=]() { fn(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
+
 static inline void tangential_relaxation(Mesh &M, const SurfaceGrid *surface) {
     const size_t nv = M.P.size();
     std::vector<V3> N(nv, V3{0, 0, 0});
@@ -639,8 +674,10 @@ static inline void tangential_relaxation(Mesh &M, const SurfaceGrid *surface) {
             for (int k = 0; k < 3; ++k) N[M.F[f][k]] = N[M.F[f][k]] + n;
         }
     std::vector<V3> Q(M.P);
+    // Jacobi step: every vertex reads the old positions and writes only its own new one
+    parallel_ranges(nv, [&](size_t lo, size_t hi) {
     std::vector<int> nb;
-    for (size_t u = 0; u < nv; ++u) {
+    for (size_t u = lo; u < hi; ++u) {
         if (!M.valive[u] || M.vf[u].size() == 0 || M.is_boundary_vertex((int)u)) continue;
         M.neighbours((int)u, nb);
         V3 c{0, 0, 0};
@@ -661,6 +698,7 @@ static inline void tangential_relaxation(Mesh &M, const SurfaceGrid *surface) {
         if (!ok) continue;
         Q[u] = surface ? surface->closest(p) : p;
     }
+    });
     M.P.swap(Q);
 }
 

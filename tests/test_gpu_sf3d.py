@@ -394,7 +394,9 @@ def test_fast3d_generator_facade(cuda, tmp_path):
     assert g.model.remesher is native_remesher
     assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, enable_texture=False) == 0
     fr = np.asarray(g.last_mesh["faces"]).reshape(-1, 3)
-    assert 0.5 * nf_plain < len(fr) < 0.95 * nf_plain, (nf_plain, len(fr))
+    # (decimation keeps 75 % of the faces; the remesh then evens the edges out at the decimated mesh's MEAN edge length,
+    # which on a marching-tetrahedra mesh -- many tiny triangles -- needs far fewer faces for the same area)
+    assert 0.2 * nf_plain < len(fr) < 0.8 * nf_plain, (nf_plain, len(fr))
     # (the unwrap step splits every vertex per face corner: weld by position before looking at the connectivity)
     _, inv = np.unique(np.asarray(g.last_mesh["vertices"]), axis=0, return_inverse=True)
     fw = inv.reshape(-1)[fr].astype(np.int64)
