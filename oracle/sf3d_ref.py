@@ -30,7 +30,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .tsr_ref import IMAGE_MEAN, IMAGE_STD, LOG2E, _Q, _attn, _t
+from .tsr_ref import IMAGE_MEAN, IMAGE_STD, LOG2E, _Q, _attn, _ln_linear, _t
 
 
 # ----------------------------------------------------------------------------- camera
@@ -86,6 +86,13 @@ def _modulate(x, sd, key, cond):
     return x * (1 + scale) + shift
 
 
+def _modulated(sd, key, gamma, beta, cond):
+    """adaLN as LayerNorm parameters: LN(x; g, b) * (1 + scale) + shift = LN(x; g (1 + scale), b (1 + scale) + shift)."""
+    emb = F.linear(F.silu(cond), _t(sd[key + "_modulation.linear2.weight"]).float(), _t(sd[key + "_modulation.linear2.bias"]).float())
+    scale, shift = emb.chunk(2, dim=-1)
+    return gamma * (1 + scale), beta * (1 + scale) + shift
+
+
 def dino_forward(sd, image_hwc, cond, cfg, prefix="image_tokenizer.", bf16=False):
     """image [S,S,3] in [0,1], cond [Cc] -> last_hidden_state [T, H] (CLS kept)."""
     Q = _Q(bf16)
@@ -104,39 +111,71 @@ def dino_forward(sd, image_hwc, cond, cfg, prefix="image_tokenizer.", bf16=False
     cond = _t(cond).float().view(-1)
     for i in range(nl):
         q = "encoder.layer.%d." % i
-        xn = F.layer_norm(h, (H,), g(q + "norm1.weight"), g(q + "norm1.bias"), eps)
-        xn = Q(_modulate(xn, sd, p + q + "norm1_modulation.", cond))
         # bf16 emulation: the HIP pipeline stores bf16(softmax_scale * log2(e) * q) (scale folded into the projection before its
-        # bf16 rounding) and _attn takes the scores as exponents of 2 (oracle/tsr_ref.py); fp32: the reference's plain q
+        # bf16 rounding) and _attn takes the scores as exponents of 2 (oracle/tsr_ref.py); every LayerNorm (here with its adaLN
+        # modulation, a constant of the camera) is folded into the projection that consumes it (tsr_ref._ln_linear).
+        # fp32: the reference's own sequence of calls.
         qc = LOG2E / math.sqrt(H // nh) if Q.on else 1.0
-        qq = Q(F.linear(xn, Q(g(q + "attention.attention.query.weight") * qc), g(q + "attention.attention.query.bias") * qc))
-        kk = Q(F.linear(xn, Q(g(q + "attention.attention.key.weight")), g(q + "attention.attention.key.bias")))
-        vv = Q(F.linear(xn, Q(g(q + "attention.attention.value.weight")), g(q + "attention.attention.value.bias")))
+        att = lambda n: (g(q + "attention.attention.%s.weight" % n), g(q + "attention.attention.%s.bias" % n))  # noqa: E731
+        if Q.on:
+            gm, bm = _modulated(sd, p + q + "norm1", g(q + "norm1.weight"), g(q + "norm1.bias"), cond)
+            qq = Q(_ln_linear(h, gm, bm, eps, *att("query"), Q, q_scale=qc))
+            kk = Q(_ln_linear(h, gm, bm, eps, *att("key"), Q))
+            vv = Q(_ln_linear(h, gm, bm, eps, *att("value"), Q))
+        else:
+            xn = F.layer_norm(h, (H,), g(q + "norm1.weight"), g(q + "norm1.bias"), eps)
+            xn = _modulate(xn, sd, p + q + "norm1_modulation.", cond)
+            qq, kk, vv = (F.linear(xn, *att(n)) for n in ("query", "key", "value"))
         a = Q(_attn(qq, kk, vv, nh, Q))
         a = F.linear(a, Q(g(q + "attention.output.dense.weight")), g(q + "attention.output.dense.bias"))
         h = a * g(q + "layer_scale1.lambda1") + h
-        xn = F.layer_norm(h, (H,), g(q + "norm2.weight"), g(q + "norm2.bias"), eps)
-        xn = Q(_modulate(xn, sd, p + q + "norm2_modulation.", cond))
-        f = Q(F.gelu(F.linear(xn, Q(g(q + "mlp.fc1.weight")), g(q + "mlp.fc1.bias"))))
+        if Q.on:
+            gm, bm = _modulated(sd, p + q + "norm2", g(q + "norm2.weight"), g(q + "norm2.bias"), cond)
+            f = Q(F.gelu(_ln_linear(h, gm, bm, eps, g(q + "mlp.fc1.weight"), g(q + "mlp.fc1.bias"), Q)))
+        else:
+            xn = F.layer_norm(h, (H,), g(q + "norm2.weight"), g(q + "norm2.bias"), eps)
+            xn = _modulate(xn, sd, p + q + "norm2_modulation.", cond)
+            f = F.gelu(F.linear(xn, g(q + "mlp.fc1.weight"), g(q + "mlp.fc1.bias")))
         f = F.linear(f, Q(g(q + "mlp.fc2.weight")), g(q + "mlp.fc2.bias"))
         h = f * g(q + "layer_scale2.lambda1") + h
     return F.layer_norm(h, (H,), g("layernorm.weight"), g("layernorm.bias"), eps)
 
 
 # ----------------------------------------------------------------------------- two-stream backbone
-def _cross_attention(sd, key, xq, xkv, heads, Q):
-    g = lambda k: Q(_t(sd[key + k]).float())  # noqa: E731
-    wq = _t(sd[key + "wq.weight"]).float()
-    qc = LOG2E / math.sqrt(wq.shape[0] // heads) if Q.on else 1.0   # see dino_forward: bf16(c q), scores = exponents of 2
-    q = Q(F.linear(xq, Q(wq * qc)))
-    k = Q(F.linear(xkv, g("wk.weight")))
-    v = Q(F.linear(xkv, g("wv.weight")))
+def _lnp(sd, key):
+    return _t(sd[key + "weight"]).float(), _t(sd[key + "bias"]).float()
+
+
+def _cross_attention(sd, key, z, zn_key, x, xn_key, heads, Q):
+    """attn(LN(z), x') with x' = z's own normalised rows (x is None: self-attention), LN(x) (xn_key given) or x as it is.
+    bf16 emulation: every LayerNorm folded into the projection that reads it (tsr_ref._ln_linear), queries pre-scaled."""
+    w = lambda k: _t(sd[key + k]).float()  # noqa: E731
+    wq = w("wq.weight")
+    if Q.on:
+        qc = LOG2E / math.sqrt(wq.shape[0] // heads)   # see dino_forward: bf16(c q), scores = exponents of 2
+        gz, bz = _lnp(sd, zn_key)
+        q = Q(_ln_linear(z, gz, bz, 1e-5, wq, None, Q, q_scale=qc))
+        if x is None:
+            k, v = Q(_ln_linear(z, gz, bz, 1e-5, w("wk.weight"), None, Q)), Q(_ln_linear(z, gz, bz, 1e-5, w("wv.weight"), None, Q))
+        elif xn_key is not None:
+            gx, bx = _lnp(sd, xn_key)
+            k, v = Q(_ln_linear(x, gx, bx, 1e-5, w("wk.weight"), None, Q)), Q(_ln_linear(x, gx, bx, 1e-5, w("wv.weight"), None, Q))
+        else:
+            k, v = Q(F.linear(Q(x), Q(w("wk.weight")))), Q(F.linear(Q(x), Q(w("wv.weight"))))
+    else:
+        zn = _ln(sd, zn_key, z)
+        xin = zn if x is None else (_ln(sd, xn_key, x) if xn_key is not None else x)
+        q, k, v = F.linear(zn, wq), F.linear(xin, w("wk.weight")), F.linear(xin, w("wv.weight"))
     a = Q(_attn(q, k, v, heads, Q))
-    return F.linear(a, g("proj.weight"), _t(sd[key + "proj.bias"]).float())
+    return F.linear(a, Q(w("proj.weight")), w("proj.bias"))
 
 
-def _feed_forward(sd, key, x, Q):
-    pr = F.linear(x, Q(_t(sd[key + "net.0.proj.weight"]).float()), _t(sd[key + "net.0.proj.bias"]).float())
+def _feed_forward(sd, key, z, zn_key, Q):
+    w0, b0 = _t(sd[key + "net.0.proj.weight"]).float(), _t(sd[key + "net.0.proj.bias"]).float()
+    if Q.on:
+        pr = _ln_linear(z, *_lnp(sd, zn_key), 1e-5, w0, b0, Q)
+    else:
+        pr = F.linear(_ln(sd, zn_key, z), w0, b0)
     val, gate = pr.chunk(2, dim=-1)
     f = Q(val * F.gelu(gate))
     return F.linear(f, Q(_t(sd[key + "net.2.weight"]).float()), _t(sd[key + "net.2.bias"]).float())
@@ -147,18 +186,14 @@ def _ln(sd, key, x, eps=1e-5):
 
 
 def _basic_block(sd, key, z, x, heads, Q):
-    zn = Q(_ln(sd, key + "norm1.", z))
-    z = z + _cross_attention(sd, key + "attn1.", zn, zn, heads, Q)
-    zn = Q(_ln(sd, key + "norm2.", z))
-    z = z + _cross_attention(sd, key + "attn2.", zn, Q(x) if x is not None else zn, heads, Q)
-    zn = Q(_ln(sd, key + "norm3.", z))
-    return z + _feed_forward(sd, key + "ff.", zn, Q)
+    z = z + _cross_attention(sd, key + "attn1.", z, key + "norm1.", None, None, heads, Q)
+    z = z + _cross_attention(sd, key + "attn2.", z, key + "norm2.", x, None, heads, Q)
+    return z + _feed_forward(sd, key + "ff.", z, key + "norm3.", Q)
 
 
 def _fuse_block(sd, key, z, x, heads, Q, norm_x_input):
-    xin = Q(_ln(sd, key + "norm_x.", x)) if norm_x_input else Q(x)
-    z = z + _cross_attention(sd, key + "attn.", Q(_ln(sd, key + "norm_z1.", z)), xin, heads, Q)
-    return z + _feed_forward(sd, key + "ff.", Q(_ln(sd, key + "norm_z2.", z)), Q)
+    z = z + _cross_attention(sd, key + "attn.", z, key + "norm_z1.", x, key + "norm_x." if norm_x_input else None, heads, Q)
+    return z + _feed_forward(sd, key + "ff.", z, key + "norm_z2.", Q)
 
 
 def backbone_forward(sd, tokens_ct, image_tokens, cfg, prefix="backbone.", bf16=False, collect=None):

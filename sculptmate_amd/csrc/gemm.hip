@@ -32,7 +32,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-static constexpr int BM_DEFAULT = 128;   // activation rows per block (the big-tile variant uses 256)
+static constexpr int BM = 128;   // activation rows per block
 static constexpr int BK = 64;
 
 // GELU(erf).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, below fp32 noise of the GEMM that
@@ -85,17 +85,16 @@ static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 til
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
 // NW: waves per workgroup.  4 = 2x2 waves of 64 activation x BW/2 weight rows; 8 = 2 (weight) x 4 (activation)
 // waves of 32 x BW/2: twice the waves per SIMD to hide LDS / barrier latency, at 1.5x the LDS bytes per MFMA.
-template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT>
+template <int EPI, int BW, int NW, bool CONV = false>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int WT = BW * 128;  // bytes of a weight tile
     constexpr int AT = BM * 128;
     // LDS ring depth: 3 stages (two K-tiles in flight) for the 64-row tile, 2 for the 128-row tile --
     // either way 64-72 KiB, i.e. two workgroups per CU (a third stage at 96 KiB measured slower: one
     // workgroup per CU leaves the epilogue and the ramp-up uncovered).
-    // The 256 x 128 tile (BM = 256: 144 KiB, ONE workgroup of 8 waves per CU, wave tile 64 x 64) moves 25 % fewer L2 -> LDS bytes
-    // per flop than 128 x 128 and half of 128 x 64 -- these launches are bound by exactly those bytes -- and keeps two K-tiles
-    // (96 KiB) in flight.
-    constexpr int NSTAGE = (BW == 64 || BM == 256) ? 3 : 2;
+    // (A 256 x 128 tile -- one 144-KiB workgroup per CU, 25 % fewer L2 -> LDS bytes per flop -- measured slower on every shape
+    // of the two transformers, as did a 96 x 64 tile inside the pipeline: DESIGN.md 3.3.)
+    constexpr int NSTAGE = BW == 64 ? 3 : 2;
     constexpr int DIST = NSTAGE - 1;  // prefetch distance in K-tiles
     // [stage][W | A], then 2 KiB of exchange space for the LayerNorm statistics (ONE shared array: a second __shared__ object
     // beside the LDS-DMA ring can make hipcc drain the DMA queue before every fragment read)
@@ -507,7 +506,7 @@ extern "C" int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, 
     GemmArgs g{in, ld_in, Wt, K, bias, nullptr, 0, out_f32, out_bf16, ldo, nullptr, 0, (int)M, N, K, N, (long)N > M ? 1 : 0,
                n_store, H, W, C_pad / 64, dilation, zp, nullptr, 0, nullptr, 0.f, nullptr, 0, reinterpret_cast<const float *>(zp)};
     SC_REQUIRE((long)N <= ZERO_FLOATS, "conv3x3_bf16: N=%d too large", N);
-    const int mt = cdiv(M, BM_DEFAULT);
+    const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
     const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
     if (epilogue == SCULPT_EPI_RELU) {
@@ -567,26 +566,8 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                    "gemm_bf16_ln: stats_out is for the plain fp32 output (no activation, no column split / n_store)");
         g.stats_out = ln->stats_out;
     }
-    const int mt = cdiv(M, BM_DEFAULT);
+    const int mt = cdiv(M, BM);
     hipStream_t st = as_stream(stream);
-    // big-tile variant (experiment switch SCULPT_GEMM_BIG: 0 off, 1 on where it applies)
-    static const int big = [] { const char *e = getenv("SCULPT_GEMM_BIG"); return e ? atoi(e) : 0; }();
-    if (big && M >= 512) {
-        const int mt2 = cdiv(M, 256);
-        if (epilogue == SCULPT_EPI_GEGLU && (big & 1)) {
-            SC_REQUIRE(N % 64 == 0, "gemm_bf16(GEGLU): N=%d must be a multiple of 64", N);
-            if (big & 8) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GEGLU, 128, 16, false, 256>), dim3(N / 64, mt2), dim3(1024), 0, st, g);
-            else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GEGLU, 128, 8, false, 256>), dim3(N / 64, mt2), dim3(512), 0, st, g);
-            SC_LAUNCH_CHECK();
-            return 0;
-        }
-        if (epilogue == SCULPT_EPI_NONE && N % 128 == 0 && (((big & 2) && N >= 2048) || ((big & 4) && N < 2048))) {
-            if (big & 8) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 16, false, 256>), dim3(N / 128, mt2), dim3(1024), 0, st, g);
-            else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8, false, 256>), dim3(N / 128, mt2), dim3(512), 0, st, g);
-            SC_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of
     // the two transformers except the deep-K 64-row-tile case (K = 4096, N = 1024: -4 %), which keeps 4 waves
     // ... unless the launch has fewer workgroups than CUs (the ViT's 1025 x 768 x 3072): then 8 waves are the only

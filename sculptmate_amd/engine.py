@@ -8,6 +8,30 @@ import torch
 
 from . import ops
 
+BF16 = torch.bfloat16
+
+
+def prepare_ln_linear(L, key, W, bias, gamma, beta, fold, to_weight, to_f32, q_rows=0, q_scale=1.0):
+    """A Linear fed by a LayerNorm, prepared for KernelEngine._ln_gemm.  fold (bf16 mode): the LayerNorm is folded into the
+    GEMM (ops.fold_layernorm): L[key] = bf16(W * gamma), L[key_b] = bias + W . beta, L[key_cs] = column sums.
+    Otherwise (fp32 mode): plain weights + the LayerNorm's own parameters for the stand-alone kernel.
+    q_rows / q_scale (fold only): the first q_rows output rows are an attention's query projection and carry
+    softmax_scale * log2(e) -- multiplied in BEFORE the bf16 rounding of the weights, so q is stored as bf16(c q), one rounding as
+    before -- which lets the attention kernel take its scores as exponents of 2 (scale = 0 entry)."""
+    W = torch.as_tensor(W)
+    if fold:
+        if q_rows:
+            W = W.clone().to(torch.float32)
+            W[:q_rows] *= q_scale
+            if bias is not None:
+                bias = torch.as_tensor(bias).clone().to(torch.float32)
+                bias[:q_rows] *= q_scale
+        Wp, bp, cs = ops.fold_layernorm(W, bias, gamma, beta)
+        L[key], L[key + "_b"], L[key + "_cs"] = to_weight(Wp), to_f32(bp), to_f32(cs)
+    else:
+        L[key], L[key + "_b"] = to_weight(W), (None if bias is None else to_f32(bias))
+        L[key + "_ln"] = (to_f32(gamma), to_f32(beta))
+
 
 class KernelEngine:
     def _b(self, name, shape, dtype, zero=False):
@@ -39,3 +63,43 @@ class KernelEngine:
         if self.precision == "bf16":
             return ops.layernorm(x, gamma, beta, eps, y=y)
         return ops.layernorm(x, gamma, beta, eps, y_f32=y)
+
+    # ---- residual stream with the LayerNorm fold (bf16 mode) ------------------------------------------------------
+    # Every LayerNorm of the two transformers sits between a GEMM that writes the residual stream h and a GEMM that
+    # consumes LN(h).  In bf16 mode the producer also writes bf16(h) and per-row statistics of 32-column slices, and the
+    # consumer applies mean / rstd in its epilogue with gamma / beta folded into its weights (sculpt_gemm_bf16_ln): no
+    # LayerNorm launch, no normalised copy.  fp32 parity mode keeps the stand-alone LayerNorm kernel.
+    def _stream_state(self, name, h):
+        T, D = h.shape
+        st = {"h": h, "name": name}
+        if self.precision == "bf16":
+            st["hb"] = self._b(name + "_hb", (T, D), BF16)
+            st["stats"] = self._b(name + "_stats", (D // ops.LN_SLOT, T, 2), torch.float32)  # slice-major
+        else:
+            st["xn"] = self._b(name + "_xn", (T, D), torch.float32)
+        return st
+
+    def _state_from(self, h, name="bb"):
+        """Stream state for a residual stream given as a plain fp32 tensor (tests, external callers)."""
+        st = self._stream_state(name, h)
+        self._stats_of(st)
+        return st
+
+    def _stats_of(self, st):
+        if self.precision == "bf16":
+            ops.row_slice_stats(st["h"], st["stats"], st["hb"])
+
+    def _ln_gemm(self, st, L, key, eps, **kw):
+        """Linear(LayerNorm(h)) with the weights prepared by ln_linear()."""
+        if self.precision == "bf16":
+            return ops.gemm(st["hb"], L[key], bias=L[key + "_b"], ln_stats=st["stats"], ln_colsum=L[key + "_cs"], ln_eps=eps, **kw)
+        g, b = L[key + "_ln"]
+        ops.layernorm(st["h"], g, b, eps, y_f32=st["xn"])
+        return self._gemm(st["xn"], L[key], bias=L[key + "_b"], **kw)
+
+    def _res_gemm(self, st, A, W, bias):
+        """h += A . W^T + bias (in place); bf16 mode also refreshes bf16(h) and the slice statistics."""
+        h = st["h"]
+        if self.precision == "bf16":
+            return ops.gemm(A, W, bias=bias, residual=h, out_f32=h, out_bf16=st["hb"], stats_out=st["stats"])
+        return self._gemm(A, W, bias=bias, residual=h, out_f32=h)

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from ..engine import KernelEngine
+from ..engine import KernelEngine, prepare_ln_linear
 from ..tsr.posemb import interpolate_pos_embedding
 from .spec import DEFAULT_CFG, IGNORED_PREFIXES, param_spec
 from .tets import load_tets
@@ -320,7 +320,7 @@ class SF3D(KernelEngine):
         return (W @ cond.astype(np.float64) + b).astype(np.float32)
 
     def _attn_scale(self, scale):
-        """bf16 mode: the query projections carry scale * log2(e) (qscaled in _prepare) -> sculpt_attention_bf16's scale = 0 entry."""
+        """bf16 mode: the query projections carry scale * log2(e) (ln_linear in _prepare) -> sculpt_attention_bf16's scale = 0 entry."""
         return 0.0 if self.precision == "bf16" else scale
 
     def _prepare(self, dev):
@@ -331,19 +331,11 @@ class SF3D(KernelEngine):
         wt = _bf if self.precision == "bf16" else _f32
         pre = self.precision == "bf16"   # query projections carry softmax_scale * log2(e) (sculpt_attention_bf16, scale = 0 entry)
 
-        def qscaled(W, rows, head_dim, bias=None):
-            """bf16 mode: the first `rows` output rows (an attention's query projection) times scale * log2(e), in fp32,
-            before the bf16 rounding of the weights -- q is then stored as bf16(c q), one rounding as before."""
-            if not pre:
-                return W if bias is None else (W, bias)
-            c = 1.4426950408889634 / math.sqrt(head_dim)
-            W = torch.as_tensor(W).clone().to(torch.float32)
-            W[:rows] *= c
-            if bias is None:
-                return W
-            bias = torch.as_tensor(bias).clone().to(torch.float32)
-            bias[:rows] *= c
-            return W, bias
+        def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, head_dim=1):
+            """A Linear fed by a LayerNorm: folded into the GEMM in bf16 mode (engine.prepare_ln_linear), with the
+            first q_rows output rows (an attention's queries) carrying softmax_scale * log2(e)."""
+            prepare_ln_linear(L, key, W, bias, torch.as_tensor(gamma), torch.as_tensor(beta), pre, lambda x: wt(x, dev),
+                              lambda x: _f32(x, dev), q_rows if pre else 0, 1.4426950408889634 / math.sqrt(head_dim))
 
         v, b, t, pp = cfg["image_tokenizer"], cfg["backbone"], cfg["tokenizer"], cfg["post_processor"]
         H, P = v["hidden_size"], v["patch_size"]
@@ -361,7 +353,7 @@ class SF3D(KernelEngine):
         w["dino"] = []
         for i in range(v["num_hidden_layers"]):
             q = p + "encoder.layer.%d." % i
-            L = {}
+            L, mod = {}, {}
             for j, ln in ((1, "norm1"), (2, "norm2")):
                 # adaLN (attention.py:27-31): LN(x)*(1+scale)+shift with (scale|shift) = linear2(silu(cam)) constant
                 Wm = sd[q + ln + "_modulation.linear2.weight"].numpy().astype(np.float64)
@@ -370,17 +362,15 @@ class SF3D(KernelEngine):
                 scale, shift = emb[:H], emb[H:]
                 g = sd[q + ln + ".weight"].numpy().astype(np.float64)
                 be = sd[q + ln + ".bias"].numpy().astype(np.float64)
-                L["ln%d_w" % j] = _f32((g * (1 + scale)).astype(np.float32), dev)
-                L["ln%d_b" % j] = _f32((be * (1 + scale) + shift).astype(np.float32), dev)
-            qkv_w, qkv_b = qscaled(torch.cat([torch.as_tensor(sd[q + "attention.attention.%s.weight" % n]) for n in ("query", "key", "value")], 0),
-                                   H, H // v["num_attention_heads"],
-                                   torch.cat([torch.as_tensor(sd[q + "attention.attention.%s.bias" % n]) for n in ("query", "key", "value")], 0))
-            L["qkv_w"], L["qkv_b"] = wt(qkv_w, dev), _f32(qkv_b, dev)
+                mod[j] = (torch.from_numpy((g * (1 + scale)).astype(np.float32)), torch.from_numpy((be * (1 + scale) + shift).astype(np.float32)))
+            ln_linear(L, "qkv_w", torch.cat([torch.as_tensor(sd[q + "attention.attention.%s.weight" % n]) for n in ("query", "key", "value")], 0),
+                      torch.cat([torch.as_tensor(sd[q + "attention.attention.%s.bias" % n]) for n in ("query", "key", "value")], 0),
+                      mod[1][0], mod[1][1], q_rows=H, head_dim=H // v["num_attention_heads"])
             l1, l2 = sd[q + "layer_scale1.lambda1"], sd[q + "layer_scale2.lambda1"]
             # LayerScale (dinov2.py:380-396) folded into the preceding Linear
             L["o_w"] = wt(sd[q + "attention.output.dense.weight"] * l1[:, None], dev)
             L["o_b"] = _f32(sd[q + "attention.output.dense.bias"] * l1, dev)
-            L["f1_w"], L["f1_b"] = wt(sd[q + "mlp.fc1.weight"], dev), _f32(sd[q + "mlp.fc1.bias"], dev)
+            ln_linear(L, "f1_w", sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"], mod[2][0], mod[2][1])
             L["f2_w"] = wt(sd[q + "mlp.fc2.weight"] * l2[:, None], dev)
             L["f2_b"] = _f32(sd[q + "mlp.fc2.bias"] * l2, dev)
             w["dino"].append(L)
@@ -410,14 +400,17 @@ class SF3D(KernelEngine):
 
         def fuse(key):
             F = {}
-            F["q"] = wt(qscaled(sd[key + "attn.wq.weight"], 1 << 30, b["attention_head_dim"]), dev)
-            F["kv"] = wt(torch.cat([sd[key + "attn.wk.weight"], sd[key + "attn.wv.weight"]], 0), dev)
-            F["o"], F["ob"] = wt(sd[key + "attn.proj.weight"], dev), _f32(sd[key + "attn.proj.bias"], dev)
-            F["nz1"] = (_f32(sd[key + "norm_z1.weight"], dev), _f32(sd[key + "norm_z1.bias"], dev))
-            F["nz2"] = (_f32(sd[key + "norm_z2.weight"], dev), _f32(sd[key + "norm_z2.bias"], dev))
+            Dq = sd[key + "attn.wq.weight"].shape[0]
+            ln_linear(F, "q", sd[key + "attn.wq.weight"], None, sd[key + "norm_z1.weight"], sd[key + "norm_z1.bias"], q_rows=Dq,
+                      head_dim=b["attention_head_dim"])
+            kv = torch.cat([torch.as_tensor(sd[key + "attn.wk.weight"]), torch.as_tensor(sd[key + "attn.wv.weight"])], 0)
             if b.get("norm_x_input", False):
-                F["nx"] = (_f32(sd[key + "norm_x.weight"], dev), _f32(sd[key + "norm_x.bias"], dev))
-            F["ff1"], F["ff1_b"] = wt(sd[key + "ff.net.0.proj.weight"], dev), _f32(sd[key + "ff.net.0.proj.bias"], dev)
+                ln_linear(F, "kv", kv, None, sd[key + "norm_x.weight"], sd[key + "norm_x.bias"])
+            else:
+                F["kv"] = wt(kv, dev)
+            F["o"], F["ob"] = wt(sd[key + "attn.proj.weight"], dev), _f32(sd[key + "attn.proj.bias"], dev)
+            ln_linear(F, "ff1", sd[key + "ff.net.0.proj.weight"], sd[key + "ff.net.0.proj.bias"], sd[key + "norm_z2.weight"],
+                      sd[key + "norm_z2.bias"])
             F["ff2"], F["ff2_b"] = wt(sd[key + "ff.net.2.weight"], dev), _f32(sd[key + "ff.net.2.bias"], dev)
             return F
 
@@ -429,17 +422,18 @@ class SF3D(KernelEngine):
             for j in range(b["num_basic_blocks"]):
                 kk = k + "transformer_block.%d." % j
                 L = {}
-                for n in (1, 2, 3):
-                    L["n%d" % n] = (_f32(sd[kk + "norm%d.weight" % n], dev), _f32(sd[kk + "norm%d.bias" % n], dev))
                 Db = b["num_attention_heads"] * b["attention_head_dim"]
-                L["sa_qkv"] = wt(qscaled(torch.cat([torch.as_tensor(sd[kk + "attn1.wq.weight"]), torch.as_tensor(sd[kk + "attn1.wk.weight"]),
-                                                    torch.as_tensor(sd[kk + "attn1.wv.weight"])], 0), Db, b["attention_head_dim"]), dev)
+                ln_linear(L, "sa_qkv", torch.cat([torch.as_tensor(sd[kk + "attn1.wq.weight"]), torch.as_tensor(sd[kk + "attn1.wk.weight"]),
+                                                  torch.as_tensor(sd[kk + "attn1.wv.weight"])], 0), None,
+                          sd[kk + "norm1.weight"], sd[kk + "norm1.bias"], q_rows=Db, head_dim=b["attention_head_dim"])
                 L["sa_o"], L["sa_ob"] = wt(sd[kk + "attn1.proj.weight"], dev), _f32(sd[kk + "attn1.proj.bias"], dev)
-                L["ca_q"] = wt(qscaled(sd[kk + "attn2.wq.weight"], 1 << 30, b["attention_head_dim"]), dev)
+                ln_linear(L, "ca_q", sd[kk + "attn2.wq.weight"], None, sd[kk + "norm2.weight"], sd[kk + "norm2.bias"], q_rows=Db,
+                          head_dim=b["attention_head_dim"])
                 ca_k.append(sd[kk + "attn2.wk.weight"])
                 ca_v.append(sd[kk + "attn2.wv.weight"])
                 L["ca_o"], L["ca_ob"] = wt(sd[kk + "attn2.proj.weight"], dev), _f32(sd[kk + "attn2.proj.bias"], dev)
-                L["ff1"], L["ff1_b"] = wt(sd[kk + "ff.net.0.proj.weight"], dev), _f32(sd[kk + "ff.net.0.proj.bias"], dev)
+                ln_linear(L, "ff1", sd[kk + "ff.net.0.proj.weight"], sd[kk + "ff.net.0.proj.bias"], sd[kk + "norm3.weight"],
+                          sd[kk + "norm3.bias"])
                 L["ff2"], L["ff2_b"] = wt(sd[kk + "ff.net.2.weight"], dev), _f32(sd[kk + "ff.net.2.bias"], dev)
                 B["basic"].append(L)
             w["blocks"].append(B)
@@ -495,20 +489,19 @@ class SF3D(KernelEngine):
         self._gemm(patches, w["patch_w"], bias=w["patch_b"], out_f32=pout)
         h = self._b("d_h", (T, H), torch.float32)
         ops.vit_assemble(pout, w["cls"], self._pos(n_side, image_hwc.device), h)
-        xn = self._b("d_xn", (T, H), self.adt)
+        st = self._stream_state("d", h)  # the residual stream + its bf16 copy + slice statistics (LayerNorm fold, engine.py)
+        self._stats_of(st)
         qk = self._b("d_qk", (T, 2 * H), self.adt)
         vt = self._b("d_vt", (H, Tp), self.adt, zero=True)
         att = self._b("d_att", (T, H), self.adt)
         ff = self._b("d_ff", (T, M), self.adt)
         eps = v["layer_norm_eps"]
         for L in w["dino"]:
-            self._ln(h, L["ln1_w"], L["ln1_b"], eps, xn)
-            self._gemm(xn, L["qkv_w"], bias=L["qkv_b"], out_bf16=qk, out_t=vt, n_split=2 * H)
+            self._ln_gemm(st, L, "qkv_w", eps, out_bf16=qk, out_t=vt, n_split=2 * H)  # adaLN folded into the projection
             self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(H // nh)))
-            self._gemm(att, L["o_w"], bias=L["o_b"], residual=h, out_f32=h)
-            self._ln(h, L["ln2_w"], L["ln2_b"], eps, xn)
-            self._gemm(xn, L["f1_w"], bias=L["f1_b"], out_bf16=ff, epilogue=_lib.EPI_GELU)
-            self._gemm(ff, L["f2_w"], bias=L["f2_b"], residual=h, out_f32=h)
+            self._res_gemm(st, att, L["o_w"], L["o_b"])
+            self._ln_gemm(st, L, "f1_w", eps, out_bf16=ff, epilogue=_lib.EPI_GELU)
+            self._res_gemm(st, ff, L["f2_w"], L["f2_b"])
         tok = self._b("d_tok", (T, H), torch.float32)
         ops.layernorm(h, w["dino_ln_w"], w["dino_ln_b"], eps, y_f32=tok)
         return tok
@@ -540,29 +533,35 @@ class SF3D(KernelEngine):
         ops.cast_bf16(x, y)
         return y
 
-    def _ff(self, z, n2, ff1, ff1_b, ff2, ff2_b, rows, D, tag):
-        xn = self._b(tag + "_xn", (rows, D), self.adt)
-        self._ln(z, n2[0], n2[1], 1e-5, xn)
+    def _ff(self, zst, L, rows, D, tag):
+        """z += FF(LN(z)): GEGLU feed-forward with its LayerNorm folded into the first projection."""
         ffb = self._b(tag + "_ff", (rows, 4 * D), self.adt)
-        self._gemm(xn, ff1, bias=ff1_b, out_bf16=ffb, epilogue=_lib.EPI_GEGLU)
-        self._gemm(ffb, ff2, bias=ff2_b, residual=z, out_f32=z)
+        self._ln_gemm(zst, L, "ff1", 1e-5, out_bf16=ffb, epilogue=_lib.EPI_GEGLU)
+        self._res_gemm(zst, ffb, L["ff2"], L["ff2_b"])
 
-    def _fuse(self, F, z, x_act, rows_z, rows_x, D, nh, tag):
-        """FuseBlock.forward (backbone.py:249-257): z += attn(LN(z), x); z += FF(LN(z)).  x_act = x in storage type
-        (norm_x_input is False in the shipped config; when set, x_act is LN(x))."""
+    def _act(self, st):
+        """The stream in the storage type the K/V (or proj_out) GEMMs read: its bf16 copy, kept current by every GEMM that
+        writes the stream (fp32 mode: the stream itself)."""
+        return st["hb"] if self.precision == "bf16" else st["h"]
+
+    def _fuse(self, F, zst, xst, D, nh, tag):
+        """FuseBlock.forward (backbone.py:249-257): z += attn(LN(z), x); z += FF(LN(z)), on the stream states of z and x
+        (norm_x_input, False in the shipped config: K / V read LN(x), folded into their projection like the others)."""
+        rows_z, rows_x = zst["h"].shape[0], xst["h"].shape[0]
         scale = self._attn_scale(1.0 / math.sqrt(D // nh))
-        xn = self._b(tag + "_xn", (rows_z, D), self.adt)
-        self._ln(z, F["nz1"][0], F["nz1"][1], 1e-5, xn)
         qb = self._b(tag + "_q", (rows_z, D), self.adt)
-        self._gemm(xn, F["q"], out_bf16=qb)
+        self._ln_gemm(zst, F, "q", 1e-5, out_bf16=qb)
         kb = self._b(tag + "_k", (rows_x, D), self.adt)
         xp = ((rows_x + 63) // 64) * 64
         vt = self._b(tag + "_vt", (D, xp), self.adt, zero=True)
-        self._gemm(x_act, F["kv"], out_bf16=kb, out_t=vt, n_split=D, M=rows_x)
+        if self.cfg["backbone"].get("norm_x_input", False):
+            self._ln_gemm(xst, F, "kv", 1e-5, out_bf16=kb, out_t=vt, n_split=D, M=rows_x)
+        else:
+            self._gemm(self._act(xst), F["kv"], out_bf16=kb, out_t=vt, n_split=D, M=rows_x)
         att = self._b(tag + "_att", (rows_z, D), self.adt)
         self._attn(qb, kb, vt, att, rows_z, rows_x, nh, scale)
-        self._gemm(att, F["o"], bias=F["ob"], residual=z, out_f32=z)
-        self._ff(z, F["nz2"], F["ff1"], F["ff1_b"], F["ff2"], F["ff2_b"], rows_z, D, tag)
+        self._res_gemm(zst, att, F["o"], F["ob"])
+        self._ff(zst, F, rows_z, D, tag)
 
     def backbone_tokens(self, img_tok: torch.Tensor):
         """TwoStreamInterleaveTransformer.forward -> direct codes, token-major fp32 [3*S*S, C]
@@ -577,11 +576,15 @@ class SF3D(KernelEngine):
         tri0, lat0 = self._constants()
         tri = self._b("bb_tri", (T, D), torch.float32)
         tri.copy_(tri0)
+        tst = self._stream_state("bb_tri", tri)
+        self._stats_of(tst)
         latent = self._b("bb_latent", (Lr, D), torch.float32)
         xn = self._b("bb_img_n", (Ni, img_tok.shape[1]), self.adt)
         self._ln(img_tok, w["norm_image"][0], w["norm_image"][1], 1e-5, xn)
         self._gemm(xn, w["proj_image"][0], bias=w["proj_image"][1], out_f32=latent[:Ni])
         latent[Ni:].copy_(lat0)
+        lst = self._stream_state("bb_lat", latent)
+        self._stats_of(lst)
         # cross-attention K / V^T of every BasicBlock from the raw image tokens, one GEMM
         img_act = self._cast(img_tok, "bb_img_act")
         nb = b["num_blocks"] * b["num_basic_blocks"]
@@ -591,40 +594,25 @@ class SF3D(KernelEngine):
         self._gemm(img_act, w["ca_kv_all"], out_bf16=cak, out_t=cavt, n_split=nb * D)
         scale = self._attn_scale(1.0 / math.sqrt(D // nh))
         Lp = ((Lr + 63) // 64) * 64
-        nxi = b.get("norm_x_input", False)
         ib = 0
         for B in w["blocks"]:
-            if nxi:
-                x_act = self._b("bb_trix", (T, D), self.adt)
-                self._ln(tri, B["fuse_in"]["nx"][0], B["fuse_in"]["nx"][1], 1e-5, x_act)
-            else:
-                x_act = self._cast(tri, "bb_tri_act")
-            self._fuse(B["fuse_in"], latent, x_act, Lr, T, D, nh, "fi")
+            self._fuse(B["fuse_in"], lst, tst, D, nh, "fi")
             for L in B["basic"]:
-                zn = self._b("bs_xn", (Lr, D), self.adt)
-                self._ln(latent, L["n1"][0], L["n1"][1], 1e-5, zn)
                 qk = self._b("bs_qk", (Lr, 2 * D), self.adt)
                 vt = self._b("bs_vt", (D, Lp), self.adt, zero=True)
-                self._gemm(zn, L["sa_qkv"], out_bf16=qk, out_t=vt, n_split=2 * D)
+                self._ln_gemm(lst, L, "sa_qkv", 1e-5, out_bf16=qk, out_t=vt, n_split=2 * D)
                 att = self._b("bs_att", (Lr, D), self.adt)
                 self._attn(qk[:, :D], qk[:, D:], vt, att, Lr, Lr, nh, scale)
-                self._gemm(att, L["sa_o"], bias=L["sa_ob"], residual=latent, out_f32=latent)
-                self._ln(latent, L["n2"][0], L["n2"][1], 1e-5, zn)
+                self._res_gemm(lst, att, L["sa_o"], L["sa_ob"])
                 qb = self._b("bs_q", (Lr, D), self.adt)
-                self._gemm(zn, L["ca_q"], out_bf16=qb)
+                self._ln_gemm(lst, L, "ca_q", 1e-5, out_bf16=qb)
                 self._attn(qb, cak[:, ib * D:(ib + 1) * D], cavt[ib * D:(ib + 1) * D], att, Lr, Ni, nh, scale)
-                self._gemm(att, L["ca_o"], bias=L["ca_ob"], residual=latent, out_f32=latent)
-                self._ff(latent, L["n3"], L["ff1"], L["ff1_b"], L["ff2"], L["ff2_b"], Lr, D, "bs")
+                self._res_gemm(lst, att, L["ca_o"], L["ca_ob"])
+                self._ff(lst, L, Lr, D, "bs")
                 ib += 1
-            if nxi:
-                x_act = self._b("bb_latx", (Lr, D), self.adt)
-                self._ln(latent, B["fuse_out"]["nx"][0], B["fuse_out"]["nx"][1], 1e-5, x_act)
-            else:
-                x_act = self._cast(latent, "bb_lat_act")
-            self._fuse(B["fuse_out"], tri, x_act, T, Lr, D, nh, "fo")
+            self._fuse(B["fuse_out"], tst, lst, D, nh, "fo")
         direct = self._b("bb_direct", (T, C), torch.float32)
-        self._gemm(self._cast(tri, "bb_tri_act"), w["proj_out"][0], bias=w["proj_out"][1], residual=w["emb_tc"],
-                   out_f32=direct)
+        self._gemm(self._act(tst), w["proj_out"][0], bias=w["proj_out"][1], residual=w["emb_tc"], out_f32=direct)
         return direct
 
     def post_process(self, direct_tc: torch.Tensor):

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _lib, ops
-from ..engine import KernelEngine
+from ..engine import KernelEngine, prepare_ln_linear
 from .posemb import interpolate_pos_embedding
 from .utils import ImagePreprocessor, scale_tensor
 
@@ -251,24 +251,8 @@ class TSR(KernelEngine):
         fold = self.precision == "bf16"
 
         def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, q_scale=1.0):
-            """A Linear fed by a LayerNorm.  bf16 mode: the LayerNorm is folded into the GEMM (ops.fold_layernorm):
-            L[key] = bf16(W * gamma), L[key_b] = bias + W . beta, L[key_cs] = column sums.  fp32 mode: plain weights + the
-            LayerNorm's own parameters for the stand-alone kernel.
-            q_rows / q_scale (bf16 mode): the first q_rows output rows are an attention's query projection and carry
-            softmax_scale * log2(e) -- multiplied in BEFORE the bf16 rounding of the weights, so q is stored as bf16(c q), one
-            rounding as before -- which lets the attention kernel take its scores as exponents of 2 (scale = 0 entry)."""
-            if fold:
-                if q_rows:
-                    W = W.clone().to(torch.float32)
-                    W[:q_rows] *= q_scale
-                    if bias is not None:
-                        bias = bias.clone().to(torch.float32)
-                        bias[:q_rows] *= q_scale
-                Wp, bp, cs = ops.fold_layernorm(W, bias, gamma, beta)
-                L[key], L[key + "_b"], L[key + "_cs"] = wt(Wp, dev), _f32(bp, dev), _f32(cs, dev)
-            else:
-                L[key], L[key + "_b"] = wt(W, dev), (None if bias is None else _f32(bias, dev))
-                L[key + "_ln"] = (_f32(gamma, dev), _f32(beta, dev))
+            """A Linear fed by a LayerNorm (engine.prepare_ln_linear): folded into the GEMM in bf16 mode."""
+            prepare_ln_linear(L, key, W, bias, gamma, beta, fold, lambda x: wt(x, dev), lambda x: _f32(x, dev), q_rows, q_scale)
 
         w["vit"] = []
         for i in range(v["num_hidden_layers"]):
@@ -372,49 +356,9 @@ class TSR(KernelEngine):
             ctx = ctx32
         return ctx, ctx32
 
-    # ---- residual stream with the LayerNorm fold (bf16 mode) ------------------------------------------------------
-    # Every LayerNorm of the two transformers sits between a GEMM that writes the residual stream h and a GEMM that
-    # consumes LN(h).  In bf16 mode the producer also writes bf16(h) and per-row statistics of 32-column slices, and the
-    # consumer applies mean / rstd in its epilogue with gamma / beta folded into its weights (sculpt_gemm_bf16_ln): no
-    # LayerNorm launch, no normalised copy.  fp32 parity mode keeps the stand-alone LayerNorm kernel.
-    def _stream_state(self, name, h):
-        T, D = h.shape
-        st = {"h": h, "name": name}
-        if self.precision == "bf16":
-            st["hb"] = self._b(name + "_hb", (T, D), BF16)
-            st["stats"] = self._b(name + "_stats", (D // ops.LN_SLOT, T, 2), torch.float32)  # slice-major
-        else:
-            st["xn"] = self._b(name + "_xn", (T, D), torch.float32)
-        return st
-
     def _attn_scale(self, scale):
         """bf16 mode: the query projections carry scale * log2(e) (ln_linear q_scale) -> sculpt_attention_bf16's scale = 0 entry."""
         return 0.0 if self.precision == "bf16" else scale
-
-    def _state_from(self, h, name="bb"):
-        """Stream state for a residual stream given as a plain fp32 tensor (tests, external callers)."""
-        st = self._stream_state(name, h)
-        self._stats_of(st)
-        return st
-
-    def _stats_of(self, st):
-        if self.precision == "bf16":
-            ops.row_slice_stats(st["h"], st["stats"], st["hb"])
-
-    def _ln_gemm(self, st, L, key, eps, **kw):
-        """Linear(LayerNorm(h)) with the weights prepared by ln_linear()."""
-        if self.precision == "bf16":
-            return ops.gemm(st["hb"], L[key], bias=L[key + "_b"], ln_stats=st["stats"], ln_colsum=L[key + "_cs"], ln_eps=eps, **kw)
-        g, b = L[key + "_ln"]
-        ops.layernorm(st["h"], g, b, eps, y_f32=st["xn"])
-        return self._gemm(st["xn"], L[key], bias=L[key + "_b"], **kw)
-
-    def _res_gemm(self, st, A, W, bias):
-        """h += A . W^T + bias (in place); bf16 mode also refreshes bf16(h) and the slice statistics."""
-        h = st["h"]
-        if self.precision == "bf16":
-            return ops.gemm(A, W, bias=bias, residual=h, out_f32=h, out_bf16=st["hb"], stats_out=st["stats"])
-        return self._gemm(A, W, bias=bias, residual=h, out_f32=h)
 
     def _self_attention(self, st, L):
         """h += attn1(LN1(h)) of one BasicTransformerBlock (basic_transformer_block.py:149-167)."""
