@@ -302,3 +302,39 @@ def test_triangle_remesh_follows_the_reference_sequence():
     assert chi == 2 and nb == 0
     with pytest.raises(NotImplementedError):
         rm.native_remesher(mesh, "quad", 100)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_isosurface_meshes_with_borders_keep_their_topology(seed):
+    """Marching-cubes surfaces of a random smooth field (several components, handles, open rims where the surface leaves the
+    grid) through the whole triangle_remesh sequence: manifold in -> manifold out, Euler characteristic and the number of
+    boundary loops' worth of rim unchanged in kind (closed stays closed, open stays open), every vertex near the input."""
+    from scipy.spatial import cKDTree
+
+    from oracle import capi
+
+    rng = np.random.default_rng(seed)
+    n = 28
+    g = np.linspace(-1, 1, n)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    vol = np.zeros((n, n, n))
+    for _ in range(6):
+        k = rng.uniform(1.0, 3.5, 3)
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        vol += rng.uniform(0.5, 1.0) * np.sin(k[0] * X + ph[0]) * np.sin(k[1] * Y + ph[1]) * np.sin(k[2] * Z + ph[2])
+    v, f = capi.marching_cubes(vol.astype(np.float32), 0.15)[:2]
+    v, f = v.astype(np.float64), f.astype(np.int32)
+    chi0, nb0 = topology(v, f)
+    vd, fd, _, _ = rm.decimate(v, f, face_ratio=0.4)
+    chi1, nb1 = topology(vd, fd)
+    assert chi1 == chi0 and (nb1 > 0) == (nb0 > 0) and len(fd) <= int(0.4 * len(f)) + 1
+    vr, fr = rm.remesh_botsch(vd, fd, 10, None)
+    chi2, nb2 = topology(vr, fr)
+    assert chi2 == chi0 and (nb2 > 0) == (nb0 > 0)
+    # on the decimated surface; the decimated surface within a cell or so of the isosurface
+    h = edge_lengths(vd, fd).mean()
+    tree = cKDTree(vd)
+    assert tree.query(vr)[0].max() < 1.5 * h
+    assert cKDTree(v).query(vr)[0].max() < 2.5 * h
+    el = edge_lengths(vr, fr)
+    assert ((el > 0.7 * h) & (el < 1.45 * h)).mean() > 0.9
