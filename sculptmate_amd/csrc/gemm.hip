@@ -33,6 +33,9 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 static constexpr int BM = 128;   // activation rows per block
+#ifndef SCULPT_GEMM_READ_AHEAD
+#define SCULPT_GEMM_READ_AHEAD 1
+#endif
 static constexpr int BK = 64;
 
 // GELU(erf).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, below fp32 noise of the GEMM that
@@ -254,6 +257,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         if (kt + DIST < nk) STAGE((kt + DIST) % NSTAGE, kt + DIST);
         const unsigned char *wb = smem + buf * (WT + AT);
         const unsigned char *ab = wb + WT;
+        if (NW == 8 && SCULPT_GEMM_READ_AHEAD) {
+            // both k-steps' fragments are requested before the first MFMA: one exposed LDS latency per K-tile instead of one
+            // per group of four MFMAs (the register budget of the 8-wave tiles allows the 2 (TI + TJ) fragments)
+            bf16x8_t af[2][TI], bfr[2][TJ];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8_t *>(wb + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8_t *>(ab + (boff[j] ^ (ks << 6)));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+            // keep the request order: all 2 (TI + TJ) LDS reads, then the MFMAs (mask 0x100 = DS read, 0x8 = MFMA)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TI + TJ), 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 2 * TI * TJ, 0);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t af[TI], bfr[TJ];
@@ -266,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
         }
     }
 #undef STAGE
