@@ -16,6 +16,8 @@
 // K and V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4) one tile ahead into double-buffered
 // LDS (one barrier per tile); rows use the (row>>1)&7 chunk swizzle (applied to the source address
 // and to the read address) so ds_read_b128 is conflict-free.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sculpt {
@@ -259,8 +261,12 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
                 const abf16x4 a = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c0 << 4)));
                 const abf16x4 b = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c1 << 4)));
                 const abf16x8 v0 = abf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                const abf16x4 c = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c0 << 4)) + 4096);
-                const abf16x4 d = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c1 << 4)) + 4096);
+                // (volatile: left to itself the compiler pairs the pieces of rows qc and 32 + qc -- a constant 4096 bytes apart --
+                // into one ds_read2st64_b64 and then needs 6 v_mov per k-step to regroup them into the two MFMA operands:
+                // 24 VALU instructions per key tile; self-attention 53.5 -> 51.1 us, SF3D's fuse attentions 439 / 414 -> 409 / 389)
+                typedef const volatile __attribute__((address_space(3))) abf16x4 *lds_vol_t;
+                const abf16x4 c = *(lds_vol_t)(Vtl + (vbase ^ (c0 << 4)) + 4096);
+                const abf16x4 d = *(lds_vol_t)(Vtl + (vbase ^ (c1 << 4)) + 4096);
                 const abf16x8 v1 = abf16x8{c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
@@ -322,17 +328,36 @@ extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t 
     SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
     SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
-    // 256-query workgroups (16 waves, one per CU) halve the K/V re-staging; worth it once they still cover 3/4 of the CUs
-    const bool big = (long)cdiv(Tq, 256) * heads * 4 >= (long)num_cus() * 3;
+    // Queries per workgroup: 128, 192 or 256 (8 / 12 / 16 waves, 2 - 4 per SIMD).  A workgroup's time grows with its query
+    // count, a launch lasts ceil(workgroups / CUs) rounds (the 16-wave form fits one per CU; smaller ones are counted the same
+    // way: a second resident workgroup shares the CU's matrix pipe).  3072 queries x 16 heads: 192 workgroups of 256 (3/4 of
+    // the CUs for 8 units of time), 384 of 128 (two rounds of 4), 256 of 192 -- every CU once, 6 units.
+    static const int force = [] { const char *e = getenv("SCULPT_ATTN_NQB"); return e ? atoi(e) : 0; }();
+    // (measured: self-attention 51.1 -> 48.8 us, cross 25.2 -> 23.5 us with 192; a smaller workgroup re-stages the head's K / V
+    // more often, so it has to win by more than 15 %: SF3D's 27 648 queries, 54 against 56 units, ran 4 % slower with 192)
+    int nqb = 8;
+    const long cost8 = cdiv((long)cdiv(Tq, 256) * heads, (long)num_cus()) * 8;
+    long best = cost8 * 100;
+    for (int c : {6, 4}) {
+        const long wgs = (long)cdiv(Tq, 32 * c) * heads, cost = cdiv(wgs, (long)num_cus()) * c;
+        if (cost * 115 < best) { best = cost * 115; nqb = c; }
+    }
+    if (force == 4 || force == 6 || force == 8) nqb = force;
     const float sl = scale * 1.44269504088896340736f;
     hipStream_t st = as_stream(stream);
+    const dim3 grid(cdiv(Tq, 32 * nqb), heads), block(128 * nqb);
+#define SCULPT_ATTN_LAUNCH(NQB, PRE, SC) \
+    hipLaunchKernelGGL((attention_kernel<NQB, PRE>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, SC)
     if (scale == 0.f) {  // Q carries scale * log2(e) already
-        if (big) hipLaunchKernelGGL((attention_kernel<8, true>), dim3(cdiv(Tq, 256), heads), dim3(1024), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, 1.0f);
-        else hipLaunchKernelGGL((attention_kernel<4, true>), dim3(cdiv(Tq, 128), heads), dim3(512), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, 1.0f);
+        if (nqb == 8) SCULPT_ATTN_LAUNCH(8, true, 1.0f);
+        else if (nqb == 6) SCULPT_ATTN_LAUNCH(6, true, 1.0f);
+        else SCULPT_ATTN_LAUNCH(4, true, 1.0f);
     } else {
-        if (big) hipLaunchKernelGGL((attention_kernel<8, false>), dim3(cdiv(Tq, 256), heads), dim3(1024), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, sl);
-        else hipLaunchKernelGGL((attention_kernel<4, false>), dim3(cdiv(Tq, 128), heads), dim3(512), 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, sl);
+        if (nqb == 8) SCULPT_ATTN_LAUNCH(8, false, sl);
+        else if (nqb == 6) SCULPT_ATTN_LAUNCH(6, false, sl);
+        else SCULPT_ATTN_LAUNCH(4, false, sl);
     }
+#undef SCULPT_ATTN_LAUNCH
     SC_LAUNCH_CHECK();
     return 0;
 }
