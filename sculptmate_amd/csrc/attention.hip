@@ -103,26 +103,30 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     // VGPR pairs around the tile loop (global_load_lds with base + offset cost 2-8 VGPRs that way and spilled one pair)
     const auto k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Kh), 0, 0x7fffffff, 0x00020000);
     const auto v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Vh), 0, 0x7fffffff, 0x00020000);
-    auto stage = [&](int buf, int tp) {
-        const bool last = (tp * 128 + 128 > Tk);  // wave-uniform: only the final pair can run past the arrays
+    // K and V of a tile pair are staged separately: kt / vt = tile pair (skipped when past the last one), kbuf / vbuf = ring slot
+    auto stage2 = [&](int kbuf, int kt, int vbuf, int vt) {
 #pragma unroll
         for (int i = 0; i < (32 + NW - 1) / NW; ++i) {
             const int j = wave + NW * i;  // scalar
             if (j < 32) {
                 const int sub = j >> 3, rg = j & 7, half = sub & 1;
-                unsigned char *dst = smem + buf * 32768 + sub * 8192 + rg * 1024;
                 if (sub < 2) {
-                    const int row0 = tp * 128 + half * 64 + 8 * rg;
-                    if (!last) {
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (alds_ptr_t)dst, 16, (rg & 1) ? klane1 : klane0,
-                                                                 row0 * ldk * 2, 0, 0);
-                    } else {
-                        const int key = min(row0 + srow, Tk - 1);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (alds_ptr_t)dst, 16,
-                                                                 (unsigned)(key * ldk + ((rg & 1) ? cs1 : cs0)) * 2u, 0, 0, 0);
+                    if (kt < ntp) {
+                        unsigned char *dst = smem + kbuf * 32768 + sub * 8192 + rg * 1024;
+                        const int row0 = kt * 128 + half * 64 + 8 * rg;
+                        if (kt * 128 + 128 <= Tk) {  // wave-uniform: only the final pair can run past the arrays
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (alds_ptr_t)dst, 16, (rg & 1) ? klane1 : klane0,
+                                                                     row0 * ldk * 2, 0, 0);
+                        } else {
+                            const int key = min(row0 + srow, Tk - 1);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (alds_ptr_t)dst, 16,
+                                                                     (unsigned)(key * ldk + ((rg & 1) ? cs1 : cs0)) * 2u, 0, 0, 0);
+                        }
                     }
-                } else {
-                    const int col = last ? min(tp * 128 + half * 64, ldvt - 64) : tp * 128 + half * 64;
+                } else if (vt < ntp) {
+                    unsigned char *dst = smem + vbuf * 32768 + sub * 8192 + rg * 1024;
+                    const bool last = (vt * 128 + 128 > Tk);
+                    const int col = last ? min(vt * 128 + half * 64, ldvt - 64) : vt * 128 + half * 64;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (alds_ptr_t)dst, 16, (rg & 1) ? vlane1 : vlane0,
                                                              ((8 * rg) * ldvt + col) * 2, 0, 0);
                 }
@@ -143,134 +147,148 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     const int kbase = a_lds_off(qc, h);
     const int vbase = a_lds_off(qc, 0) + 8 * h;  // V^T rows qc / 32+qc, chunk c -> base ^ (c << 4)
 
-    stage(0, 0);
+    // ---- S^T = K . Q^T of the wave's 64 keys of tile pair tp (K in ring slot kbuf)
+    auto qk = [&](int kbuf, f32x16 &s0, f32x16 &s1) {
+        const unsigned char *Kt = smem + kbuf * 32768 + kh * 8192;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        if (PRE) {  // s = -M for every key of this query (column), first: the K fragments are not live yet; m_run == hi + lo exactly
+            const __bf16 hi = (__bf16)m_run;
+            const __bf16 lo = (__bf16)(m_run - (float)hi);
+            const unsigned neg = ((unsigned)(unsigned short)__builtin_bit_cast(short, hi) |
+                                  ((unsigned)(unsigned short)__builtin_bit_cast(short, lo) << 16)) ^ 0x80008000u;
+            const unsigned w_ones = h == 0 ? 0x3f803f80u : 0u, w_mq = h == 0 ? neg : 0u;
+            const abf16x4s ones = {(short)(w_ones & 0xffffu), (short)(w_ones >> 16), 0, 0};
+            const abf16x4s mq = {(short)(w_mq & 0xffffu), (short)(w_mq >> 16), 0, 0};
+            s0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ones, mq, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ones, mq, s1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const abf16x8 k0 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)));
+            const abf16x8 k1 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)) + 4096);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
+        }
+    };
+
+    // ---- online softmax over this lane's 32 keys (+ the other half's 32) of tile pair tp, then O^T += V^T . P^T (V in slot vbuf)
+    auto softmax_pv = [&](int tp, int vbuf, f32x16 &s0, f32x16 &s1) {
+        const int key_start = tp * 128 + kh * 64;
+        const unsigned char *Vtl = smem + vbuf * 32768 + (2 + kh) * 8192;
+        if (key_start + 64 > Tk) {  // ragged last tile only
+            const int kb = key_start + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key0 = kb + (r & 3) + 8 * (r >> 2);
+                if (key0 >= Tk) s0[r] = -INFINITY;
+                if (key0 + 32 >= Tk) s1[r] = -INFINITY;
+            }
+        }
+        float mx = max3f(s0[0], s1[0], s0[1]);
+        mx = max3f(mx, s1[1], s0[2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) mx = max3f(mx, s1[r], s0[r + 1]);
+        mx = max3f(mx, s1[15], __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both halves now hold the row maximum
+        af32x2 ps = {0.f, 0.f};
+        if (PRE) {
+            // mx = (tile maximum) - M.  Rescale when this is the wave's first tile or some query jumped by > 2^PRE_THR
+            const bool need = tp == 0 || mx > PRE_THR;  // (a wave's first tile is tile pair 0, or it has no tile at all)
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
+                float m_new = m_run;
+                if (need && mx > -INFINITY) {
+                    const float t = m_run + mx;
+                    const __bf16 hi = (__bf16)t;
+                    const __bf16 lo = (__bf16)(t - (float)hi);
+                    m_new = (float)hi + (float)lo;  // M stays exactly representable as the two bf16 parts
+                }
+                const float delta = m_new - m_run;
+                m_run = m_new;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                af32x2 a = {__builtin_amdgcn_exp2f(s0[r]), __builtin_amdgcn_exp2f(s0[r + 1])};
+                af32x2 b = {__builtin_amdgcn_exp2f(s1[r]), __builtin_amdgcn_exp2f(s1[r + 1])};
+                s0[r] = a[0]; s0[r + 1] = a[1];
+                s1[r] = b[0]; s1[r + 1] = b[1];
+                ps += a;
+                ps += b;
+            }
+        } else {
+            const float m_new = fmaxf(m_run, mx);
+            // rescale the running state only when some query of the wave saw a new maximum (wave-uniform branch)
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                m_run = m_new;
+            }
+            const float mc = -m_run * scale_log2e;
+            const af32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                af32x2 a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
+                a = a * sc2 + mc2;  // v_pk_fma_f32
+                b = b * sc2 + mc2;
+                a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+                b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
+                s0[r] = a[0]; s0[r + 1] = a[1];
+                s1[r] = b[0]; s1[r + 1] = b[1];
+                ps += a;
+                ps += b;
+            }
+        }
+        l_run += ps[0] + ps[1];
+        // ---- O^T += V^T . P^T   (4 k-steps of 16 keys)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            abf16x8 pb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = (kk < 2) ? s0[8 * (kk & 1) + j] : s1[8 * (kk & 1) + j];
+                pb[j] = (__bf16)pv;
+            }
+            // keys of element j: 16*kk + 8*(j>>2) + 4h + (j&3)  -> two 8-byte reads per d row
+            const int c0 = 2 * kk, c1 = 2 * kk + 1;
+            const abf16x4 a = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c0 << 4)));
+            const abf16x4 b = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c1 << 4)));
+            const abf16x8 v0 = abf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            // (volatile: left to itself the compiler pairs the pieces of rows qc and 32 + qc -- a constant 4096 bytes apart --
+            // into one ds_read2st64_b64 and then needs 6 v_mov per k-step to regroup them into the two MFMA operands:
+            // 24 VALU instructions per key tile; self-attention 53.5 -> 51.1 us, SF3D's fuse attentions 439 / 414 -> 409 / 389)
+            typedef const volatile __attribute__((address_space(3))) abf16x4 *lds_vol_t;
+            const abf16x4 c = *(lds_vol_t)(Vtl + (vbase ^ (c0 << 4)) + 4096);
+            const abf16x4 d = *(lds_vol_t)(Vtl + (vbase ^ (c1 << 4)) + 4096);
+            const abf16x8 v1 = abf16x8{c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
+        }
+    };
+
+    // A software-pipelined form of this loop -- the scores of tile pair tp + 1 requested from the matrix pipe BEFORE the softmax
+    // of tile pair tp (K one tile pair ahead of V in the ring, two score accumulator sets, 159 VGPRs, 12- and 8-wave workgroups)
+    // -- was built on these two lambdas, gave identical results and was no faster: 49.5 vs 48.2 us at 3072 x 3072 x 16.  PMC of
+    // the loop (tools/attn_pmc.sh): VALU active 41 % of the SIMD cycles (32 quarter-rate v_exp_f32 per wave and key tile are
+    // 512 of its ~720 VALU cycles), matrix pipe busy 31 %, some instruction active 68 %: the two do not overlap on a SIMD,
+    // whatever the program order -- the loop is bound by their SUM.
+    stage2(0, 0, 0, 0);
     for (int tp = 0; tp < ntp; ++tp) {
         const int buf = tp & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tp + 1 < ntp) stage(buf ^ 1, tp + 1);
-        const int key_start = tp * 128 + kh * 64;
-        if (key_start < Tk) {  // wave-uniform: a wholly out-of-range tile is skipped
-            const unsigned char *Kt = smem + buf * 32768 + kh * 8192;
-            const unsigned char *Vtl = smem + buf * 32768 + (2 + kh) * 8192;
-            // ---- S^T = K . Q^T
+        stage2(buf ^ 1, tp + 1, buf ^ 1, tp + 1);
+        if (tp * 128 + kh * 64 < Tk) {  // wave-uniform: a wholly out-of-range tile is skipped
             f32x16 s0, s1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-            if (PRE) {  // s = -M for every key of this query (column), first: the K fragments are not live yet; m_run == hi + lo exactly
-                const __bf16 hi = (__bf16)m_run;
-                const __bf16 lo = (__bf16)(m_run - (float)hi);
-                const unsigned neg = ((unsigned)(unsigned short)__builtin_bit_cast(short, hi) |
-                                      ((unsigned)(unsigned short)__builtin_bit_cast(short, lo) << 16)) ^ 0x80008000u;
-                const unsigned w_ones = h == 0 ? 0x3f803f80u : 0u, w_mq = h == 0 ? neg : 0u;
-                const abf16x4s ones = {(short)(w_ones & 0xffffu), (short)(w_ones >> 16), 0, 0};
-                const abf16x4s mq = {(short)(w_mq & 0xffffu), (short)(w_mq >> 16), 0, 0};
-                s0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ones, mq, s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ones, mq, s1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const abf16x8 k0 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)));
-                const abf16x8 k1 = *reinterpret_cast<const abf16x8 *>(Kt + (kbase ^ (ks << 5)) + 4096);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ks], s1, 0, 0, 0);
-            }
-            // ---- online softmax over this lane's 32 keys (+ the other half's 32)
-            if (key_start + 64 > Tk) {  // ragged last tile only
-                const int kb = key_start + 4 * h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key0 = kb + (r & 3) + 8 * (r >> 2);
-                    if (key0 >= Tk) s0[r] = -INFINITY;
-                    if (key0 + 32 >= Tk) s1[r] = -INFINITY;
-                }
-            }
-            float mx = max3f(s0[0], s1[0], s0[1]);
-            mx = max3f(mx, s1[1], s0[2]);
-#pragma unroll
-            for (int r = 2; r < 15; ++r) mx = max3f(mx, s1[r], s0[r + 1]);
-            mx = max3f(mx, s1[15], __shfl_xor(mx, 32, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both halves now hold the row maximum
-            af32x2 ps = {0.f, 0.f};
-            if (PRE) {
-                // mx = (tile maximum) - M.  Rescale when this is the wave's first tile or some query jumped by > 2^PRE_THR
-                const bool need = tp == 0 || mx > PRE_THR;  // (a wave's first tile is tile pair 0, or it has no tile at all)
-                if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
-                    float m_new = m_run;
-                    if (need && mx > -INFINITY) {
-                        const float t = m_run + mx;
-                        const __bf16 hi = (__bf16)t;
-                        const __bf16 lo = (__bf16)(t - (float)hi);
-                        m_new = (float)hi + (float)lo;  // M stays exactly representable as the two bf16 parts
-                    }
-                    const float delta = m_new - m_run;
-                    m_run = m_new;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    af32x2 a = {__builtin_amdgcn_exp2f(s0[r]), __builtin_amdgcn_exp2f(s0[r + 1])};
-                    af32x2 b = {__builtin_amdgcn_exp2f(s1[r]), __builtin_amdgcn_exp2f(s1[r + 1])};
-                    s0[r] = a[0]; s0[r + 1] = a[1];
-                    s1[r] = b[0]; s1[r + 1] = b[1];
-                    ps += a;
-                    ps += b;
-                }
-            } else {
-                const float m_new = fmaxf(m_run, mx);
-                // rescale the running state only when some query of the wave saw a new maximum (wave-uniform branch)
-                if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-                    m_run = m_new;
-                }
-                const float mc = -m_run * scale_log2e;
-                const af32x2 sc2 = {scale_log2e, scale_log2e}, mc2 = {mc, mc};
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    af32x2 a = {s0[r], s0[r + 1]}, b = {s1[r], s1[r + 1]};
-                    a = a * sc2 + mc2;  // v_pk_fma_f32
-                    b = b * sc2 + mc2;
-                    a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
-                    b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
-                    s0[r] = a[0]; s0[r + 1] = a[1];
-                    s1[r] = b[0]; s1[r + 1] = b[1];
-                    ps += a;
-                    ps += b;
-                }
-            }
-            l_run += ps[0] + ps[1];
-            // ---- O^T += V^T . P^T   (4 k-steps of 16 keys)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                abf16x8 pb;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = (kk < 2) ? s0[8 * (kk & 1) + j] : s1[8 * (kk & 1) + j];
-                    pb[j] = (__bf16)pv;
-                }
-                // keys of element j: 16*kk + 8*(j>>2) + 4h + (j&3)  -> two 8-byte reads per d row
-                const int c0 = 2 * kk, c1 = 2 * kk + 1;
-                const abf16x4 a = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c0 << 4)));
-                const abf16x4 b = *reinterpret_cast<const abf16x4 *>(Vtl + (vbase ^ (c1 << 4)));
-                const abf16x8 v0 = abf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                // (volatile: left to itself the compiler pairs the pieces of rows qc and 32 + qc -- a constant 4096 bytes apart --
-                // into one ds_read2st64_b64 and then needs 6 v_mov per k-step to regroup them into the two MFMA operands:
-                // 24 VALU instructions per key tile; self-attention 53.5 -> 51.1 us, SF3D's fuse attentions 439 / 414 -> 409 / 389)
-                typedef const volatile __attribute__((address_space(3))) abf16x4 *lds_vol_t;
-                const abf16x4 c = *(lds_vol_t)(Vtl + (vbase ^ (c0 << 4)) + 4096);
-                const abf16x4 d = *(lds_vol_t)(Vtl + (vbase ^ (c1 << 4)) + 4096);
-                const abf16x8 v1 = abf16x8{c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb, o1, 0, 0, 0);
-            }
+            qk(buf, s0, s1);
+            softmax_pv(tp, buf, s0, s1);
         }
     }
     // ---- merge the two key halves of each query block through LDS: layout [qi][r (0..33)][lane]
