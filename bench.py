@@ -320,8 +320,8 @@ def sf3d_extra(device, n=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional-modes", action="store_true",
                     help="skip the informational split-operand rates (profiling runs: keeps the kernel rows to the default path)")
