@@ -11,10 +11,9 @@ the per-slab meshes in rank order reproduces the single-GPU mesh exactly (vertic
   * everything else is local; ids only need the rank's vertex base offset.
 The only exchange step is the gather of (verts, faces, top_plane_map) -- one padded all_gather each.
 """
-import numpy as np
 import torch
 
-from . import ops, parallel
+from . import ops
 
 
 def slab_ranges(R, world):

@@ -23,7 +23,7 @@ import torch
 from .. import _lib, ops
 from ..engine import KernelEngine, prepare_ln_linear
 from .posemb import interpolate_pos_embedding
-from .utils import ImagePreprocessor, scale_tensor
+from .utils import ImagePreprocessor
 
 BF16 = torch.bfloat16
 LOG2E = 1.4426950408889634

@@ -402,6 +402,12 @@ def test_fast3d_generator_facade(cuda, tmp_path):
     fw = inv.reshape(-1)[fr].astype(np.int64)
     de = np.concatenate([fw[:, [0, 1]], fw[:, [1, 2]], fw[:, [2, 0]]], 0)
     assert len(np.unique(de[:, 0] * (int(fw.max()) + 2) + de[:, 1])) == len(de)  # every directed edge once: consistently oriented
+    # the add-on's default call: remesh + unwrap + texture bake on the remeshed surface (generate.py:32-36)
+    assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, enable_texture=True) == 0
+    full = g.last_mesh
+    assert full["faces"].shape[0] == len(fr) and full["uvs"].shape == (3 * len(fr), 2)
+    assert full["basecolor_tex"].size == (64, 64) and full["bump_tex"].size == (64, 64)
+    assert np.isfinite(np.asarray(full["vertices"])).all() and 0.0 <= np.asarray(full["uvs"]).min() and np.asarray(full["uvs"]).max() <= 1.0
     # without a remesher the facade hands over the un-remeshed mesh (with a printed warning), the model itself refuses
     g.model.remesher = None
     assert g.generate_mesh(img, "thing", remesh_option="triangle", texture_resolution=64, enable_texture=False) == 0

@@ -3,7 +3,6 @@ made by tests/golden/make_sf3d_goldens.py in the build container).  CPU only."""
 import os
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import sf3d_ref as R
