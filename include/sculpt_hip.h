@@ -114,6 +114,10 @@ size_t sculpt_density_grid_workspace_bytes(int R, int nx);
 int sculpt_plane_features(const float *planes, int C, int H, int W, const void *mlp_packed,
                           const float *axis_coords, int R, int x_begin, int x_end, float radius,
                           void *workspace, sculpt_stream_t stream);
+/* The same tables with flags: SCULPT_QUERY_ALIGN_CORNERS = grid_sample(align_corners=True), SF3D's query (sf3d/system.py:185-195). */
+int sculpt_plane_features_ex(const float *planes, int C, int H, int W, const void *mlp_packed,
+                             const float *axis_coords, int R, int x_begin, int x_end, float radius, unsigned flags,
+                             void *workspace, sculpt_stream_t stream);
 int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                         float density_bias, float out_add, const void *workspace, float *out,
                         sculpt_stream_t stream);
@@ -127,6 +131,11 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
 int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                            float density_bias, float out_add, const void *workspace, float *out, unsigned flags,
                            sculpt_stream_t stream);
+/* Step 2 for a decoder head with a 3-channel output (SF3D's MaterialMLP heads evaluated on the marching-tetrahedra lattice,
+ * sf3d/system.py:141-168 + network.py:148-210): density_act (nullable) = exp(row 0 + density_bias) + out_add as above,
+ * features (nullable) f32 [(x_end-x_begin)*R*R][3] = rows 1..3 of the last layer, raw.  Exact-fp32 kernel only. */
+int sculpt_grid_decode(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end, float density_bias,
+                       float out_add, const void *workspace, float *density_act, float *features, sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Marching cubes (Lewiner), output identical to skimage.measure.marching_cubes(vol, level)

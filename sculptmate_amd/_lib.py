@@ -45,6 +45,8 @@ SIGNATURES = {
     "sculpt_planes_channel_last": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "sculpt_density_grid_workspace_bytes": (_sz, [_i, _i]),
     "sculpt_plane_features": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "sculpt_plane_features_ex": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _f, _u, _vp, _vp]),
+    "sculpt_grid_decode": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sculpt_density_grid_ex": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _u, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),

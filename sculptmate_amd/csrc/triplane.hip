@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void query_points_kernel(
 // of one cache line per lane.  A lane keeps its pair's 64 pre-activations in registers and runs, channel by channel, the
 // same fmaf chain (c ascending) one thread per (pair, neuron) would run; the weights of the workgroup's table sit in LDS
 // (wl[c][j], j in accumulator order) and are read as broadcasts.  Four waves = four consecutive b.
-template <int C>
+template <int C, bool AC = false>
 __global__ __launch_bounds__(256) void plane_features_kernel(
     const float *__restrict__ planes, int H, int W, const float *__restrict__ blob,
     const float *__restrict__ axis, int R, int x_begin, int nx, float radius, float span,
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void plane_features_kernel(
     const int ac = live ? a : na - 1;
     const int ia = (k == 2) ? ac : ac + x_begin;
     const float gx = to_unit(axis[ia], radius, span), gy = to_unit(axis[b], radius, span);
-    Tap1 tx = tap_of(gx, W), ty = tap_of(gy, H);
+    Tap1 tx = tap_of<AC>(gx, W), ty = tap_of<AC>(gy, H);
     const float wx = tx.w1, ex = 1.0f - wx, wy = ty.w1, ey = 1.0f - wy;
     const int x0 = tx.i0, x1 = x0 + 1, y0 = ty.i0, y1 = y0 + 1;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
@@ -475,11 +475,13 @@ __device__ __forceinline__ void load_row32(const float *row, f32x16 &a, f32x16 &
     }
 }
 
-template <int NT>
+// FEAT (the SF3D lattice decode, sculpt_grid_decode): also / instead writes rows 1..3 of the last layer, raw, as
+// features[idx][3]; `out` may then be null.  The TripoSR launch uses FEAT = false: its code is unchanged.
+template <int NT, bool FEAT = false>
 __global__ __launch_bounds__(NT) void density_grid_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
     const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out,
-    int xcd_band) {
+    int xcd_band, float *__restrict__ features = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
@@ -524,7 +526,16 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
         x0 = silu16(x0); x1 = silu16(x1);
         hidden_layers(L, NH, lane, h, x0, x1);
         const float d = last_dot(L, 0, h, x0, x1);
-        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
+        if (!FEAT) {
+            if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
+        } else {
+            const float f0 = last_dot(L, 1, h, x0, x1), f1 = last_dot(L, 2, h, x0, x1), f2 = last_dot(L, 3, h, x0, x1);
+            if (h == 0 && iz < R) {
+                const long idx = ((long)ixl * R + iy) * R + iz;
+                if (out) out[idx] = exp_f(d + density_bias) + out_add;
+                if (features) { features[3 * idx] = f0; features[3 * idx + 1] = f1; features[3 * idx + 2] = f2; }
+            }
+        }
     }
 }
 
@@ -829,7 +840,14 @@ size_t sculpt_density_grid_workspace_bytes(int R, int nx) {
 int sculpt_plane_features(const float *planes, int C, int H, int W, const void *mlp_packed,
                           const float *axis_coords, int R, int x_begin, int x_end, float radius,
                           void *workspace, sculpt_stream_t stream) {
+    return sculpt_plane_features_ex(planes, C, H, W, mlp_packed, axis_coords, R, x_begin, x_end, radius, 0u, workspace, stream);
+}
+
+int sculpt_plane_features_ex(const float *planes, int C, int H, int W, const void *mlp_packed,
+                             const float *axis_coords, int R, int x_begin, int x_end, float radius, unsigned flags,
+                             void *workspace, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
+    SC_REQUIRE((flags & ~SCULPT_QUERY_ALIGN_CORNERS) == 0, "plane_features: planes are channel-first [3][C][H][W]; unknown flags %u", flags);
     SC_REQUIRE(C == 40, "plane_features: built for C=40 channels per plane (got %d)", C);
     SC_REQUIRE(planes && mlp_packed && axis_coords && workspace, "plane_features: null argument");
     SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "plane_features: bad range [%d,%d) of %d", x_begin, x_end, R);
@@ -842,9 +860,14 @@ int sculpt_plane_features(const float *planes, int C, int H, int W, const void *
     (void)pairs;
     const long pf_bg = (R + 3) / 4;
     const long pf_blocks = 2 * (long)((nx + 63) / 64) * pf_bg + (long)((R + 63) / 64) * pf_bg;
-    hipLaunchKernelGGL(plane_features_kernel<40>, dim3((unsigned)pf_blocks), dim3(256), 0, st, planes, H, W,
-                       reinterpret_cast<const float *>(mlp_packed), axis_coords, R, x_begin, nx, radius,
-                       span, FA, FB, FC);
+    if (flags & SCULPT_QUERY_ALIGN_CORNERS)
+        hipLaunchKernelGGL((plane_features_kernel<40, true>), dim3((unsigned)pf_blocks), dim3(256), 0, st, planes, H, W,
+                           reinterpret_cast<const float *>(mlp_packed), axis_coords, R, x_begin, nx, radius,
+                           span, FA, FB, FC);
+    else
+        hipLaunchKernelGGL((plane_features_kernel<40, false>), dim3((unsigned)pf_blocks), dim3(256), 0, st, planes, H, W,
+                           reinterpret_cast<const float *>(mlp_packed), axis_coords, R, x_begin, nx, radius,
+                           span, FA, FB, FC);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -892,6 +915,28 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
         hipLaunchKernelGGL(density_grid_kernel<512>, dim3(grid), dim3(512), lds, st,
                            reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out, xcd_band);
     }
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_grid_decode(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end, float density_bias,
+                       float out_add, const void *workspace, float *density_act, float *features, sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    SC_REQUIRE(mlp_packed && workspace && (density_act || features), "grid_decode: null argument");
+    SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "grid_decode: bad range [%d,%d) of %d", x_begin, x_end, R);
+    SC_REQUIRE(n_hidden_64 >= 0, "grid_decode: bad n_hidden_64");
+    const size_t lds = lds_bytes_for(n_hidden_64);
+    SC_REQUIRE(lds <= 160 * 1024, "grid_decode: %d hidden layers do not fit LDS", n_hidden_64);
+    const int nx = x_end - x_begin;
+    const float *FA = reinterpret_cast<const float *>(workspace);
+    const float *FB = FA + (size_t)nx * R * 64;
+    const float *FC = FB + (size_t)nx * R * 64;
+    const long ntiles = (long)nx * ((R + 31) / 32) * R;
+    auto kern = density_grid_kernel<1024, true>;
+    SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
+                       density_bias, out_add, density_act, 1, features);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -112,6 +112,34 @@ def _workspace(key, nbytes, device):
 _DENSITY_FLAGS = {"fp32": 0, "bf16x3": _lib.DENSITY_BF16X3, "fp16x3": _lib.DENSITY_FP16X3}
 
 
+def lattice_decode(planes, mlp, axis, radius, density_bias=0.0, out_add=0.0, want=("density_act",), align_corners=True,
+                   out=None):
+    """One decoder head on the full R^3 lattice point(ix, iy, iz) = (axis[ix], axis[iy], axis[iz]), flat order
+    (ix*R + iy)*R + iz, through the separable layer-0 tables (sculpt_plane_features_ex + sculpt_grid_decode): what
+    triplane_query + the head MLP give at those points, with the first layer's sum regrouped per plane.
+    axis f32 [R] device (world coordinates exactly as the caller's positions have them); planes [3,C,H,W] channel-first.
+    want: "density_act" -> f32 [R^3] = exp(row 0 + density_bias) + out_add; "features" -> f32 [R^3, 3] = rows 1..3, raw."""
+    planes = _req(planes, torch.float32, "planes")
+    axis = _req(axis, torch.float32, "axis")
+    R = int(axis.numel())
+    _, C, H, W = planes.shape
+    ws = _workspace(("dg", planes.device), lib.sculpt_density_grid_workspace_bytes(R, R), planes.device)
+    res = {}
+    if "density_act" in want:
+        res["density_act"] = out if out is not None else torch.empty(R * R * R, dtype=torch.float32, device=planes.device)
+    if "features" in want:
+        res["features"] = torch.empty((R * R * R, 3), dtype=torch.float32, device=planes.device)
+    if not res:
+        raise SculptError("lattice_decode: want must name density_act and / or features")
+    flags = _lib.QUERY_ALIGN_CORNERS if align_corners else 0
+    check(lib.sculpt_plane_features_ex(_ptr(planes), C, H, W, _ptr(mlp.blob), _ptr(axis), R, 0, R, float(radius), flags,
+                                       _ptr(ws), _stream()))
+    check(lib.sculpt_grid_decode(_ptr(mlp.blob), mlp.n_hidden, R, 0, R, float(density_bias), float(out_add), _ptr(ws),
+                                 _ptr(res["density_act"]) if "density_act" in res else None,
+                                 _ptr(res["features"]) if "features" in res else None, _stream()))
+    return res
+
+
 def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None,
                  out_add=0.0, events=None, precision="fp32"):
     """density_act (+ out_add) over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]

@@ -134,6 +134,24 @@ class MaterialMLP:
             out[name] = r[None]  # the reference keeps a leading batch dimension of 1
         return out
 
+    def lattice_heads(self, planes, axis, radius, density_out_add=0.0, density_out=None):
+        """The "density" and "vertex_offset" heads on the full lattice axis x axis x axis (flat order (ix*R + iy)*R + iz) --
+        what triplane_to_meshes asks of query_triplane + this decoder (system.py:141-168) when the marching-tetrahedra grid is
+        a regular lattice: the first layer is linear in the three plane samples, so it is evaluated once per lattice PAIR and
+        plane (3 R^2 rows) instead of per point (ops.lattice_decode).  -> (density_act + density_out_add [R^3], offsets [R^3, 3]),
+        or None when a head is not of the shape the lattice kernel writes (then the caller takes the per-point path)."""
+        d, v = self.heads.get("density"), self.heads.get("vertex_offset")
+        if d is None or v is None:
+            return None
+        (dh, dmlp), (vh, vmlp) = d, v
+        if (dh["out_channels"], dh["output_activation"]) != (1, "trunc_exp") or \
+                (vh["out_channels"], vh["output_activation"], float(vh["out_bias"])) != (3, None, 0.0):
+            return None
+        dens = ops.lattice_decode(planes, dmlp, axis, radius, density_bias=float(dh["out_bias"]), out_add=density_out_add,
+                                  want=("density_act",), out=density_out)["density_act"]
+        offs = ops.lattice_decode(planes, vmlp, axis, radius, want=("features",))["features"]
+        return dens, offs
+
 
 class Mesh:
     """sf3d/models/mesh.py:18-139, 236-262: positions, faces, lazily computed normals / tangents / UVs."""
@@ -234,6 +252,9 @@ class SF3D(KernelEngine):
         from .remesh import default_remesher
 
         self.remesher = default_remesher()
+        # triplane_to_meshes: evaluate the density / vertex_offset heads through the separable lattice kernels when the
+        # tetrahedral grid is a regular lattice (False: always the per-point query, as the reference does it)
+        self.lattice_decode = True
         # built by load_state_dict when the checkpoint carries their weights (estimators.py); None otherwise, and
         # then roughness / metallic stay None in run_image's dict
         self.image_estimator = None
@@ -464,6 +485,17 @@ class SF3D(KernelEngine):
         # scale_tensor(grid_vertices, (0,1), bbox): ((g - 0) / (1 - 0)) * (hi - lo) + lo, fp32 op by op
         world = ((gv - np.float32(0)) / np.float32(1)) * np.float32(self._bbox_mul) + np.float32(self._bbox_add)
         self._grid_world = _f32(world.astype(np.float32), dev)
+        # Is the grid the plain (n x n x n) lattice in ij-order (the Kuhn stand-in is; the reference's npz file may not be)?
+        # Then the two heads of triplane_to_meshes run through the separable lattice kernels (MaterialMLP.lattice_heads).
+        self._lattice_axis = None
+        n = int(round(gv.shape[0] ** (1.0 / 3.0)))
+        if n >= 2 and n ** 3 == gv.shape[0]:
+            w4 = world.astype(np.float32).reshape(n, n, n, 3)
+            ax = w4[0, 0, :, 2].copy()
+            if (np.array_equal(w4[..., 2], np.broadcast_to(ax[None, None, :], (n, n, n))) and
+                    np.array_equal(w4[..., 1], np.broadcast_to(ax[None, :, None], (n, n, n))) and
+                    np.array_equal(w4[..., 0], np.broadcast_to(ax[:, None, None], (n, n, n)))):
+                self._lattice_axis = _f32(ax, dev)
         self._pos_cache = {}
 
     def _pos(self, n_side, dev):
@@ -696,11 +728,18 @@ class SF3D(KernelEngine):
         meshes = []
         h = self.isosurface_helper
         for i in range(triplanes.shape[0]):
-            values = self.query_triplane(self._grid_world, triplanes[i])
-            decoded = self.decoder(values, include=["vertex_offset", "density"])
             sdf = self._b("sdf", (h.grid.n_vertices,), torch.float32)
-            torch.sub(decoded["density"].reshape(-1), self.cfg["isosurface_threshold"], out=sdf)
-            deform = decoded["vertex_offset"].reshape(-1, 3)
+            fast = None
+            if self._lattice_axis is not None and self.lattice_decode:
+                fast = self.decoder.lattice_heads(triplanes[i].contiguous(), self._lattice_axis, self.cfg["radius"],
+                                                  density_out_add=-float(self.cfg["isosurface_threshold"]), density_out=sdf)
+            if fast is not None:
+                deform = fast[1]
+            else:
+                values = self.query_triplane(self._grid_world, triplanes[i])
+                decoded = self.decoder(values, include=["vertex_offset", "density"])
+                torch.sub(decoded["density"].reshape(-1), self.cfg["isosurface_threshold"], out=sdf)
+                deform = decoded["vertex_offset"].reshape(-1, 3)
             meshes.append(h(sdf, deform, vert_mul=self._bbox_mul, vert_add=self._bbox_add, unwrapper=self.unwrapper))
         return meshes
 

@@ -205,6 +205,16 @@ def test_small_sf3d_mesh_vs_oracle(cuda):
     assert abs(rv.shape[0] - ev.shape[0]) <= max(8, 0.01 * rv.shape[0])
     nrm = mesh.v_nrm
     assert nrm.shape == mesh.v_pos.shape and torch.isfinite(nrm).all()
+    # the run above took the separable lattice kernels (the Kuhn grid is a plain lattice); the per-point query of the
+    # reference's formulation gives the same field up to the regrouped fp32 sum of the first layer
+    assert m._lattice_axis is not None and m.lattice_decode
+    m.lattice_decode = False
+    mesh_pt = m.triplane_to_meshes(codes[None])[0]
+    sdf_pt = mesh_pt.extras["grid_level"].cpu().numpy()
+    np.testing.assert_allclose(sdf, sdf_pt, rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(mesh.extras["grid_vertices"].cpu().numpy(), mesh_pt.extras["grid_vertices"].cpu().numpy(),
+                               rtol=0, atol=1e-6)
+    assert abs(mesh_pt.v_pos.shape[0] - mesh.v_pos.shape[0]) <= max(4, 0.002 * mesh.v_pos.shape[0])
 
 
 def test_sf3d_rejects_cpu_and_bad_state(cuda):
