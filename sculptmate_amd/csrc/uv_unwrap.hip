@@ -130,8 +130,9 @@ __global__ __launch_bounds__(UVB) void uv_rotate_mesh_kernel(const float *__rest
             b = fmaxf(b, __shfl_xor(b, d, 64));
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&st[ST_BBOX_MIN + r], uv_f2ord(a));
-            atomicMax(&st[ST_BBOX_MAX + r], uv_f2ord(b));
+            const volatile unsigned *sv = st;
+            if (uv_f2ord(a) < sv[ST_BBOX_MIN + r]) atomicMin(&st[ST_BBOX_MIN + r], uv_f2ord(a));
+            if (uv_f2ord(b) > sv[ST_BBOX_MAX + r]) atomicMax(&st[ST_BBOX_MAX + r], uv_f2ord(b));
         }
     }
 }
@@ -332,8 +333,9 @@ __global__ __launch_bounds__(UVB) void uv_rotate_chart_kernel(float *__restrict_
             b = fmaxf(b, __shfl_xor(b, d, 64));
         }
         if ((threadIdx.x & 63) == 0 && a <= b) {
-            atomicMin(&st[ST_CH_MIN + c], uv_f2ord(a));
-            atomicMax(&st[ST_CH_MAX + c], uv_f2ord(b));
+            const volatile unsigned *sv = st;
+            if (uv_f2ord(a) < sv[ST_CH_MIN + c]) atomicMin(&st[ST_CH_MIN + c], uv_f2ord(a));
+            if (uv_f2ord(b) > sv[ST_CH_MAX + c]) atomicMax(&st[ST_CH_MAX + c], uv_f2ord(b));
         }
     }
 }
@@ -439,17 +441,43 @@ __global__ __launch_bounds__(UVB) void uv_slice_stats_kernel(const float *__rest
                                                              unsigned *__restrict__ st, int *__restrict__ block_cnt) {
     const long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool rem = false;
+    int slice = -1;
+    float umin = FLT_MAX, umax = -FLT_MAX, vmin = FLT_MAX, vmax = -FLT_MAX;
     if (f < nf) {
         const int a = assigned[f];
         rem = a >= 12;
         if (a >= 6 && a < 12) {
             const float *t = face_uv + 6 * f;
-            const float umin = fminf(t[0], fminf(t[2], t[4])), umax = fmaxf(t[0], fmaxf(t[2], t[4]));
-            const float vmin = fminf(t[1], fminf(t[3], t[5])), vmax = fmaxf(t[1], fmaxf(t[3], t[5]));
-            atomicMin(&st[ST_SL_UMIN + a - 6], uv_f2ord(umin));
-            atomicMax(&st[ST_SL_UMAX + a - 6], uv_f2ord(umax));
-            atomicMin(&st[ST_SL_VMIN + a - 6], uv_f2ord(vmin));
-            atomicMax(&st[ST_SL_VMAX + a - 6], uv_f2ord(vmax));
+            slice = a - 6;
+            umin = fminf(t[0], fminf(t[2], t[4])); umax = fmaxf(t[0], fmaxf(t[2], t[4]));
+            vmin = fminf(t[1], fminf(t[3], t[5])); vmax = fmaxf(t[1], fmaxf(t[3], t[5]));
+        }
+    }
+    // one atomic per wave, slice and bound instead of four per face: every face of a slice hits the same four words
+    // (9.6 M faces: 20.7 ms of same-address atomics -> wave reductions first, like the chart bounds above)
+    if (__ballot(slice >= 0) != 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const bool mine = slice == c;
+            if (__ballot(mine) == 0) continue;  // wave-uniform
+            float a0 = mine ? umin : FLT_MAX, a1 = mine ? umax : -FLT_MAX, b0 = mine ? vmin : FLT_MAX, b1 = mine ? vmax : -FLT_MAX;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                a0 = fminf(a0, __shfl_xor(a0, d, 64));
+                a1 = fmaxf(a1, __shfl_xor(a1, d, 64));
+                b0 = fminf(b0, __shfl_xor(b0, d, 64));
+                b1 = fmaxf(b1, __shfl_xor(b1, d, 64));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                // ... and only when the wave's bound improves on what is already there (a plain load: the bounds settle
+                // after the first few thousand faces, the remaining same-address atomics would still serialise in L2)
+                const unsigned o0 = uv_f2ord(a0), o1 = uv_f2ord(a1), p0 = uv_f2ord(b0), p1 = uv_f2ord(b1);
+                const volatile unsigned *sv = st;
+                if (o0 < sv[ST_SL_UMIN + c]) atomicMin(&st[ST_SL_UMIN + c], o0);
+                if (o1 > sv[ST_SL_UMAX + c]) atomicMax(&st[ST_SL_UMAX + c], o1);
+                if (p0 < sv[ST_SL_VMIN + c]) atomicMin(&st[ST_SL_VMIN + c], p0);
+                if (p1 > sv[ST_SL_VMAX + c]) atomicMax(&st[ST_SL_VMAX + c], p1);
+            }
         }
     }
     __shared__ int wc[UVB / 64];
