@@ -350,6 +350,28 @@ def test_end_to_end_run_returns_meshes(cuda):
     assert np.array_equal(v.view(np.uint32), rv.astype(np.float32).view(np.uint32))
 
 
+def test_batch_of_images_equals_one_at_a_time(cuda):
+    """BASELINE config 3 per GPU: TSR.forward / TSR.run on a LIST of images (the reference batches them, system.py:94-125)
+    gives, image by image, exactly what single-image calls give -- scene codes bit for bit, meshes bit for bit."""
+    m, sd = _small_model(cuda, seed=43)
+    S = SMALL_CFG["cond_image_size"]
+    imgs = [synth.composite_rgb(synth.image_rgba(seed=60 + i, size=S)) for i in range(3)]
+    codes = m(imgs, device=cuda)
+    assert codes.shape[0] == 3
+    from sculptmate_amd import ops
+
+    thr = float(ops.density_grid(codes[0].contiguous(), m.decoder, 32).median())
+    batch = m.run(imgs, mc_resolution=32, threshold=thr)
+    assert len(batch) == 3
+    for i, im in enumerate(imgs):
+        one = m([im], device=cuda)
+        assert torch.equal(one[0], codes[i])
+        single = m.run([im], mc_resolution=32, threshold=thr)[0]
+        assert np.array_equal(single.vertices.view(np.uint32), batch[i].vertices.view(np.uint32))
+        assert np.array_equal(single.faces, batch[i].faces)
+    assert not np.array_equal(batch[0].vertices[:50], batch[1].vertices[:50])  # different images, different meshes
+
+
 def test_generator_facade_end_to_end(cuda, tmp_path):
     """TripoGenerator (the add-on's entry point): initiate_model -> generate_mesh, return codes 0,
     meshes delivered to the sink with the reference's array types (system.py:200)."""
