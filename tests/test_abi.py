@@ -55,3 +55,34 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "oracle/" not in txt or f == "mc_luts.h", f
+
+
+def test_host_mesh_entry_points_refuse_bad_arguments():
+    """sculpt_mesh_* take HOST pointers and run without a GPU: null / oversized / inconsistent arguments come back as an error
+    code with a message, never a crash; a released or null handle is harmless."""
+    import ctypes
+
+    import numpy as np
+
+    from sculptmate_amd import _lib
+
+    lib = _lib.lib
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float64)
+    f = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [2, 0, 3]], np.int32)
+    out = ctypes.c_void_p()
+    assert lib.sculpt_mesh_decimate(v.ctypes.data, 4, f.ctypes.data, 4, 0, None) != 0 and "null result" in _lib.last_error()
+    assert lib.sculpt_mesh_decimate(None, 4, f.ctypes.data, 4, 0, ctypes.byref(out)) != 0 and out.value is None
+    assert lib.sculpt_mesh_subdivide(v.ctypes.data, 4, f.ctypes.data, 4, 13, ctypes.byref(out)) != 0      # iters out of range
+    assert lib.sculpt_mesh_subdivide(v.ctypes.data, 4, f.ctypes.data, 4, -1, ctypes.byref(out)) != 0
+    assert lib.sculpt_mesh_remesh_botsch(v.ctypes.data, 4, f.ctypes.data, 4, 5, float("nan"), 1, ctypes.byref(out)) != 0
+    assert lib.sculpt_mesh_remesh_botsch(v.ctypes.data, 4, f.ctypes.data, 4, -3, -1.0, 1, ctypes.byref(out)) != 0
+    assert lib.sculpt_mesh_read(None, v.ctypes.data, f.ctypes.data) != 0
+    assert lib.sculpt_mesh_num_vertices(None) == 0 and lib.sculpt_mesh_num_faces(None) == 0
+    lib.sculpt_mesh_free(None)
+    # and the good call still works afterwards: a tetrahedron cannot be decimated
+    assert lib.sculpt_mesh_decimate(v.ctypes.data, 4, f.ctypes.data, 4, 0, ctypes.byref(out)) == 0
+    assert lib.sculpt_mesh_num_vertices(out) == 4 and lib.sculpt_mesh_num_faces(out) == 4
+    v2, f2 = np.empty((4, 3)), np.empty((4, 3), np.int32)
+    assert lib.sculpt_mesh_read(out, v2.ctypes.data, f2.ctypes.data) == 0
+    lib.sculpt_mesh_free(out)
+    assert np.array_equal(v2, v) and np.array_equal(f2, f)
