@@ -475,13 +475,11 @@ __device__ __forceinline__ void load_row32(const float *row, f32x16 &a, f32x16 &
     }
 }
 
-// FEAT (the SF3D lattice decode, sculpt_grid_decode): also / instead writes rows 1..3 of the last layer, raw, as
-// features[idx][3]; `out` may then be null.  The TripoSR launch uses FEAT = false: its code is unchanged.
-template <int NT, bool FEAT = false>
+template <int NT>
 __global__ __launch_bounds__(NT) void density_grid_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
     const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out,
-    int xcd_band, float *__restrict__ features = nullptr) {
+    int xcd_band) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
@@ -526,15 +524,54 @@ __global__ __launch_bounds__(NT) void density_grid_kernel(
         x0 = silu16(x0); x1 = silu16(x1);
         hidden_layers(L, NH, lane, h, x0, x1);
         const float d = last_dot(L, 0, h, x0, x1);
-        if (!FEAT) {
-            if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
-        } else {
-            const float f0 = last_dot(L, 1, h, x0, x1), f1 = last_dot(L, 2, h, x0, x1), f2 = last_dot(L, 3, h, x0, x1);
-            if (h == 0 && iz < R) {
-                const long idx = ((long)ixl * R + iy) * R + iz;
-                if (out) out[idx] = exp_f(d + density_bias) + out_add;
-                if (features) { features[3 * idx] = f0; features[3 * idx + 1] = f1; features[3 * idx + 2] = f2; }
-            }
+        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same step for a decoder head of StableFast-3D on its marching-tetrahedra lattice (sculpt_grid_decode): few hidden
+// layers (one), so the launch is bound by its table reads, not by the matrix pipe, and R = 161 is not a multiple of 32.
+// A tile is therefore 32 consecutive points of the flattened (iy, iz) plane of one ix -- no ragged sixth tile per row
+// (-16 % tiles), the FC rows of a tile are consecutive -- and writes density_act (row 0) and / or the three raw feature rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void lattice_decode_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out,
+    float *__restrict__ features) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;
+    load_weights_to_lds(smem, blob, hd);
+    const LdsView L = lds_view(smem, NH);
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const long plane = (long)R * R;
+    const long tpx = (plane + 31) / 32, ntiles = (long)nx * tpx;
+    const long nw_total = (long)gridDim.x * nwave;
+    // XCD band order as in density_grid_kernel: one XCD streams one band of ix (FA / FB rows)
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    for (long t = t_begin; t < t_end; ++t) {
+        const int ixl = (int)(t / tpx);
+        const long flat = (t - (long)ixl * tpx) * 32 + p;
+        const long fc = min(flat, plane - 1);
+        const int iy = (int)(fc / R), iz = (int)(fc - (long)iy * R);
+        f32x16 x0, x1, y0, y1;
+        load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
+        load_row32(FB + ((long)ixl * R + iz) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        load_row32(FC + fc * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        x0 = silu16(x0); x1 = silu16(x1);
+        hidden_layers(L, NH, lane, h, x0, x1);
+        const float d = last_dot(L, 0, h, x0, x1);
+        const float f0 = last_dot(L, 1, h, x0, x1), f1 = last_dot(L, 2, h, x0, x1), f2 = last_dot(L, 3, h, x0, x1);
+        if (h == 0 && flat < plane) {
+            const long idx = (long)ixl * plane + flat;
+            if (out) out[idx] = exp_f(d + density_bias) + out_add;
+            if (features) { features[3 * idx] = f0; features[3 * idx + 1] = f1; features[3 * idx + 2] = f2; }
         }
     }
 }
@@ -931,12 +968,11 @@ int sculpt_grid_decode(const void *mlp_packed, int n_hidden_64, int R, int x_beg
     const float *FA = reinterpret_cast<const float *>(workspace);
     const float *FB = FA + (size_t)nx * R * 64;
     const float *FC = FB + (size_t)nx * R * 64;
-    const long ntiles = (long)nx * ((R + 31) / 32) * R;
-    auto kern = density_grid_kernel<1024, true>;
-    SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long ntiles = (long)nx * (((long)R * R + 31) / 32);
+    SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lattice_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
-                       density_bias, out_add, density_act, 1, features);
+    hipLaunchKernelGGL(lattice_decode_kernel, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC,
+                       R, nx, density_bias, out_add, density_act, features);
     SC_LAUNCH_CHECK();
     return 0;
 }
