@@ -32,7 +32,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-static constexpr int BM = 128;   // activation rows per block
+static constexpr int BM_DEFAULT = 128;   // activation rows per block (64 for launches of fewer tiles than CUs)
 #ifndef SCULPT_GEMM_READ_AHEAD
 #define SCULPT_GEMM_READ_AHEAD 1
 #endif
@@ -88,7 +88,7 @@ static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 til
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
 // NW: waves per workgroup.  4 = 2x2 waves of 64 activation x BW/2 weight rows; 8 = 2 (weight) x 4 (activation)
 // waves of 32 x BW/2: twice the waves per SIMD to hide LDS / barrier latency, at 1.5x the LDS bytes per MFMA.
-template <int EPI, int BW, int NW, bool CONV = false>
+template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     constexpr int WT = BW * 128;  // bytes of a weight tile
     constexpr int AT = BM * 128;
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         const uint16_t *a0 = (!CONV || ((amask0 >> tap) & 1u)) ? asrc0 + ao : zsrc;                          \
         const uint16_t *a1 = (!CONV || ((amask1 >> tap) & 1u)) ? asrc1 + ao : zsrc;                          \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)a0, (lds_ptr_t)(ab + adst), 16, 0, 0);                   \
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)a1, (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);            \
+        if (AI >= 2)                                                                                         \
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)a1, (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);        \
         if (AI == 4) {                                                                                       \
             const uint16_t *a2 = (!CONV || ((amask2 >> tap) & 1u)) ? asrc2 + ao : zsrc;                      \
             const uint16_t *a3 = (!CONV || ((amask3 >> tap) & 1u)) ? asrc3 + ao : zsrc;                      \
@@ -244,11 +245,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         const int buf = kt % NSTAGE;
         // wait until tile kt has landed; tiles kt+1 .. kt+DIST-1 (if issued) stay in flight
         if (DIST > 1 && kt + 1 < nk && !(kt == 0 && g.ln_stats)) {
-            static_assert(LPT == 3 || LPT == 4 || LPT == 6 || LPT == 8, "counted wait needs an immediate");
-            if (LPT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (LPT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -532,7 +529,7 @@ extern "C" int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, 
     GemmArgs g{in, ld_in, Wt, K, bias, nullptr, 0, out_f32, out_bf16, ldo, nullptr, 0, (int)M, N, K, N, (long)N > M ? 1 : 0,
                n_store, H, W, C_pad / 64, dilation, zp, nullptr, 0, nullptr, 0.f, nullptr, 0, reinterpret_cast<const float *>(zp)};
     SC_REQUIRE((long)N <= ZERO_FLOATS, "conv3x3_bf16: N=%d too large", N);
-    const int mt = cdiv(M, BM);
+    const int mt = cdiv(M, BM_DEFAULT);
     hipStream_t st = as_stream(stream);
     const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
     if (epilogue == SCULPT_EPI_RELU) {
@@ -592,7 +589,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                    "gemm_bf16_ln: stats_out is for the plain fp32 output (no activation, no column split / n_store)");
         g.stats_out = ln->stats_out;
     }
-    const int mt = cdiv(M, BM);
+    const int mt = cdiv(M, BM_DEFAULT);
     hipStream_t st = as_stream(stream);
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of
     // the two transformers except the deep-K 64-row-tile case (K = 4096, N = 1024: -4 %), which keeps 4 waves
@@ -623,7 +620,13 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             else if (nw8) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_RELU, 128, 8>), dim3(N / 128, mt), dim3(512), 0, st, g);
             else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_RELU, 128, 4>), dim3(N / 128, mt), dim3(256), 0, st, g);
         } else if (epilogue == SCULPT_EPI_NONE) {
-            if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
+            // Fewer tiles than CUs: every workgroup has a CU to itself and its K loop runs at that CU's L2 -> LDS fill rate
+            // (~57 GB/s, whatever the ring depth or the number of barriers: a six-stage ring and two K-tiles per barrier both
+            // measured +-0); 64 x 64 tiles put the same bytes through up to twice as many CUs.
+            static const int bm64_env = [] { const char *e = getenv("SCULPT_GEMM_BM64"); return e ? atoi(e) : 1; }();
+            if (small && underfilled && bm64_env && (long)(N / 64) * cdiv(M, 64) <= 2L * num_cus())
+                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 64>), dim3(N / 64, cdiv(M, 64)), dim3(512), 0, st, g);
+            else if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
             else if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 4>), dim3(N / 64, mt), dim3(256), 0, st, g);
             else if (nw8) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8>), dim3(N / 128, mt), dim3(512), 0, st, g);
             else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 4>), dim3(N / 128, mt), dim3(256), 0, st, g);
