@@ -445,7 +445,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, imgs_np[0])
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        # on its own line whatever was written before it (RCCL warnings go to stdout without a trailing newline)
+        sys.stdout.write("\n" + json.dumps(out) + "\n")
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
