@@ -94,3 +94,42 @@ def test_config5_at_512_cubed_slabs_equal_single_pass_and_oracle(cuda):
     assert np.array_equal(sf.cpu().numpy(), rf[:, [1, 0, 2]].astype(np.int64))
     assert np.array_equal(sv.cpu().numpy().view(np.uint32), rv.view(np.uint32))
     torch.cuda.empty_cache()
+
+
+def test_slab_exchange_over_rccl_with_one_rank(cuda, tmp_path):
+    """The exchange step of config 5 on the backend the multi-GPU run uses: a one-rank "nccl" (= RCCL) process group in a child
+    process -- the padded all_gathers and the all_reduce run on device tensors through RCCL, and the assembled mesh equals the
+    single-pass one.  (Two ranks need two GPUs; the two-rank logic is covered over gloo in tests/test_parallel_gloo.py.)"""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text('''
+import sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from sculptmate_amd import ops, slab, synth
+from sculptmate_amd.tsr import TSR
+from sculptmate_amd.tsr.spec import SMALL_CFG
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+m = TSR(SMALL_CFG); m.load_state_dict(synth.tsr_state(seed=7, cfg=SMALL_CFG)); m.to(dev)
+S = SMALL_CFG["cond_image_size"]
+codes = m([synth.composite_rgb(synth.image_rgba(seed=8, size=S))], device=dev)
+R = 40
+thr = float(ops.density_grid(codes[0].contiguous(), m.decoder, R).median())
+kw = dict(radius=m.renderer.cfg.radius, density_bias=m.renderer.cfg.density_bias, threshold=thr)
+part = slab.extract_slab(codes[0].contiguous(), m.decoder, R, 0, 1, **kw)
+v, f = slab.gather_and_assemble(part, dev)
+rv, rf = slab.extract_mesh_slabs_local(codes[0].contiguous(), m.decoder, R, 1, **kw)
+assert torch.equal(v, rv) and torch.equal(f, rf) and v.shape[0] > 100, (v.shape, rv.shape)
+dist.barrier(); dist.destroy_process_group()
+print("rccl one-rank exchange ok", tuple(v.shape), tuple(f.shape))
+''' % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "rccl one-rank exchange ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
