@@ -227,6 +227,13 @@ struct Mesh {
                     at_v = at_v || index_in(F[f], v) >= 0;
                 }
             if (at_u && at_v) return false;
+        } else {
+            // boundary edge: its second "face" is (u, v, infinity).  The same shared-link-edge rule with infinity as the second
+            // apex: if (u, a) and (v, a) are boundary edges too, the faces (u, a, inf) and (v, a, inf) exist -- an isolated
+            // triangle (or a fan tip), whose collapse would make the component disappear (libigl refuses it the same way)
+            const int a = third(ef[0], u, v);
+            int tmp[2];
+            if (edge_faces(u, a, tmp) == 1 && edge_faces(v, a, tmp) == 1) return false;
         }
         return true;
     }

@@ -338,3 +338,53 @@ def test_isosurface_meshes_with_borders_keep_their_topology(seed):
     assert cKDTree(v).query(vr)[0].max() < 2.5 * h
     el = edge_lengths(vr, fr)
     assert ((el > 0.7 * h) & (el < 1.45 * h)).mean() > 0.9
+
+
+def test_small_components_never_disappear():
+    """An isolated triangle, a two-triangle quad and a fan tip next to a closed body: decimation towards zero faces keeps
+    every component (libigl's boundary-at-infinity link condition refuses to collapse the last triangle of a patch)."""
+    vs, fs = icosahedron()
+    tri_v = np.array([[5, 0, 0], [6, 0, 0], [5, 1, 0]], np.float64)
+    quad_v = np.array([[8, 0, 0], [9, 0, 0], [9, 1, 0], [8, 1, 0]], np.float64)
+    v = np.concatenate([vs, tri_v, quad_v], 0)
+    f = np.concatenate([fs, [[12, 13, 14]], [[15, 16, 17], [15, 17, 18]]], 0).astype(np.int32)
+    chi0, nb0 = topology(v, f)
+    assert chi0 == 2 + 1 + 1 and nb0 == 3 + 4
+    vo, fo, _, _ = rm.decimate(v, f, num_faces=0)
+    chi, nb = topology(vo, fo)
+    assert chi == chi0 and nb > 0
+    assert len(fo) == 4 + 1 + 1  # tetrahedron + one triangle + one triangle (the quad loses its diagonal, never its last face)
+    vr, fr = rm.remesh_botsch(v, f, 5, 3.0)  # a target far above every edge: collapses wherever they are allowed
+    assert topology(vr, fr)[0] == chi0
+
+
+@pytest.mark.parametrize("seed", range(1000, 1012))
+def test_random_isosurfaces_stress(seed):
+    """The bug class the three cases above came from, kept as a sweep: marching-cubes surfaces with many small components and
+    open rims through decimation (mild, strong, to exhaustion) and remeshing (default, fine, coarse target): the Euler
+    characteristic never changes and open stays open."""
+    from oracle import capi
+
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(14, 24))
+    g = np.linspace(-1, 1, n)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    vol = np.zeros((n, n, n))
+    for _ in range(int(rng.integers(3, 9))):
+        k = rng.uniform(0.8, 5.0, 3)
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        vol += rng.uniform(0.3, 1.0) * np.sin(k[0] * X + ph[0]) * np.sin(k[1] * Y + ph[1]) * np.sin(k[2] * Z + ph[2])
+    v, f = capi.marching_cubes(vol.astype(np.float32), float(rng.uniform(-0.3, 0.3)))[:2]
+    v, f = v.astype(np.float64), f.astype(np.int32)
+    chi0, nb0 = topology(v, f)
+    for ratio in (0.7, 0.08, 0.0):
+        vd, fd, _, _ = rm.decimate(v, f, face_ratio=ratio)
+        chi, nb = topology(vd, fd)
+        assert chi == chi0 and (nb > 0) == (nb0 > 0), (ratio, chi0, chi)
+        if ratio == 0.0:
+            continue
+        h = edge_lengths(vd, fd).mean()
+        for target in (None, 0.5 * h, 2.5 * h):
+            vr, fr = rm.remesh_botsch(vd, fd, 4, target)
+            chi, nb = topology(vr, fr)
+            assert chi == chi0 and (nb > 0) == (nb0 > 0), (ratio, target, chi0, chi)
