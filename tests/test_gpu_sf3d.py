@@ -48,6 +48,32 @@ def test_query_align_corners_and_material_heads_vs_reference_golden(cuda):
     assert set(dec(q, exclude=["density", "vertex_offset"])) == {"features", "perturb_normal"}
 
 
+@pytest.mark.parametrize("R,n_hidden,H,ac", [(2, 1, 16, True), (7, 1, 24, True), (33, 2, 40, True), (50, 1, 64, False), (161, 1, 96, True)])
+def test_lattice_decode_equals_point_query(cuda, R, n_hidden, H, ac):
+    """ops.lattice_decode (separable layer-0 tables + sculpt_grid_decode) against ops.triplane_query at the same lattice points,
+    both heads' output forms: equal up to the regrouped fp32 sum of the first layer -- ragged R (not a multiple of 32), R = 2,
+    one and two hidden layers, both grid_sample conventions, a non-zero density bias and output offset."""
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(R * 7 + n_hidden)
+    planes = torch.randn(3, 40, H, H, generator=g).to(cuda)
+    dims = [120] + [64] * (n_hidden + 1)
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(n_hidden + 1)] + [torch.randn(4, 64, generator=g) / 8]
+    bs = [0.1 * torch.randn(w.shape[0], generator=g) for w in Ws]
+    mlp = ops.PackedMLP(Ws, bs, cuda)
+    radius = 0.87
+    axis = (torch.linspace(0, 1, R) * (radius - (-radius)) + (-radius)).to(cuda)
+    pts = torch.stack(torch.meshgrid(axis, axis, axis, indexing="ij"), -1).reshape(-1, 3).contiguous()
+    ref = ops.triplane_query(planes, mlp, pts, radius=radius, density_bias=-0.7, want=("density_act", "features"), align_corners=ac)
+    got = ops.lattice_decode(planes, mlp, axis, radius, density_bias=-0.7, out_add=-3.0, want=("density_act", "features"),
+                             align_corners=ac)
+    assert got["density_act"].shape == (R ** 3,) and got["features"].shape == (R ** 3, 3)
+    np.testing.assert_allclose(got["features"].cpu().numpy(), ref["features"].reshape(-1, 3).cpu().numpy(), rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose((got["density_act"] + 3.0).cpu().numpy(), ref["density_act"].reshape(-1).cpu().numpy(), rtol=5e-5, atol=3e-5)
+    only = ops.lattice_decode(planes, mlp, axis, radius, want=("features",), align_corners=ac)
+    assert set(only) == {"features"} and torch.equal(only["features"], got["features"])
+
+
 # ----------------------------------------------------------------------------- marching tetrahedra
 def test_marching_tets_bit_exact_vs_reference_golden(cuda):
     from sculptmate_amd import ops
