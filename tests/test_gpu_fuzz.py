@@ -63,10 +63,12 @@ def test_gemm_random_shapes(cuda):
 
     rng = np.random.default_rng(3)
     g = torch.Generator().manual_seed(3)
-    for it in range(24):
+    for it in range(34):
         M = int(rng.integers(1, 700))
         N = 128 * int(rng.integers(1, 9))
         K = 64 * int(rng.integers(1, 17))
+        if it >= 24:  # launches of more tiles than CUs: the 128-row tiles (the small shapes above take the 64-row form)
+            M, N = int(rng.integers(2000, 3300)), 128 * int(rng.choice([8, 16, 24]))
         A = torch.randn(M, K, generator=g).to(BF)
         W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF)
         b = torch.randn(N, generator=g)
@@ -88,8 +90,10 @@ def test_attention_random_shapes(cuda):
 
     rng = np.random.default_rng(5)
     g = torch.Generator().manual_seed(5)
-    for it in range(16):
+    for it in range(28):
         Tq, Tk, heads = int(rng.integers(1, 400)), int(rng.integers(1, 400)), int(rng.integers(1, 5))
+        if it >= 16:  # the launch shapes that pick 192- and 256-query workgroups (every third with many queries)
+            Tq, heads = int(rng.integers(1500, 3200)) if it % 3 else int(rng.integers(5000, 9000)), int(rng.integers(8, 17))
         D = heads * 64
         q = torch.randn(Tq, D, generator=g).to(BF)
         k = torch.randn(Tk, D, generator=g).to(BF)
@@ -97,7 +101,12 @@ def test_attention_random_shapes(cuda):
         vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF)
         vt[:, :Tk] = v.t()
         o = torch.empty(Tq, D, dtype=BF, device=cuda)
-        ops.attention(q.to(cuda), k.to(cuda), vt.to(cuda), o, Tq, Tk, heads, 0.125)
+        if it % 2:  # the pre-scaled entry (scale = 0): q carries softmax_scale * log2(e), rounded to bf16 once
+            q = (q.float() * (0.125 * 1.4426950408889634)).to(BF)
+            ops.attention(q.to(cuda), k.to(cuda), vt.to(cuda), o, Tq, Tk, heads, 0.0)
+            q = (q.float() / (0.125 * 1.4426950408889634))  # the reference sees the same rounded queries
+        else:
+            ops.attention(q.to(cuda), k.to(cuda), vt.to(cuda), o, Tq, Tk, heads, 0.125)
         qh = q.float().view(Tq, heads, 64).transpose(0, 1)
         kh = k.float().view(Tk, heads, 64).transpose(0, 1)
         vh = v.float().view(Tk, heads, 64).transpose(0, 1)
