@@ -80,12 +80,23 @@ class _PinnedPool:
 
 
 class _PinnedLease:
+    """One pinned buffer on loan.  It goes back to the pool when the lease dies -- or, once `hand_over(array)` has tied it to
+    the NumPy array that views it, when THAT array (and every view of it) is gone."""
+
     def __init__(self, pool, cap, buf):
         self.pool, self.cap, self.buf = pool, cap, buf
 
+    def hand_over(self, array):
+        import weakref
+
+        pool, cap, buf = self.pool, self.cap, self.buf
+        self.buf = None
+        weakref.finalize(array, pool.give, cap, buf)
+
     def __del__(self):
         try:
-            self.pool.give(self.cap, self.buf)
+            if self.buf is not None:
+                self.pool.give(self.cap, self.buf)
         except Exception:  # interpreter shutdown
             pass
 
@@ -102,13 +113,14 @@ class PendingMesh:
         return self._done.query()
 
     def result(self) -> Mesh:
-        """The arrays are views of pinned host buffers that belong to the returned Mesh (recycled when it is released):
-        copy them if they must outlive it."""
+        """The arrays are views of pinned host buffers; a buffer returns to the pool when its array -- and every view or
+        slice taken from it -- has been released (it does not matter whether the Mesh object itself is kept)."""
         self._done.synchronize()
-        v, f, c = self._host
-        m = Mesh(v.numpy(), f.numpy(), None if c is None else c.numpy())
-        m._pinned = self._leases
-        return m
+        arrays = [None if t is None else t.numpy() for t in self._host]
+        for lease, a in zip(self._leases, [a for a in arrays if a is not None]):
+            lease.hand_over(a)
+        self._leases = ()
+        return Mesh(*arrays)
 
 
 class MarchingCubeHelper:

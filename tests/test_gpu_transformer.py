@@ -372,6 +372,45 @@ def test_batch_of_images_equals_one_at_a_time(cuda):
     assert not np.array_equal(batch[0].vertices[:50], batch[1].vertices[:50])  # different images, different meshes
 
 
+def test_run_async_pipeline_and_pinned_buffer_lifetime(cuda):
+    """TSR.run_async: several images in flight, results collected later == the one-at-a-time results; and the pinned host
+    buffers behind the returned arrays are recycled only when the ARRAYS are gone -- an array kept after its Mesh object was
+    dropped must survive any number of later runs unchanged."""
+    import gc
+
+    m, sd = _small_model(cuda, seed=44)
+    S = SMALL_CFG["cond_image_size"]
+    imgs = [synth.composite_rgb(synth.image_rgba(seed=70 + i, size=S)) for i in range(4)]
+    from sculptmate_amd import ops
+
+    thr = float(ops.density_grid(m([imgs[0]], device=cuda)[0].contiguous(), m.decoder, 32).median())
+    want = [m.run([im], mc_resolution=32, threshold=thr, enable_texture=True)[0] for im in imgs]
+    want = [(w.vertices.copy(), w.faces.copy(), w.vertex_colors.copy()) for w in want]
+    pend = [m.run_async(im, 32, thr, enable_texture=True) for im in imgs]          # nothing waited for in between
+    got = [p.result() for p in reversed(pend)][::-1]
+    for (wv, wf, wc), g in zip(want, got):
+        assert np.array_equal(wv, g.vertices) and np.array_equal(wf, g.faces) and np.array_equal(wc, g.vertex_colors)
+    # keep ONE array, drop everything else, run many more images through the same pool
+    keep = m.run([imgs[1]], mc_resolution=32, threshold=thr)[0].vertices          # the Mesh object dies right here
+    snapshot = keep.copy()
+    del got, pend
+    gc.collect()
+    for rep in range(6):
+        for im in imgs:
+            out = m.run([im], mc_resolution=32, threshold=thr, enable_texture=True)
+            del out
+        gc.collect()
+    assert np.array_equal(keep, snapshot) and np.array_equal(keep, want[1][0])
+    pool = m._pin_pool
+    n_free = sum(len(v) for v in pool.free.values())
+    assert 1 <= n_free <= 16, n_free  # buffers do come back (no leak): at most the 4 x 3 that were in flight at once, plus the kept ones
+    view = keep[:10]
+    del keep
+    gc.collect()
+    m.run([imgs[2]], mc_resolution=32, threshold=thr)
+    assert np.array_equal(view, snapshot[:10])  # a slice keeps its buffer out of the pool just as well
+
+
 def test_generator_facade_end_to_end(cuda, tmp_path):
     """TripoGenerator (the add-on's entry point): initiate_model -> generate_mesh, return codes 0,
     meshes delivered to the sink with the reference's array types (system.py:200)."""
