@@ -133,3 +133,40 @@ print("rccl one-rank exchange ok", tuple(v.shape), tuple(f.shape))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0 and "rccl one-rank exchange ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_cu_masked_stream_runs_the_kernels_and_refuses_bad_ranges(cuda):
+    """sculpt_stream_create_cu_mask (the CU-partition experiment's entry point): a stream restricted to a quarter of
+    the CUs runs the density grid + marching cubes to the same bits as the default stream; out-of-range masks are refused."""
+    import ctypes
+
+    from sculptmate_amd import _lib, ops
+
+    m_cfg = __import__("sculptmate_amd.tsr.spec", fromlist=["SMALL_CFG"]).SMALL_CFG
+    from sculptmate_amd.tsr import TSR
+
+    m = TSR(m_cfg)
+    m.load_state_dict(synth.tsr_state(seed=9, cfg=m_cfg))
+    m.to(cuda)
+    S = m_cfg["cond_image_size"]
+    codes = m([synth.composite_rgb(synth.image_rgba(seed=10, size=S))], device=cuda)
+    R = 40
+    vol = ops.density_grid(codes[0].contiguous(), m.decoder, R)
+    thr = float(vol.median())
+    ref = ops.marching_cubes((vol - thr).view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0)
+    h = ctypes.c_void_p()
+    _lib.check(_lib.lib.sculpt_stream_create_cu_mask(0, 64, ctypes.byref(h)))
+    try:
+        st = torch.cuda.ExternalStream(h.value, device=cuda)
+        st.wait_stream(torch.cuda.current_stream(cuda))
+        with torch.cuda.stream(st):
+            vol2 = ops.density_grid(codes[0].contiguous(), m.decoder, R)
+            got = ops.marching_cubes((vol2 - thr).view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0)
+        st.synchronize()
+        assert torch.equal(vol2, vol) and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    finally:
+        assert _lib.lib.sculpt_stream_destroy(h) == 0
+    for first, n in ((0, 0), (-1, 8), (250, 64), (0, 100000)):
+        bad = ctypes.c_void_p()
+        assert _lib.lib.sculpt_stream_create_cu_mask(first, n, ctypes.byref(bad)) != 0, (first, n)
+    assert _lib.lib.sculpt_stream_create_cu_mask(0, 8, None) != 0
