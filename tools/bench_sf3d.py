@@ -98,3 +98,27 @@ print("box-projection unwrap (incl. normals / tangents of the unrolled mesh): %.
       "remaining %.1f %%" % (tu, 100 * f0, 100 * f1, 100 * f2))
 fl = dict(dino=0.95e12, backbone=8.5e12, post=1.9e12)
 print("approx TFLOP/s: dino %.0f backbone %.0f upsampler %.0f" % (fl["dino"] / t[0] / 1e9, fl["backbone"] / t[1] / 1e9, fl["post"] / t[2] / 1e9))
+
+
+def bake_time(res=512, n=3):
+    """Texture bake on the unwrapped bench mesh: rasterize -> interpolate -> heads at the texels -> bake_material -> dilate_fill."""
+    from sculptmate_amd.sf3d.bake import bake_textures
+    from sculptmate_amd.sf3d.system import Mesh
+
+    mm = Mesh(mesh.v_pos.clone(), mesh.t_pos_idx.clone(), unwrapper=m.unwrapper)
+    mm.unwrap_uv()
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tex = bake_textures(m, mm, codes, res, {}, 0)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return min(ts), tex
+
+
+try:
+    tb, tex = bake_time()
+    print("texture bake at 512^2 (rasterize + interpolate + 3 heads at the texels + material + dilate, incl. the PIL hand-off): %.2f ms" % tb)
+except Exception as e:  # noqa: BLE001  (a timing tool: report, do not hide the stages above)
+    print("texture bake: failed (%s: %s)" % (type(e).__name__, e))
