@@ -340,15 +340,21 @@ def main():
         raise SystemExit("--gpus %d needs %d ranks (WORLD_SIZE=%d): launch with python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus, world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Test plumbing for 1-GPU boxes (tests/test_gpu_bench_ranks.py): SCULPT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # SCULPT_BENCH_BACKEND=gloo runs the two collectives of this script on the host -- RCCL refuses two ranks on one device.
+    # The driver's multi-GPU runs set neither: one rank per GPU over RCCL.
+    share_gpu = bool(os.environ.get("SCULPT_BENCH_SHARE_GPU"))
+    backend = os.environ.get("SCULPT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     from sculptmate_amd import parallel, synth
 
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"  # keep stdout to the one JSON line (RCCL prints its banner there)
 
     # SCULPT_FORCE_DIST=1 exercises the RCCL path with a single rank (used to validate it on a 1-GPU box)
-    dist = parallel.init("nccl", device) if (world > 1 or os.environ.get("SCULPT_FORCE_DIST")) else None
+    dist = parallel.init(backend, device) if (world > 1 or os.environ.get("SCULPT_FORCE_DIST")) else None
 
     model, sd = build_model(device, seed=0)  # every rank holds a full replica (no weight sharding)
     model.decoder_precision = DECODER_PRECISION
@@ -373,7 +379,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, device)
+    elapsed = parallel.max_over_ranks(elapsed, device if backend == "nccl" else "cpu")
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0:
