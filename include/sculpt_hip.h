@@ -128,6 +128,12 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
 /* SCULPT_DENSITY_FP16X3: the same with IEEE-half parts (11-bit significands: operands represented to ~2^-22,
  * hidden activations and weights must stay inside the fp16 range, |v| < 65504). */
 #define SCULPT_DENSITY_FP16X3 2u
+/* SCULPT_DENSITY_BF16L3: fp32-equivalent mode on the 16-bit matrix pipe (what TSR.extract_meshes uses by default): both
+ * operands split EXACTLY into three bf16 limbs (8 + 8 + 8 = 24 significant bits, fp32 exponent range),
+ * W.x = W1.x3 + W3.x1 + W2.x2 + W1.x2 + W2.x1 + W1.x1 with every product exact and fp32 accumulation; the three dropped
+ * products are below 2^-23 |W||x|.  No range limit, no fallback.  Replaces NeRFMLP's hidden Linear layers,
+ * TripoSR/tsr/models/network_utils.py:116-124, inside nerf_renderer.py:82-87. */
+#define SCULPT_DENSITY_BF16L3 4u
 int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                            float density_bias, float out_add, const void *workspace, float *out, unsigned flags,
                            sculpt_stream_t stream);

@@ -134,6 +134,7 @@ QUERY_ALIGN_CORNERS = 1
 QUERY_CHANNEL_LAST = 2
 DENSITY_BF16X3 = 1
 DENSITY_FP16X3 = 2
+DENSITY_BF16L3 = 4
 
 
 def last_error():

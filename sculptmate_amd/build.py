@@ -14,6 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libsculpt_hip.so")
 ARCH = "gfx950"
+# triplane.hip: the SLP vectoriser packs the scalar fp32 adds / multiplies of the SiLU + split chunks into v_pk_add_f32 /
+# v_pk_mul_f32, which cost ~10 issue cycles each and break the overlap with the bf16 MFMAs they are interleaved with
+# (tools/micro/mfma_fill.hip); the kernels that want packed operations ask for them with vector types.
+PER_FILE_FLAGS = {"triplane.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -51,14 +55,15 @@ def build(force=False, verbose=False):
     extra = os.environ.get("SCULPT_EXTRA_HIPCC_FLAGS", "").split()
     flags = ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wno-unused-result"] + extra
     stamp = os.path.join(objdir, "flags.txt")
-    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+    stamp_text = " ".join(flags) + " | " + repr(sorted(PER_FILE_FLAGS.items()))
+    if not os.path.exists(stamp) or open(stamp).read() != stamp_text:
         force = True
     hdr_time = max(os.path.getmtime(h) for h in _headers())
     jobs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            jobs.append([hipcc()] + flags + ["-c", src, "-o", obj])
+            jobs.append([hipcc()] + flags + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -68,7 +73,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     with open(stamp, "w") as f:
-        f.write(" ".join(flags))
+        f.write(stamp_text)
     objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in sources()]
     link = [hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", SO + ".tmp"] + objs
     run(link)

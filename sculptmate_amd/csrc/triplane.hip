@@ -28,7 +28,7 @@
 namespace sculpt {
 
 static constexpr int HID = 64;          // hidden width (n_neurons)
-static constexpr uint32_t PACK_MAGIC = 0x53434d32u;  // "SCM2": activations scaled by log2(e), see silu_f
+static constexpr uint32_t PACK_MAGIC = 0x53434d33u;  // "SCM3": activations scaled by log2(e) (silu_f), third bf16 limb of the hidden weights
 
 struct MlpPackHeader {
     uint32_t magic;
@@ -44,7 +44,8 @@ struct MlpPackHeader {
     int32_t off_blast; // [4]
     int32_t off_x3;    // [NH][hi|lo][2 T][4 s][64 lane][8] bf16 (as 4096 floats per layer): split weights, bf16x3 mode
     int32_t off_x3h;   // same with fp16 halves (fp16x3 mode)
-    int32_t pad[3];
+    int32_t off_w3;    // [NH][2 T][4 s][64 lane][8] bf16 (as 2048 floats per layer): third limb W - W1 - W2, bf16 3-limb mode
+    int32_t pad[2];
 };
 static_assert(sizeof(MlpPackHeader) == 64, "header is 16 words");
 
@@ -79,6 +80,7 @@ static void pack_layout(int K0, int NH, MlpPackHeader *hd) {
     o = (o + 3) & ~3;
     hd->off_x3 = o;    o += NH * 4096;
     hd->off_x3h = o;   o += NH * 4096;
+    hd->off_w3 = o;    o += NH * 2048;
     hd->total_floats = (o + 3) & ~3;
 }
 
@@ -114,6 +116,15 @@ __device__ __forceinline__ f32x16 silu16(f32x16 v) {
         const tf32x2 y = x * r;
         o[i] = y[0]; o[i + 1] = y[1];
     }
+    return o;
+}
+
+// the same with scalar full-rate operations: beside bf16 MFMAs the packed fp32 forms cost more issue time than the two scalar
+// instructions they replace (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+__device__ __forceinline__ f32x16 silu16_scalar(f32x16 v) {
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = silu_f(v[i]);
     return o;
 }
 
@@ -590,10 +601,12 @@ typedef _Float16 tf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 tf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 tbf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    // v_cvt_pk_bf16_f32 (round to nearest even; a NaN stays a NaN); the builtin form, not inline asm, so that hipcc can
+    // schedule it between MFMAs like any other vector instruction
+    const tf32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tbf16x2));
 }
 
 // x (16 fp32 accumulator values of one 32-neuron tile) -> two B-operand vectors per part: hi[2], lo[2]
@@ -707,6 +720,553 @@ __global__ __launch_bounds__(1024) void density_grid_x3_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 THREE-LIMB mode of the dense grid (SCULPT_DENSITY_BF16L3, the default of TSR.extract_meshes): the eight 64x64
+// hidden layers on v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 limbs,
+//     x = x1 + x2 + x3,  W = W1 + W2 + W3        EXACTLY (8 + 8 + 8 = 24 significant bits, fp32 exponent range:
+//                                                 every limb is the round-to-nearest bf16 of the exact remainder, and
+//                                                 the last remainder has at most 8 significant bits)
+//     W.x = W1.x3 + W3.x1 + W2.x2 + W1.x2 + W2.x1 + W1.x1   (+ W2.x3 + W3.x2 + W3.x3 < 2^-23 |W||x|, dropped)
+// Every bf16 x bf16 product is exact in fp32 and the matrix pipe accumulates in fp32, so this is fp32 arithmetic with the
+// operands carried to 24 bits -- not a narrower format: no range limit, no fallback.  48 bf16 MFMAs (1536 cycles) per
+// layer and 32 points instead of 64 fp32 MFMAs (4096 cycles).  Tables, SiLU, the last layer and exp stay fp32; the
+// accumulator of layer l is the B operand of layer l+1 after the split, so activations still never leave registers.
+// W1 | W2 of all layers sit in LDS (128 KiB); the 8 KiB of W3 a layer needs come from L2 (64 KiB for all layers, read by
+// every wave of the chip): the loads are issued before the SiLU + split of the previous layer's output and land under it.
+// ---------------------------------------------------------------------------------------------
+// x (16 fp32 accumulator values of one 32-neuron tile) -> B-operand vectors of its two k-steps, three limbs each
+__device__ __forceinline__ void split16_l3(const f32x16 &x, tbf16x8 p1[2], tbf16x8 p2[2], tbf16x8 p3[2]) {
+    // no contraction: x is y * rcp(..) of the inlined SiLU, and fma(y, r, -x1) would be the remainder of the EXACT product
+    // (up to 24 bits of it) instead of the exact remainder of the fp32 value x, which the three limbs then could not hold
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4 v1, v2, v3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = x[8 * q + 2 * i], b = x[8 * q + 2 * i + 1];
+            const unsigned h1 = cvt_pk_bf16(a, b);
+            const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);  // exact
+            const unsigned h2 = cvt_pk_bf16(ra, rb);
+            const float sa = ra - __uint_as_float(h2 << 16), sb = rb - __uint_as_float(h2 & 0xffff0000u);  // exact, <= 8 bits
+            v1[i] = h1;
+            v2[i] = h2;
+            v3[i] = cvt_pk_bf16(sa, sb);
+        }
+        p1[q] = __builtin_bit_cast(tbf16x8, v1);
+        p2[q] = __builtin_bit_cast(tbf16x8, v2);
+        p3[q] = __builtin_bit_cast(tbf16x8, v3);
+    }
+}
+
+// One k-step (8 accumulator values of one lane = 8 of the 64 activations of its point) of SiLU + three-limb split: the
+// VALU work of a k-step as one unit, so that the kernel can run it UNDER the previous k-step's twelve MFMAs.
+__device__ __forceinline__ void silu_split8(const f32x16 &x, int q, tbf16x8 &p1, tbf16x8 &p2, tbf16x8 &p3) {
+#pragma clang fp contract(off)
+    u32x4 v1, v2, v3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = silu_f(x[8 * q + 2 * i]), b = silu_f(x[8 * q + 2 * i + 1]);
+        const unsigned h1 = cvt_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);
+        const unsigned h2 = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(h2 << 16), sb = rb - __uint_as_float(h2 & 0xffff0000u);
+        v1[i] = h1;
+        v2[i] = h2;
+        v3[i] = cvt_pk_bf16(sa, sb);
+    }
+    p1 = __builtin_bit_cast(tbf16x8, v1);
+    p2 = __builtin_bit_cast(tbf16x8, v2);
+    p3 = __builtin_bit_cast(tbf16x8, v3);
+}
+
+template <int NT, int PIPE>
+__global__ __launch_bounds__(NT) void density_grid_l3_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out, int sched) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
+        float *bacc = smem + NH * 4096;
+        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
+        float *wl = bacc + (NH + 1) * 64;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
+        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
+        __syncthreads();
+    }
+    const LdsView L = lds_view(smem, NH);
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int nzb = (R + 31) / 32;
+    const long ntiles = (long)nx * nzb * R;
+    const long nw_total = (long)gridDim.x * nwave;
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    int iy = (int)(t_begin % R);
+    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
+    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
+    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
+    if (sched & 1) {  // static, distinct priorities for the waves that share a SIMD (waves w, w + 4, w + 8, w + 12)
+        const int pr = (wave >> 2) & 3;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    if (sched & 2) {  // stagger: every second wave of a SIMD starts half a layer late
+        if ((wave >> 2) & 1) __builtin_amdgcn_s_sleep(20);
+    }
+
+    for (long t = t_begin; t < t_end; ++t, ++iy) {
+        if (iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+        }
+        const int iz = zb * 32 + p;
+        const int izc = min(iz, R - 1);
+        f32x16 x0, x1, y0, y1;
+        load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
+        load_row32(FB + ((long)ixl * R + izc) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
+        x0 += y0; x1 += y1;
+        for (int l = 0; l < NH; ++l) {
+            // third-limb weights of this layer: in flight while the VALU work below runs
+            tbf16x8 c0[4], c1[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                c0[s4] = A3[(long)l * 512 + (0 * 4 + s4) * 64];
+                c1[s4] = A3[(long)l * 512 + (1 * 4 + s4) * 64];
+            }
+            // keep the eight loads HERE: left alone, hipcc sinks each one to just before the MFMA that consumes it and
+            // waits vmcnt(0) there -- eight exposed L2 round trips per layer
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
+            const tbf16x8 *Al = A + (long)l * 16 * 64;
+            if (PIPE) {
+                // k-step software pipeline inside the wave: the SiLU + split of k-step g + 1 (76 vector instructions) is
+                // issued in the shadow of the twelve MFMAs of k-step g (24 free issue cycles behind each), so a wave
+                // overlaps its own vector and matrix work instead of relying on its SIMD partners being out of phase
+                tbf16x8 p1, p2, p3;
+                silu_split8(x0, 0, p1, p2, p3);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    tbf16x8 n1 = p1, n2 = p2, n3 = p3;
+                    if (g < 3) silu_split8(g + 1 < 2 ? x0 : x1, (g + 1) & 1, n1, n2, n3);
+                    const tbf16x8 a10 = Al[((0 * 2 + 0) * 4 + g) * 64], a11 = Al[((0 * 2 + 1) * 4 + g) * 64];
+                    const tbf16x8 a20 = Al[((1 * 2 + 0) * 4 + g) * 64], a21 = Al[((1 * 2 + 1) * 4 + g) * 64];
+                    acc0 = mfma16(a10, p3, acc0);
+                    acc1 = mfma16(a11, p3, acc1);
+                    acc0 = mfma16(c0[g], p1, acc0);
+                    acc1 = mfma16(c1[g], p1, acc1);
+                    acc0 = mfma16(a20, p2, acc0);
+                    acc1 = mfma16(a21, p2, acc1);
+                    acc0 = mfma16(a10, p2, acc0);
+                    acc1 = mfma16(a11, p2, acc1);
+                    acc0 = mfma16(a20, p1, acc0);
+                    acc1 = mfma16(a21, p1, acc1);
+                    acc0 = mfma16(a10, p1, acc0);
+                    acc1 = mfma16(a11, p1, acc1);
+                    if (g < 3) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {  // one MFMA, then its share of the 76 vector instructions
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    p1 = n1; p2 = n2; p3 = n3;
+                }
+            } else {
+                x0 = silu16_scalar(x0);
+                x1 = silu16_scalar(x1);
+                tbf16x8 b1[4], b2[4], b3[4];  // B operands of the four k-steps: tiles (x0: s = 0,1), (x1: s = 2,3)
+                split16_l3(x0, b1, b2, b3);
+                split16_l3(x1, b1 + 2, b2 + 2, b3 + 2);
+                // The matrix phase outranks the vector phases of the other waves on this SIMD: with equal priorities the
+                // arbiter keeps feeding the (older) waves that have vector instructions ready and this wave's MFMAs wait,
+                // so matrix and vector work of different waves end up one after the other instead of side by side.
+                if (sched & 4) __builtin_amdgcn_s_setprio(3);
+                // small terms first (order 2^-16 of the result), the leading product last
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const tbf16x8 a10 = Al[((0 * 2 + 0) * 4 + s4) * 64], a11 = Al[((0 * 2 + 1) * 4 + s4) * 64];
+                    const tbf16x8 a20 = Al[((1 * 2 + 0) * 4 + s4) * 64], a21 = Al[((1 * 2 + 1) * 4 + s4) * 64];
+                    acc0 = mfma16(a10, b3[s4], acc0);
+                    acc1 = mfma16(a11, b3[s4], acc1);
+                    acc0 = mfma16(c0[s4], b1[s4], acc0);
+                    acc1 = mfma16(c1[s4], b1[s4], acc1);
+                    acc0 = mfma16(a20, b2[s4], acc0);
+                    acc1 = mfma16(a21, b2[s4], acc1);
+                    acc0 = mfma16(a10, b2[s4], acc0);
+                    acc1 = mfma16(a11, b2[s4], acc1);
+                    acc0 = mfma16(a20, b1[s4], acc0);
+                    acc1 = mfma16(a21, b1[s4], acc1);
+                    acc0 = mfma16(a10, b1[s4], acc0);
+                    acc1 = mfma16(a11, b1[s4], acc1);
+                }
+                if (sched & 4) __builtin_amdgcn_s_setprio(0);
+            }
+            x0 = acc0;
+            x1 = acc1;
+        }
+        x0 = silu16_scalar(x0);
+        x1 = silu16_scalar(x1);
+        const float d = last_dot(L, 0, h, x0, x1);
+        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same arithmetic, scheduled: TWO tiles per wave that alternate roles.  The kernel above leaves the overlap of the
+// vector work (SiLU + split: 304 instructions per layer and tile) with the matrix work (48 MFMAs) to the four waves of a
+// SIMD being out of phase, and they are not: measured (profiles/round3/pmc_density_l3.txt) the SIMD is EITHER issuing
+// vector instructions OR running MFMAs, 2 670 cycles per tile and layer against 1 536 of MFMA.  Here a wave holds tiles A
+// and B; while the 48 MFMAs of tile A's layer run, the SiLU + split of tile B's layer input is issued in their shadow
+// -- one MFMA, then one "chunk" of about eight vector instructions (32 issue cycles), fenced by sched_barrier so that
+// hipcc keeps the interleave -- then the tiles swap.  No prologue / epilogue per layer, every MFMA has vector work behind it.
+// A and W3 fragments of the next k-step are fetched (LDS / L2) during the current one.
+// ---------------------------------------------------------------------------------------------
+struct VState {
+    float x[8], t[8];
+    unsigned h1[4], h2[4], h3[4];
+};
+
+// chunk C (0..11) of the SiLU + three-limb split of the 8 values in s.x; stage-major so that neighbours are independent.
+// SPLIT = false (input of the last layer): SiLU only, s.x holds the activations afterwards.
+template <int C, bool SPLIT>
+__device__ __forceinline__ void vchunk(VState &s) {
+#pragma clang fp contract(off)
+    constexpr unsigned M = 0xffff0000u;
+    if constexpr (C == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.t[i] = __builtin_amdgcn_exp2f(-s.x[i]);
+    } else if constexpr (C == 1) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) s.t[i] = __builtin_amdgcn_exp2f(-s.x[i]);
+    } else if constexpr (C == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.t[i] = 1.0f + s.t[i];
+    } else if constexpr (C == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.t[i] = __builtin_amdgcn_rcpf(s.t[i]);
+    } else if constexpr (C == 4) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) s.t[i] = __builtin_amdgcn_rcpf(s.t[i]);
+    } else if constexpr (C == 5) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.x[i] = s.x[i] * s.t[i];
+    } else if constexpr (!SPLIT) {
+    } else if constexpr (C == 6) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.h1[q] = cvt_pk_bf16(s.x[2 * q], s.x[2 * q + 1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { s.t[2 * q] = __uint_as_float(s.h1[q] << 16); s.t[2 * q + 1] = __uint_as_float(s.h1[q] & M); }
+    } else if constexpr (C == 7) {
+#pragma unroll
+        for (int q = 2; q < 4; ++q) { s.t[2 * q] = __uint_as_float(s.h1[q] << 16); s.t[2 * q + 1] = __uint_as_float(s.h1[q] & M); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.x[i] = s.x[i] - s.t[i];
+    } else if constexpr (C == 8) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) s.x[i] = s.x[i] - s.t[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.h2[q] = cvt_pk_bf16(s.x[2 * q], s.x[2 * q + 1]);
+    } else if constexpr (C == 9) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s.t[2 * q] = __uint_as_float(s.h2[q] << 16); s.t[2 * q + 1] = __uint_as_float(s.h2[q] & M); }
+    } else if constexpr (C == 10) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.x[i] = s.x[i] - s.t[i];
+    } else if constexpr (C == 11) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.h3[q] = cvt_pk_bf16(s.x[2 * q], s.x[2 * q + 1]);
+    }
+}
+
+struct Limbs {  // B operands of one tile's layer input: [k-step] x three limbs
+    tbf16x8 p1[4], p2[4], p3[4];
+};
+struct Frags {  // A operands that cross a k-step boundary: W1 tile 0 (LDS) and the two W3 tiles (L2) of the NEXT k-step
+    tbf16x8 a10, c0, c1;
+};
+
+// One phase = the 48 MFMAs of layer `Al` for the tile whose limbs are `m` (accumulators acc0 / acc1), with the SiLU (+ split)
+// of the OTHER tile's 64 pending values v0 / v1 issued behind them; `f` holds a10 / c0 / c1 of k-step 0 on entry and those of
+// the next phase's k-step 0 (at Anext / A3next) on exit.  Per k-step the products run fragment by fragment
+//   W1 tile 0 x (x3, x2, x1) | W1 tile 1 x (x3, x2, x1) | W2 tile 0 x (x2, x1) | W2 tile 1 x (x2, x1) | W3 tile 0 x x1 | W3 tile 1 x x1
+// so that an A fragment lives for two or three MFMAs and is fetched three slots before its first use (about 20 registers
+// of fragments in flight instead of 48).
+template <bool SPLIT>
+__device__ __forceinline__ void l3_phase(f32x16 &acc0, f32x16 &acc1, const Limbs &m, f32x16 &v0, f32x16 &v1, Limbs &o,
+                                         Frags &f, const tbf16x8 *Al, const tbf16x8 *A3l, const tbf16x8 *Anext,
+                                         const tbf16x8 *A3next) {
+#define L3_SLOT(CH, ACC, AOP, BOP, PREFETCH)                 \
+    ACC = mfma16(AOP, BOP, ACC);                             \
+    vchunk<CH, SPLIT>(s);                                    \
+    PREFETCH;                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        VState s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.x[i] = (g < 2 ? v0 : v1)[8 * (g & 1) + i];
+        const tbf16x8 *Ag = Al + g * 64;                            // [part][T][s4][lane]: + (part * 2 + T) * 256
+        const tbf16x8 *An = g < 3 ? Al + (g + 1) * 64 : Anext;
+        const tbf16x8 *A3n = g < 3 ? A3l + (g + 1) * 64 : A3next;   // [T][s4][lane]: + T * 256
+        tbf16x8 a11, a20, a21;
+        Frags n;
+        L3_SLOT(0, acc0, f.a10, m.p3[g], a11 = Ag[256])
+        L3_SLOT(1, acc0, f.a10, m.p2[g], n.c0 = A3n[0])
+        L3_SLOT(2, acc0, f.a10, m.p1[g], n.c1 = A3n[256])
+        L3_SLOT(3, acc1, a11, m.p3[g], a20 = Ag[512])
+        L3_SLOT(4, acc1, a11, m.p2[g], )
+        L3_SLOT(5, acc1, a11, m.p1[g], a21 = Ag[768])
+        L3_SLOT(6, acc0, a20, m.p2[g], )
+        L3_SLOT(7, acc0, a20, m.p1[g], n.a10 = An[0])
+        L3_SLOT(8, acc1, a21, m.p2[g], )
+        L3_SLOT(9, acc1, a21, m.p1[g], )
+        L3_SLOT(10, acc0, f.c0, m.p1[g], )
+        L3_SLOT(11, acc1, f.c1, m.p1[g], )
+        f = n;
+        if (SPLIT) {
+            u32x4 w1 = {s.h1[0], s.h1[1], s.h1[2], s.h1[3]}, w2 = {s.h2[0], s.h2[1], s.h2[2], s.h2[3]},
+                  w3 = {s.h3[0], s.h3[1], s.h3[2], s.h3[3]};
+            o.p1[g] = __builtin_bit_cast(tbf16x8, w1);
+            o.p2[g] = __builtin_bit_cast(tbf16x8, w2);
+            o.p3[g] = __builtin_bit_cast(tbf16x8, w3);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) (g < 2 ? v0 : v1)[8 * (g & 1) + i] = s.x[i];
+        }
+    }
+#undef L3_SLOT
+}
+
+// SiLU + split of all 64 pending values of a tile with nothing to hide behind (once per tile pair: tile A's first layer)
+__device__ __forceinline__ void l3_split_all(const f32x16 &v0, const f32x16 &v1, Limbs &o) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) silu_split8(g < 2 ? v0 : v1, g & 1, o.p1[g], o.p2[g], o.p3[g]);
+}
+
+__device__ __forceinline__ void l3_table_sum(const float *FA, const float *FB, const float *FC, int R, int ixl, int iy, int izc,
+                                             int h, f32x16 &x0, f32x16 &x1) {
+    f32x16 y0, y1;
+    load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
+    load_row32(FB + ((long)ixl * R + izc) * 64 + h * 32, y0, y1);
+    x0 += y0; x1 += y1;
+    load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
+    x0 += y0; x1 += y1;
+}
+
+// One k-step of ONE tile (the k-step software pipeline of density_grid_l3k_kernel): twelve MFMAs with the limbs p1 / p2 / p3
+// of k-step g, and behind them (VALU = true) the SiLU + split chunks of the values already placed in `s` (k-step g + 1).
+template <bool VALU>
+__device__ __forceinline__ void l3_kstep(f32x16 &acc0, f32x16 &acc1, const tbf16x8 &p1, const tbf16x8 &p2, const tbf16x8 &p3,
+                                         VState &s, Frags &f, const tbf16x8 *Ag, const tbf16x8 *An, const tbf16x8 *A3n) {
+#define L3_SLOT(CH, ACC, AOP, BOP, PREFETCH)                 \
+    ACC = mfma16(AOP, BOP, ACC);                             \
+    if (VALU) vchunk<CH, true>(s);                           \
+    PREFETCH;                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    tbf16x8 a11, a20, a21;
+    Frags n;
+    L3_SLOT(0, acc0, f.a10, p3, a11 = Ag[256])
+    L3_SLOT(1, acc0, f.a10, p2, n.c0 = A3n[0])
+    L3_SLOT(2, acc0, f.a10, p1, n.c1 = A3n[256])
+    L3_SLOT(3, acc1, a11, p3, a20 = Ag[512])
+    L3_SLOT(4, acc1, a11, p2, )
+    L3_SLOT(5, acc1, a11, p1, a21 = Ag[768])
+    L3_SLOT(6, acc0, a20, p2, )
+    L3_SLOT(7, acc0, a20, p1, n.a10 = An[0])
+    L3_SLOT(8, acc1, a21, p2, )
+    L3_SLOT(9, acc1, a21, p1, )
+    L3_SLOT(10, acc0, f.c0, p1, )
+    L3_SLOT(11, acc1, f.c1, p1, )
+    f = n;
+#undef L3_SLOT
+}
+
+__device__ __forceinline__ void vstate_limbs(const VState &s, tbf16x8 &p1, tbf16x8 &p2, tbf16x8 &p3) {
+    const u32x4 w1 = {s.h1[0], s.h1[1], s.h1[2], s.h1[3]}, w2 = {s.h2[0], s.h2[1], s.h2[2], s.h2[3]},
+                w3 = {s.h3[0], s.h3[1], s.h3[2], s.h3[3]};
+    p1 = __builtin_bit_cast(tbf16x8, w1);
+    p2 = __builtin_bit_cast(tbf16x8, w2);
+    p3 = __builtin_bit_cast(tbf16x8, w3);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void density_grid_l3k_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;  // >= 1 (the launcher sends NH == 0 to the plain kernel)
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
+        float *bacc = smem + NH * 4096;
+        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
+        float *wl = bacc + (NH + 1) * 64;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
+        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
+        __syncthreads();
+    }
+    const LdsView L = lds_view(smem, NH);
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int nzb = (R + 31) / 32;
+    const long ntiles = (long)nx * nzb * R;
+    const long nw_total = (long)gridDim.x * nwave;
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    int iy = (int)(t_begin % R);
+    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
+    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
+    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
+
+    for (long t = t_begin; t < t_end; ++t, ++iy) {
+        if (iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+        }
+        const int iz = zb * 32 + p;
+        f32x16 x0, x1;
+        l3_table_sum(FA, FB, FC, R, ixl, iy, min(iz, R - 1), h, x0, x1);
+        Frags f;
+        f.a10 = A[0];
+        f.c0 = A3[0]; f.c1 = A3[256];
+        for (int l = 0; l < NH; ++l) {
+            const tbf16x8 *Al = A + (long)l * 1024, *A3l = A3 + (long)l * 512;
+            const int ln = min(l + 1, NH - 1);  // the fetch behind the last k-step is never used; keep it inside the arrays
+            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
+            tbf16x8 p1, p2, p3;
+            {   // k-step 0's SiLU + split has no MFMAs of this tile to run behind
+                VState s;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s.x[i] = x0[i];
+                vchunk<0, true>(s); vchunk<1, true>(s); vchunk<2, true>(s); vchunk<3, true>(s); vchunk<4, true>(s); vchunk<5, true>(s);
+                vchunk<6, true>(s); vchunk<7, true>(s); vchunk<8, true>(s); vchunk<9, true>(s); vchunk<10, true>(s); vchunk<11, true>(s);
+                vstate_limbs(s, p1, p2, p3);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                VState s;
+                if (g < 3) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s.x[i] = (g + 1 < 2 ? x0 : x1)[8 * ((g + 1) & 1) + i];
+                }
+                const tbf16x8 *Ag = Al + g * 64;
+                const tbf16x8 *An = g < 3 ? Al + (g + 1) * 64 : A + (long)ln * 1024;
+                const tbf16x8 *A3n = g < 3 ? A3l + (g + 1) * 64 : A3 + (long)ln * 512;
+                if (g < 3) {
+                    l3_kstep<true>(acc0, acc1, p1, p2, p3, s, f, Ag, An, A3n);
+                    vstate_limbs(s, p1, p2, p3);
+                } else {
+                    l3_kstep<false>(acc0, acc1, p1, p2, p3, s, f, Ag, An, A3n);
+                }
+            }
+            x0 = acc0;
+            x1 = acc1;
+        }
+        x0 = silu16_scalar(x0);
+        x1 = silu16_scalar(x1);
+        const float d = last_dot(L, 0, h, x0, x1);
+        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void density_grid_l3p_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;  // >= 1 (the launcher sends NH == 0 to the plain kernel)
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
+        float *bacc = smem + NH * 4096;
+        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
+        float *wl = bacc + (NH + 1) * 64;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
+        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
+        __syncthreads();
+    }
+    const LdsView L = lds_view(smem, NH);
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int nzb = (R + 31) / 32;
+    const long ntiles = (long)nx * nzb * R;
+    const long nw_total = (long)gridDim.x * nwave;
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    int iy = (int)(t_begin % R);
+    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
+    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
+    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
+
+    for (long t = t_begin; t < t_end; t += 2) {
+        // tile A = t, tile B = t + 1 (the next iy of the same (ix, z block) row, or a repeat of A at the end of the range)
+        const bool haveB = t + 1 < t_end;
+        const int iyA = iy, zbA = zb, ixA = ixl;
+        if (haveB && ++iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+        }
+        const int iyB = iy, zbB = zb, ixB = ixl;
+        if (++iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+        }
+        const int izA = zbA * 32 + p, izB = zbB * 32 + p;
+        f32x16 a0, a1, b0, b1;  // pending values (layer input before SiLU) / accumulators of tiles A and B
+        l3_table_sum(FA, FB, FC, R, ixA, iyA, min(izA, R - 1), h, a0, a1);
+        l3_table_sum(FA, FB, FC, R, ixB, iyB, min(izB, R - 1), h, b0, b1);
+        Limbs la, lb;
+        Frags f;
+        f.a10 = A[0];
+        f.c0 = A3[0]; f.c1 = A3[256];
+        l3_split_all(a0, a1, la);
+        for (int l = 0; l < NH; ++l) {
+            const tbf16x8 *Al = A + (long)l * 1024, *A3l = A3 + (long)l * 512;
+            const int ln = min(l + 1, NH - 1);  // the fetch behind the last phase is never used; keep it inside the arrays
+            a0 = lds_bias16(L.bacc, l + 1, h, 0);
+            a1 = lds_bias16(L.bacc, l + 1, h, 1);
+            // A's layer l on the matrix pipe, B's input of layer l through SiLU + split
+            l3_phase<true>(a0, a1, la, b0, b1, lb, f, Al, A3l, Al, A3l);
+            b0 = lds_bias16(L.bacc, l + 1, h, 0);
+            b1 = lds_bias16(L.bacc, l + 1, h, 1);
+            // B's layer l on the matrix pipe, A's output of layer l through SiLU (+ split unless it feeds the last layer)
+            if (l + 1 < NH) l3_phase<true>(b0, b1, lb, a0, a1, la, f, Al, A3l, A + (long)ln * 1024, A3 + (long)ln * 512);
+            else l3_phase<false>(b0, b1, lb, a0, a1, la, f, Al, A3l, A + (long)ln * 1024, A3 + (long)ln * 512);
+        }
+        b0 = silu16_scalar(b0);
+        b1 = silu16_scalar(b1);
+        const float dA = last_dot(L, 0, h, a0, a1);
+        const float dB = last_dot(L, 0, h, b0, b1);
+        if (h == 0 && izA < R) out[((long)ixA * R + iyA) * R + izA] = exp_f(dA + density_bias) + out_add;
+        if (h == 0 && izB < R && haveB) out[((long)ixB * R + iyB) * R + izB] = exp_f(dB + density_bias) + out_add;
+    }
+}
+
 }  // namespace sculpt
 
 namespace sculpt {
@@ -811,6 +1371,23 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
                             const uint16_t lo = host_f32_to_bf16(w - host_bf16_to_f32(hi));
                             x3[(size_t)l * 8192 + ((((part * 2 + T) * 4 + s4) * 64 + lane) * 8) + j] = part ? lo : hi;
                         }
+    }
+    // bf16 3-limb mode: W = W1 + W2 + W3 EXACTLY (W1, W2 are the two parts above; a 24-bit significand minus two
+    // round-to-nearest 8-bit limbs leaves at most 8 significant bits, so W3 = W - W1 - W2 is itself a bf16 value)
+    uint16_t *w3 = reinterpret_cast<uint16_t *>(o + hd.off_w3);
+    for (int l = 0; l < NH; ++l) {
+        const float *Wl = Wh[l + 1];
+        for (int T = 0; T < 2; ++T)
+            for (int s4 = 0; s4 < 4; ++s4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 16 * s4 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                        const float w = Wl[(size_t)(32 * T + (lane & 31)) * HID + k];
+                        const float w1 = host_bf16_to_f32(host_f32_to_bf16(w));
+                        const float r1 = w - w1;
+                        const float w2 = host_bf16_to_f32(host_f32_to_bf16(r1));
+                        w3[(size_t)l * 4096 + (((T * 4 + s4) * 64 + lane) * 8) + j] = host_f32_to_bf16(r1 - w2);
+                    }
     }
     // fp16x3 mode: the same with IEEE half parts (11-bit significands: W - (Wh + Wl) ~ 2^-22 |W|)
     _Float16 *x3h = reinterpret_cast<_Float16 *>(o + hd.off_x3h);
@@ -930,6 +1507,46 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
     const float *FB = FA + (size_t)nx * R * 64;
     const float *FC = FB + (size_t)nx * R * 64;
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
+    if (flags & SCULPT_DENSITY_BF16L3) {
+        // A/B knobs (read per call: a debugging aid, not an interface): workgroup size and the in-wave k-step pipeline
+        const int l3_threads = getenv("SCULPT_DENSITY_L3_THREADS") ? atoi(getenv("SCULPT_DENSITY_L3_THREADS")) : 1024;
+        const bool pair = getenv("SCULPT_DENSITY_L3_PAIR") && atoi(getenv("SCULPT_DENSITY_L3_PAIR")) != 0;
+        if (pair && n_hidden_64 >= 1) {
+            const int ntp = l3_threads == 256 ? 256 : (l3_threads == 768 ? 768 : 512);
+            auto kp = ntp == 256 ? density_grid_l3p_kernel<256> : (ntp == 768 ? density_grid_l3p_kernel<768> : density_grid_l3p_kernel<512>);
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int nw = ntp / 64;
+            const int grid = (int)std::min<long>((ntiles + 2 * nw - 1) / (2 * nw), num_cus());
+            hipLaunchKernelGGL(kp, dim3(grid), dim3(ntp), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
+                               density_bias, out_add, out);
+            SC_LAUNCH_CHECK();
+            return 0;
+        }
+        const int kpipe = getenv("SCULPT_DENSITY_L3_KSTEP") ? atoi(getenv("SCULPT_DENSITY_L3_KSTEP")) : 0;
+        if (kpipe && n_hidden_64 >= 1) {
+            const int ntk = l3_threads == 512 ? 512 : (l3_threads == 768 ? 768 : 1024);
+            auto kk = ntk == 512 ? density_grid_l3k_kernel<512> : (ntk == 768 ? density_grid_l3k_kernel<768> : density_grid_l3k_kernel<1024>);
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int nw = ntk / 64;
+            const int grid = (int)std::min<long>((ntiles + nw - 1) / nw, num_cus());
+            hipLaunchKernelGGL(kk, dim3(grid), dim3(ntk), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
+                               density_bias, out_add, out);
+            SC_LAUNCH_CHECK();
+            return 0;
+        }
+        const bool pipe = !(getenv("SCULPT_DENSITY_L3_PIPE") && atoi(getenv("SCULPT_DENSITY_L3_PIPE")) == 0);
+        const int nt = l3_threads == 768 ? 768 : (l3_threads == 512 ? 512 : 1024);
+        auto kern = nt == 1024 ? (pipe ? density_grid_l3_kernel<1024, 1> : density_grid_l3_kernel<1024, 0>)
+                  : nt == 768  ? (pipe ? density_grid_l3_kernel<768, 1> : density_grid_l3_kernel<768, 0>)
+                               : (pipe ? density_grid_l3_kernel<512, 1> : density_grid_l3_kernel<512, 0>);
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int nwave = nt / 64;
+        const int grid = (int)std::min<long>((ntiles + nwave - 1) / nwave, num_cus());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
+                           density_bias, out_add, out, getenv("SCULPT_DENSITY_L3_SCHED") ? atoi(getenv("SCULPT_DENSITY_L3_SCHED")) : 0);
+        SC_LAUNCH_CHECK();
+        return 0;
+    }
     if (flags & (SCULPT_DENSITY_BF16X3 | SCULPT_DENSITY_FP16X3)) {
         auto kern = (flags & SCULPT_DENSITY_FP16X3) ? density_grid_x3_kernel<tf16x8> : density_grid_x3_kernel<tbf16x8>;
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -109,7 +109,7 @@ def _workspace(key, nbytes, device):
     return t
 
 
-_DENSITY_FLAGS = {"fp32": 0, "bf16x3": _lib.DENSITY_BF16X3, "fp16x3": _lib.DENSITY_FP16X3}
+_DENSITY_FLAGS = {"fp32": 0, "bf16x3": _lib.DENSITY_BF16X3, "fp16x3": _lib.DENSITY_FP16X3, "bf16l3": _lib.DENSITY_BF16L3}
 
 
 def lattice_decode(planes, mlp, axis, radius, density_bias=0.0, out_add=0.0, want=("density_act",), align_corners=True,
