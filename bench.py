@@ -6,7 +6,8 @@
 
 A "step" = one image -> mesh through the reference's own entry points (TripoSR/generate.py:32-43 ->
 tsr/system.py:82-115,171-200): TSR.forward (ViT-B/16 + 16-block triplane transformer, bf16 MFMA)
-+ TSR.extract_meshes at 256^3 (fused triplane sample + NeRF-MLP on fp32 MFMA, Lewiner marching cubes).
++ TSR.extract_meshes at 256^3 (fused triplane sample + NeRF-MLP: fp32 arithmetic on the bf16 matrix pipe through an exact
+three-limb split of both operands, fp32 accumulate; Lewiner marching cubes).
 `value` times those two calls with the image resident in HBM and the mesh left in HBM (the contract's
 definition); the extra key "boundary" times TSR.run_async(host image) -> host mesh (H2D of the image,
 pinned D2H of vertices / faces on a copy stream under the next image's kernels).
@@ -30,11 +31,25 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling (ALGORITHMIC, what `roofline.achieved` uses)
-EXECUTED_FLOP_PER_POINT = 65.5e3  # on the matrix pipe: 8 hidden 64x64 layers (layer 0 is hoisted into the separable plane
-                                  # tables, the last layer is a VALU dot): what `roofline.executed_frac` uses
+FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling (ALGORITHMIC: `roofline.algorithmic_*`)
+# FLOPs the dominant kernel's MFMA instructions EXECUTE per lattice point (what `roofline.achieved` / `frac` use):
+#   bf16l3: 8 hidden layers x 48 v_mfma_f32_32x32x16_bf16 (32 768 FLOP each) per 32 points = six 64x64 products per layer
+#   fp32  : 8 hidden layers x 64 v_mfma_f32_32x32x2_f32 (4 096 FLOP each) per 32 points   = one 64x64 product per layer
+# (layer 0 is hoisted into the separable plane tables, the last layer is a VALU dot: neither is on the matrix pipe)
+EXECUTED_FLOP_PER_POINT = {"bf16l3": 8 * 48 * 32768 / 32, "fp32": 8 * 64 * 4096 / 32, "bf16x3": 8 * 24 * 32768 / 32,
+                           "fp16x3": 8 * 24 * 32768 / 32}
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (only used with --decoder-precision bf16x3)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak
+KERNEL_NAME = {"bf16l3": "density_grid_l3k_kernel (fused triplane-sum + NeRF-MLP; hidden layers as six exact bf16-limb products on "
+                         "v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+               "fp32": "density_grid_kernel (fused triplane-sum + NeRF-MLP, exact fp32 on v_mfma_f32_32x32x2_f32)",
+               "bf16x3": "density_grid_x3_kernel<bf16> (two-limb experiment, 16-bit operands)",
+               "fp16x3": "density_grid_x3_kernel<f16> (two-limb experiment, 22-bit operands)"}
+DTYPE = {"bf16l3": "fp32-equivalent (bf16 3-limb split, 24 bits, fp32 accumulate) density MLP / f32 tables, SiLU, marching cubes / "
+                   "bf16 transformer",
+         "fp32": "f32 (density MLP + marching cubes) / bf16 (transformer)",
+         "bf16x3": "bf16x3 split operands (16 bits), fp32 accumulate (density MLP hidden layers) / f32 (tables, SiLU, marching cubes) / bf16 (transformer)",
+         "fp16x3": "fp16x3 split operands (22 bits), fp32 accumulate (density MLP hidden layers) / f32 (tables, SiLU, marching cubes) / bf16 (transformer)"}
 MC_RES = 256
 THRESHOLD = 25.0
 
@@ -73,7 +88,7 @@ def calibrate(model, sd, img_dev, inside=0.015):
     return shift
 
 
-DECODER_PRECISION = "fp32"  # --decoder-precision bf16x3 selects the optional split-operand bf16 mode
+DECODER_PRECISION = "bf16l3"  # TSR's default; --decoder-precision fp32 times the exact-fp32 kernel instead
 
 
 def one_step(model, img_dev, events=None):
@@ -151,8 +166,52 @@ def density_deviation(model, img_dev, mode, R=96):
     return float(((a - b).abs() / a.abs().clamp_min(1e-3)).max())
 
 
+def fp32_exact_sibling(model, imgs, steps):
+    """The exact-fp32 kernel (TSR(decoder_precision="fp32"), the parity mode) beside the default: its launch time by HIP events,
+    the fraction of the fp32 matrix peak its MFMA instructions reach, and the whole-step rate with it."""
+    keep = model.decoder_precision
+    try:
+        model.decoder_precision = "fp32"
+        one_step(model, imgs[0])
+        torch.cuda.synchronize()
+        n = max(3, min(steps, 10))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        t0 = time.perf_counter()
+        for i in range(n):
+            one_step(model, imgs[i % len(imgs)], events=ev[i])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    finally:
+        model.decoder_precision = keep
+    ex = EXECUTED_FLOP_PER_POINT["fp32"] * MC_RES ** 3
+    return {"kernel": KERNEL_NAME["fp32"], "launch_ms": ms, "bound": "mfma", "executed_flop_per_launch": ex,
+            "achieved": ex / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ex / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "meshes_per_s": n / dt, "ms_per_step": dt / n * 1e3}
+
+
+def kernel_parity(model, img_dev):
+    """Default-mode volume against the exact-fp32 kernel's on the bench's own 256^3 field: lattice points on different sides of
+    the threshold (= cells whose marching-cubes case can differ), max relative deviation of density_act."""
+    from sculptmate_amd import ops
+
+    _, outb = model.encode_image(img_dev)
+    planes = model.scene_code(outb)
+    cfg = model.renderer.cfg
+    a = ops.density_grid(planes, model.decoder, MC_RES, radius=cfg.radius, density_bias=cfg.density_bias, out_add=-THRESHOLD).clone()
+    b = ops.density_grid(planes, model.decoder, MC_RES, radius=cfg.radius, density_bias=cfg.density_bias, out_add=-THRESHOLD,
+                         precision=DECODER_PRECISION)
+    flips = torch.nonzero((a > 0) != (b > 0)).reshape(-1)
+    rel = float((((a - b).abs()) / (a + THRESHOLD).abs().clamp_min(1e-3)).max())
+    return {"field": "256^3 volume of the bench image, default mode vs exact-fp32 kernel",
+            "lattice_points_on_different_sides_of_threshold": int(flips.numel()),
+            "flipped_points": [[int(i), float(a[i]), float(b[i])] for i in flips[:8]],
+            "density_max_rel_dev": rel}
+
+
 def optional_mode_rates(model, imgs, steps):
-    """Whole-step rate with the optional split-operand density modes, measured after the timed region."""
+    """Whole-step rate with the two-limb experiment modes (narrower than fp32, never `value`)."""
     res = {}
     keep = model.decoder_precision
     try:
@@ -172,6 +231,16 @@ def optional_mode_rates(model, imgs, steps):
     return res
 
 
+def mesh_distance(v, rv, extent):
+    """Two-sided nearest-vertex distances between two meshes as fractions of `extent`."""
+    from scipy.spatial import cKDTree
+
+    v, rv = np.asarray(v, np.float64), np.asarray(rv, np.float64)
+    d = np.concatenate([cKDTree(rv).query(v)[0], cKDTree(v).query(rv)[0]]) / extent
+    return {"max": float(d.max()), "p999": float(np.quantile(d, 0.999)), "p99": float(np.quantile(d, 0.99)), "mean": float(d.mean()),
+            "vertices": [int(len(v)), int(len(rv))]}
+
+
 def _median_time(fn, warm=1, n=3):
     for _ in range(warm):
         fn()
@@ -186,8 +255,9 @@ def _median_time(fn, warm=1, n=3):
 def cpu_baseline(sd, img_np):
     """the oracle (CPU restatement of the reference, kind "port") on this box's host cores,
     configured like BASELINE config 1 -- ONE 512x512 image, mc_resolution=128, fp32 -- every stage measured whole
-    (1 warm-up + 3 timed runs, median), all cores.  The single-thread figure and the 256^3 figure are bounded samples,
-    labelled as extrapolations."""
+    (1 warm-up + 3 timed runs, median), all cores; then the metric's own size, mc_resolution=256, with the query and marching
+    cubes measured whole once (about 15 s).  Only the single-thread figure is a bounded sample, labelled as an extrapolation.
+    Returns (json dict, CPU mesh vertices at 128^3 in scene units) -- the mesh feeds `parity.bf16_mesh_vs_fp32_cpu`."""
     from oracle import capi, tsr_ref
     from sculptmate_amd import synth
     from sculptmate_amd.tsr.spec import DEFAULT_CFG
@@ -211,10 +281,23 @@ def cpu_baseline(sd, img_np):
         dens["d"] = capi.density_grid(planes, Ws, bs, R)
 
     t_q = _median_time(query)
-    thr = np.float32(np.quantile(dens["d"], 0.985))
-    level = -(dens["d"] - thr)
-    t_mc = _median_time(lambda: capi.reference_isosurface(level, R))
+    level = -(dens["d"] - np.float32(THRESHOLD))   # system.py:184 with the bench's calibrated model: the surface exists at 25
+    mesh = {}
+
+    def mc():
+        mesh["v"], mesh["f"] = capi.reference_isosurface(level, R)
+
+    t_mc = _median_time(mc)
+    cpu_verts = mesh["v"] * np.float32(0.87 - (-0.87)) + np.float32(-0.87)
     total = t_fwd + t_q + t_mc
+    # the metric's own size: mc_resolution = 256, query + marching cubes measured whole, once (forward is resolution-independent)
+    t0 = time.perf_counter()
+    d256 = capi.density_grid(planes, Ws, bs, MC_RES)
+    t_q256 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    v256, f256 = capi.reference_isosurface(-(d256 - np.float32(THRESHOLD)), MC_RES)
+    t_mc256 = time.perf_counter() - t0
+    del d256
     # single thread: bounded sample (one of 12 ViT layers incl. patch embedding, one of 16 backbone blocks, 1/16 of the
     # 128^3 lattice), extrapolated by the layer / lattice counts
     torch.set_num_threads(1)
@@ -236,17 +319,22 @@ def cpu_baseline(sd, img_np):
     total_1t = t_vit1 * 12 + t_blk1 * 16 + t_q1 + t_mc
     torch.set_num_threads(cores)
     capi.set_threads(cores)
-    return {"value": 1.0 / total, "unit": "meshes/s", "cores": cores, "kind": "port",
-            "sample": "BASELINE config 1 exactly: one 512x512 image, mc_resolution=128, fp32, all stages whole, 1 warm-up + 3 timed "
-                      "(median): TSR.forward %.2fs + query_triplane 128^3 %.2fs + marching cubes %.3fs (single thread, like "
-                      "scikit-image) = %.2fs on %d threads" % (t_fwd, t_q, t_mc, total, cores),
-            "lscpu_logical_cpus": ncpu, "ms_per_image": total * 1e3,
-            "stages_s": {"forward": t_fwd, "query_128": t_q, "marching_cubes_128": t_mc},
-            "single_thread": {"value": 1.0 / total_1t, "unit": "meshes/s", "cores": 1, "extrapolated": True,
-                              "sample": "1 of 12 ViT layers %.2fs x12 + 1 of 16 backbone blocks %.2fs x16 + 1/16 of the 128^3 query "
-                                        "x16 = %.2fs + marching cubes %.3fs" % (t_vit1, t_blk1, t_q1, t_mc)},
-            "at_256": {"value": 1.0 / (t_fwd + 8 * t_q + 8 * t_mc), "unit": "meshes/s", "cores": cores, "extrapolated": True,
-                       "sample": "the 128^3 query and marching-cubes times x8 (lattice points / cells), forward unchanged"}}
+    out = {"value": 1.0 / total, "unit": "meshes/s", "cores": cores, "kind": "port",
+           "sample": "BASELINE config 1 exactly: one 512x512 image, mc_resolution=128, fp32, all stages whole, 1 warm-up + 3 timed "
+                     "(median): TSR.forward %.2fs + query_triplane 128^3 %.2fs + marching cubes %.3fs (single thread, like "
+                     "scikit-image) = %.2fs on %d threads" % (t_fwd, t_q, t_mc, total, cores),
+           "lscpu_logical_cpus": ncpu, "ms_per_image": total * 1e3,
+           "stages_s": {"forward": t_fwd, "query_128": t_q, "marching_cubes_128": t_mc},
+           "mesh_128": {"vertices": int(len(mesh["v"])), "faces": int(len(mesh["f"]))},
+           "at_256": {"value": 1.0 / (t_fwd + t_q256 + t_mc256), "unit": "meshes/s", "cores": cores, "extrapolated": False,
+                      "stages_s": {"forward": t_fwd, "query_256": t_q256, "marching_cubes_256": t_mc256},
+                      "mesh": {"vertices": int(len(v256)), "faces": int(len(f256))},
+                      "sample": "the metric's own configuration (mc_resolution=256): query_triplane over 256^3 and marching cubes "
+                                "measured whole, one run each, + the forward time above"},
+           "single_thread": {"value": 1.0 / total_1t, "unit": "meshes/s", "cores": 1, "extrapolated": True,
+                             "sample": "the only extrapolated figure: 1 of 12 ViT layers %.2fs x12 + 1 of 16 backbone blocks %.2fs x16 "
+                                       "+ 1/16 of the 128^3 query x16 = %.2fs + marching cubes %.3fs" % (t_vit1, t_blk1, t_q1, t_mc)}}
+    return out, cpu_verts
 
 
 def slab512_extra(model, img_dev, world=8, iters=2):
@@ -327,8 +415,9 @@ def main():
                     help="skip the informational split-operand rates (profiling runs: keeps the kernel rows to the default path)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys measured after the timed region (boundary, slab512, sf3d)")
-    ap.add_argument("--decoder-precision", choices=("fp32", "fp16x3", "bf16x3"), default="fp32",
-                    help="fp32 (default, exact-fp32 MFMA density MLP) or an optional split-operand 16-bit MFMA mode")
+    ap.add_argument("--decoder-precision", choices=("bf16l3", "fp32", "fp16x3", "bf16x3"), default="bf16l3",
+                    help="bf16l3 (default = TSR's default: fp32-equivalent three-limb bf16 split), fp32 (exact-fp32 MFMA kernel), "
+                         "or a two-limb experiment mode")
     args = ap.parse_args()
     global DECODER_PRECISION
     DECODER_PRECISION = args.decoder_precision
@@ -346,6 +435,8 @@ def main():
     share_gpu = bool(os.environ.get("SCULPT_BENCH_SHARE_GPU"))
     backend = os.environ.get("SCULPT_BENCH_BACKEND", "nccl")
     dev_index = 0 if share_gpu else local_rank
+    if not share_gpu and local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU of its own (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     from sculptmate_amd import parallel, synth
@@ -383,15 +474,17 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0:
-        achieved = FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12
-        x3 = DECODER_PRECISION != "fp32"
-        peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+        mode = DECODER_PRECISION
+        executed = EXECUTED_FLOP_PER_POINT[mode] * MC_RES ** 3
+        achieved = executed / (kern_ms * 1e-3) / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if mode == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_density_grid.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                traffic, traffic_src = j.get("hbm_bytes_per_launch"), "profiles/pmc_density_grid.json (%s)" % j.get("source", "rocprofv3 --pmc passes")
+                if j.get("mode", "fp32") == mode:
+                    traffic, traffic_src = j.get("hbm_bytes_per_launch"), "profiles/pmc_density_grid.json (%s)" % j.get("source", "rocprofv3 --pmc passes")
             except Exception:
                 traffic = None
         out = {
@@ -405,25 +498,27 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("%s split operands, fp32 accumulate (density MLP hidden layers) / f32 (tables, SiLU, marching "
-                      "cubes) / bf16 (transformer)" % DECODER_PRECISION) if x3 else
-                     "f32 (density MLP + marching cubes) / bf16 (transformer)",
+            "dtype": DTYPE[mode],
             "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
             "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
                        "entry_points_timed": "TSR.forward([image resident in HBM]) + TSR.extract_meshes(codes, resolution=256): mesh "
                                              "left in HBM; the host-boundary rate is the extra key 'boundary'",
                        "mc_resolution": MC_RES, "threshold": THRESHOLD, "images_per_gpu_per_step": 1,
+                       "decoder_precision": mode,
+                       # test plumbing made visible (tests/test_gpu_bench_ranks.py): ranks sharing one device are NOT a multi-GPU figure
+                       "shared_gpu": share_gpu, "collective_backend": backend if dist is not None else None,
                        "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
-            "roofline": {"kernel": ("density_grid_x3_kernel (fused triplane-sum + NeRF-MLP, %s MFMA: 3 MFMA flops per "
-                                    "algorithmic flop)" % DECODER_PRECISION) if x3 else
-                                   "density_grid_kernel (fused triplane-sum + NeRF-MLP, fp32 MFMA)",
+            # achieved / frac: the FLOPs the kernel's MFMA instructions execute (cross-check: SQ_INSTS_VALU_MFMA_MOPS_* x 512 in
+            # profiles/round3/pmc_summary.txt) over the live HIP-event launch time, against the dense peak of that pipe
+            "roofline": {"kernel": KERNEL_NAME[mode],
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None if x3 else traffic,
-                         "traffic_source": None if x3 else traffic_src,
-                         "launch_ms": kern_ms, "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3,
-                         # the algorithmic count includes the layer-0 work the separable tables remove, so `frac` can pass 1;
-                         # the fraction of the fp32 matrix peak the kernel's own MFMA instructions reach:
-                         "executed_frac": None if x3 else EXECUTED_FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12 / peak},
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         "launch_ms": kern_ms, "executed_flop_per_launch": executed,
+                         "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3,
+                         "algorithmic_tflops": FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12,
+                         # SURVEY 8(d)'s 82.4 kFLOP/point (includes the layer-0 work the separable tables remove) over the SAME
+                         # time, against the fp32 matrix peak the reference's arithmetic would be priced at: can pass 1
+                         "algorithmic_frac": FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
             "latency_ms_per_image": elapsed / args.steps * 1e3,  # steps run back to back, one image in flight: step time = latency
         }
         with torch.no_grad():
@@ -433,7 +528,10 @@ def main():
             # bf16 MFMA fraction of the transformer stack: 2.96 TFLOP / image over the two stage times
             out["transformer_roofline"] = {"bound": "mfma", "achieved": 2.96 / (out["transformer_ms"] * 1e-3), "peak": PEAK_BF16_MFMA_TFLOPS,
                                            "unit": "TFLOP/s", "frac": 2.96 / (out["transformer_ms"] * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
-            single = args.gpus == 1 and DECODER_PRECISION == "fp32"
+            single = args.gpus == 1 and DECODER_PRECISION == "bf16l3"
+            if single:
+                out["fp32_exact"] = fp32_exact_sibling(model, imgs, args.steps)
+                out["parity"] = {"kernel_vs_fp32_kernel": kernel_parity(model, imgs[0])}
             if single and not args.no_extras:
                 out["boundary"] = boundary_rate(model, imgs_np, args.steps)
             if single and not args.no_optional_modes:
@@ -448,7 +546,16 @@ def main():
                         out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
                     torch.cuda.empty_cache()
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, imgs_np[0])
+            out["cpu_baseline"], cpu_verts = cpu_baseline(sd, imgs_np[0])
+            # the headline mode's mesh (bf16 transformer, default decoder mode) against the oracle's fp32 CPU mesh of the same
+            # image at BASELINE config 1's resolution: two-sided nearest-vertex distances over the 1.74 extent
+            with torch.no_grad():
+                gm = model.run_async(imgs_np[0], 128, THRESHOLD).result()
+            d = mesh_distance(gm.vertices, cpu_verts, 1.74)
+            d["what"] = ("128^3, bench image 0, threshold 25: default mode (bf16 transformer + %s decoder) vs the oracle's fp32 CPU path; "
+                         "two-sided nearest-vertex distance / 1.74; bounds asserted in tests/test_gpu_transformer.py: mean < 4e-4, "
+                         "p99 < 2e-3, p99.9 < 5e-2, max < 1e-1" % DECODER_PRECISION)
+            out.setdefault("parity", {})["bf16_mesh_vs_fp32_cpu"] = d
         else:
             out["cpu_baseline"] = None
         # on its own line whatever was written before it (RCCL warnings go to stdout without a trailing newline)

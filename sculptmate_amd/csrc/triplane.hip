@@ -759,31 +759,10 @@ __device__ __forceinline__ void split16_l3(const f32x16 &x, tbf16x8 p1[2], tbf16
     }
 }
 
-// One k-step (8 accumulator values of one lane = 8 of the 64 activations of its point) of SiLU + three-limb split: the
-// VALU work of a k-step as one unit, so that the kernel can run it UNDER the previous k-step's twelve MFMAs.
-__device__ __forceinline__ void silu_split8(const f32x16 &x, int q, tbf16x8 &p1, tbf16x8 &p2, tbf16x8 &p3) {
-#pragma clang fp contract(off)
-    u32x4 v1, v2, v3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = silu_f(x[8 * q + 2 * i]), b = silu_f(x[8 * q + 2 * i + 1]);
-        const unsigned h1 = cvt_pk_bf16(a, b);
-        const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);
-        const unsigned h2 = cvt_pk_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(h2 << 16), sb = rb - __uint_as_float(h2 & 0xffff0000u);
-        v1[i] = h1;
-        v2[i] = h2;
-        v3[i] = cvt_pk_bf16(sa, sb);
-    }
-    p1 = __builtin_bit_cast(tbf16x8, v1);
-    p2 = __builtin_bit_cast(tbf16x8, v2);
-    p3 = __builtin_bit_cast(tbf16x8, v3);
-}
-
-template <int NT, int PIPE>
+template <int NT>
 __global__ __launch_bounds__(NT) void density_grid_l3_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out, int sched) {
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
@@ -812,15 +791,6 @@ __global__ __launch_bounds__(NT) void density_grid_l3_kernel(
     int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
     const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
     const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
-    if (sched & 1) {  // static, distinct priorities for the waves that share a SIMD (waves w, w + 4, w + 8, w + 12)
-        const int pr = (wave >> 2) & 3;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-    if (sched & 2) {  // stagger: every second wave of a SIMD starts half a layer late
-        if ((wave >> 2) & 1) __builtin_amdgcn_s_sleep(20);
-    }
 
     for (long t = t_begin; t < t_end; ++t, ++iy) {
         if (iy == R) {
@@ -846,57 +816,16 @@ __global__ __launch_bounds__(NT) void density_grid_l3_kernel(
             // keep the eight loads HERE: left alone, hipcc sinks each one to just before the MFMA that consumes it and
             // waits vmcnt(0) there -- eight exposed L2 round trips per layer
             __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
-            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
             const tbf16x8 *Al = A + (long)l * 16 * 64;
-            if (PIPE) {
-                // k-step software pipeline inside the wave: the SiLU + split of k-step g + 1 (76 vector instructions) is
-                // issued in the shadow of the twelve MFMAs of k-step g (24 free issue cycles behind each), so a wave
-                // overlaps its own vector and matrix work instead of relying on its SIMD partners being out of phase
-                tbf16x8 p1, p2, p3;
-                silu_split8(x0, 0, p1, p2, p3);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    tbf16x8 n1 = p1, n2 = p2, n3 = p3;
-                    if (g < 3) silu_split8(g + 1 < 2 ? x0 : x1, (g + 1) & 1, n1, n2, n3);
-                    const tbf16x8 a10 = Al[((0 * 2 + 0) * 4 + g) * 64], a11 = Al[((0 * 2 + 1) * 4 + g) * 64];
-                    const tbf16x8 a20 = Al[((1 * 2 + 0) * 4 + g) * 64], a21 = Al[((1 * 2 + 1) * 4 + g) * 64];
-                    acc0 = mfma16(a10, p3, acc0);
-                    acc1 = mfma16(a11, p3, acc1);
-                    acc0 = mfma16(c0[g], p1, acc0);
-                    acc1 = mfma16(c1[g], p1, acc1);
-                    acc0 = mfma16(a20, p2, acc0);
-                    acc1 = mfma16(a21, p2, acc1);
-                    acc0 = mfma16(a10, p2, acc0);
-                    acc1 = mfma16(a11, p2, acc1);
-                    acc0 = mfma16(a20, p1, acc0);
-                    acc1 = mfma16(a21, p1, acc1);
-                    acc0 = mfma16(a10, p1, acc0);
-                    acc1 = mfma16(a11, p1, acc1);
-                    if (g < 3) {
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {  // one MFMA, then its share of the 76 vector instructions
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    p1 = n1; p2 = n2; p3 = n3;
-                }
-            } else {
+            f32x16 acc0, acc1;
+            {
                 x0 = silu16_scalar(x0);
                 x1 = silu16_scalar(x1);
                 tbf16x8 b1[4], b2[4], b3[4];  // B operands of the four k-steps: tiles (x0: s = 0,1), (x1: s = 2,3)
                 split16_l3(x0, b1, b2, b3);
                 split16_l3(x1, b1 + 2, b2 + 2, b3 + 2);
-                // The matrix phase outranks the vector phases of the other waves on this SIMD: with equal priorities the
-                // arbiter keeps feeding the (older) waves that have vector instructions ready and this wave's MFMAs wait,
-                // so matrix and vector work of different waves end up one after the other instead of side by side.
-                if (sched & 4) __builtin_amdgcn_s_setprio(3);
+                acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+                acc1 = lds_bias16(L.bacc, l + 1, h, 1);
                 // small terms first (order 2^-16 of the result), the leading product last
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
@@ -915,7 +844,6 @@ __global__ __launch_bounds__(NT) void density_grid_l3_kernel(
                     acc0 = mfma16(a10, b1[s4], acc0);
                     acc1 = mfma16(a11, b1[s4], acc1);
                 }
-                if (sched & 4) __builtin_amdgcn_s_setprio(0);
             }
             x0 = acc0;
             x1 = acc1;
@@ -928,14 +856,16 @@ __global__ __launch_bounds__(NT) void density_grid_l3_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same arithmetic, scheduled: TWO tiles per wave that alternate roles.  The kernel above leaves the overlap of the
-// vector work (SiLU + split: 304 instructions per layer and tile) with the matrix work (48 MFMAs) to the four waves of a
-// SIMD being out of phase, and they are not: measured (profiles/round3/pmc_density_l3.txt) the SIMD is EITHER issuing
-// vector instructions OR running MFMAs, 2 670 cycles per tile and layer against 1 536 of MFMA.  Here a wave holds tiles A
-// and B; while the 48 MFMAs of tile A's layer run, the SiLU + split of tile B's layer input is issued in their shadow
-// -- one MFMA, then one "chunk" of about eight vector instructions (32 issue cycles), fenced by sched_barrier so that
-// hipcc keeps the interleave -- then the tiles swap.  No prologue / epilogue per layer, every MFMA has vector work behind it.
-// A and W3 fragments of the next k-step are fetched (LDS / L2) during the current one.
+// The same arithmetic, scheduled inside the wave (density_grid_l3k_kernel, the default).  The kernel above leaves the overlap
+// of the vector work (SiLU + split: 304 instructions per layer and tile) with the matrix work (48 MFMAs) to the four waves
+// of a SIMD being out of phase; measured (profiles/round3/pmc_density_l3.txt) the SIMD is EITHER issuing vector instructions
+// OR running MFMAs, 2 670 cycles per tile and layer against 1 536 of MFMA, and neither per-wave priorities, a raised
+// priority in the matrix phase nor a start-up stagger change that.  What does overlap is a wave's OWN vector work issued
+// right behind its MFMAs (tools/micro/mfma_fill.hip: six plain or three transcendental instructions per MFMA are free).
+// So the layer runs as a k-step software pipeline: while the twelve MFMAs of k-step g run, the SiLU + split of the eight
+// values of k-step g + 1 is issued in their shadow -- one MFMA, then one "chunk" of eight plain / four transcendental
+// vector instructions, fenced by sched_barrier so that hipcc keeps the interleave.  A and W3 fragments are fetched (LDS / L2)
+// a few slots ahead of their first use.
 // ---------------------------------------------------------------------------------------------
 struct VState {
     float x[8], t[8];
@@ -994,70 +924,9 @@ __device__ __forceinline__ void vchunk(VState &s) {
     }
 }
 
-struct Limbs {  // B operands of one tile's layer input: [k-step] x three limbs
-    tbf16x8 p1[4], p2[4], p3[4];
-};
 struct Frags {  // A operands that cross a k-step boundary: W1 tile 0 (LDS) and the two W3 tiles (L2) of the NEXT k-step
     tbf16x8 a10, c0, c1;
 };
-
-// One phase = the 48 MFMAs of layer `Al` for the tile whose limbs are `m` (accumulators acc0 / acc1), with the SiLU (+ split)
-// of the OTHER tile's 64 pending values v0 / v1 issued behind them; `f` holds a10 / c0 / c1 of k-step 0 on entry and those of
-// the next phase's k-step 0 (at Anext / A3next) on exit.  Per k-step the products run fragment by fragment
-//   W1 tile 0 x (x3, x2, x1) | W1 tile 1 x (x3, x2, x1) | W2 tile 0 x (x2, x1) | W2 tile 1 x (x2, x1) | W3 tile 0 x x1 | W3 tile 1 x x1
-// so that an A fragment lives for two or three MFMAs and is fetched three slots before its first use (about 20 registers
-// of fragments in flight instead of 48).
-template <bool SPLIT>
-__device__ __forceinline__ void l3_phase(f32x16 &acc0, f32x16 &acc1, const Limbs &m, f32x16 &v0, f32x16 &v1, Limbs &o,
-                                         Frags &f, const tbf16x8 *Al, const tbf16x8 *A3l, const tbf16x8 *Anext,
-                                         const tbf16x8 *A3next) {
-#define L3_SLOT(CH, ACC, AOP, BOP, PREFETCH)                 \
-    ACC = mfma16(AOP, BOP, ACC);                             \
-    vchunk<CH, SPLIT>(s);                                    \
-    PREFETCH;                                                \
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        VState s;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s.x[i] = (g < 2 ? v0 : v1)[8 * (g & 1) + i];
-        const tbf16x8 *Ag = Al + g * 64;                            // [part][T][s4][lane]: + (part * 2 + T) * 256
-        const tbf16x8 *An = g < 3 ? Al + (g + 1) * 64 : Anext;
-        const tbf16x8 *A3n = g < 3 ? A3l + (g + 1) * 64 : A3next;   // [T][s4][lane]: + T * 256
-        tbf16x8 a11, a20, a21;
-        Frags n;
-        L3_SLOT(0, acc0, f.a10, m.p3[g], a11 = Ag[256])
-        L3_SLOT(1, acc0, f.a10, m.p2[g], n.c0 = A3n[0])
-        L3_SLOT(2, acc0, f.a10, m.p1[g], n.c1 = A3n[256])
-        L3_SLOT(3, acc1, a11, m.p3[g], a20 = Ag[512])
-        L3_SLOT(4, acc1, a11, m.p2[g], )
-        L3_SLOT(5, acc1, a11, m.p1[g], a21 = Ag[768])
-        L3_SLOT(6, acc0, a20, m.p2[g], )
-        L3_SLOT(7, acc0, a20, m.p1[g], n.a10 = An[0])
-        L3_SLOT(8, acc1, a21, m.p2[g], )
-        L3_SLOT(9, acc1, a21, m.p1[g], )
-        L3_SLOT(10, acc0, f.c0, m.p1[g], )
-        L3_SLOT(11, acc1, f.c1, m.p1[g], )
-        f = n;
-        if (SPLIT) {
-            u32x4 w1 = {s.h1[0], s.h1[1], s.h1[2], s.h1[3]}, w2 = {s.h2[0], s.h2[1], s.h2[2], s.h2[3]},
-                  w3 = {s.h3[0], s.h3[1], s.h3[2], s.h3[3]};
-            o.p1[g] = __builtin_bit_cast(tbf16x8, w1);
-            o.p2[g] = __builtin_bit_cast(tbf16x8, w2);
-            o.p3[g] = __builtin_bit_cast(tbf16x8, w3);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) (g < 2 ? v0 : v1)[8 * (g & 1) + i] = s.x[i];
-        }
-    }
-#undef L3_SLOT
-}
-
-// SiLU + split of all 64 pending values of a tile with nothing to hide behind (once per tile pair: tile A's first layer)
-__device__ __forceinline__ void l3_split_all(const f32x16 &v0, const f32x16 &v1, Limbs &o) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) silu_split8(g < 2 ? v0 : v1, g & 1, o.p1[g], o.p2[g], o.p3[g]);
-}
 
 __device__ __forceinline__ void l3_table_sum(const float *FA, const float *FB, const float *FC, int R, int ixl, int iy, int izc,
                                              int h, f32x16 &x0, f32x16 &x1) {
@@ -1187,83 +1056,6 @@ __global__ __launch_bounds__(NT) void density_grid_l3k_kernel(
         x1 = silu16_scalar(x1);
         const float d = last_dot(L, 0, h, x0, x1);
         if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void density_grid_l3p_kernel(
-    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
-    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
-    const int NH = hd.NH;  // >= 1 (the launcher sends NH == 0 to the plain kernel)
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
-        float *bacc = smem + NH * 4096;
-        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
-        float *wl = bacc + (NH + 1) * 64;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
-        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
-        __syncthreads();
-    }
-    const LdsView L = lds_view(smem, NH);
-    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = lane & 31, h = lane >> 5;
-    const int nzb = (R + 31) / 32;
-    const long ntiles = (long)nx * nzb * R;
-    const long nw_total = (long)gridDim.x * nwave;
-    long wid = (long)blockIdx.x * nwave + wave;
-    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
-    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
-    int iy = (int)(t_begin % R);
-    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
-    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
-    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
-
-    for (long t = t_begin; t < t_end; t += 2) {
-        // tile A = t, tile B = t + 1 (the next iy of the same (ix, z block) row, or a repeat of A at the end of the range)
-        const bool haveB = t + 1 < t_end;
-        const int iyA = iy, zbA = zb, ixA = ixl;
-        if (haveB && ++iy == R) {
-            iy = 0;
-            if (++zb == nzb) { zb = 0; ++ixl; }
-        }
-        const int iyB = iy, zbB = zb, ixB = ixl;
-        if (++iy == R) {
-            iy = 0;
-            if (++zb == nzb) { zb = 0; ++ixl; }
-        }
-        const int izA = zbA * 32 + p, izB = zbB * 32 + p;
-        f32x16 a0, a1, b0, b1;  // pending values (layer input before SiLU) / accumulators of tiles A and B
-        l3_table_sum(FA, FB, FC, R, ixA, iyA, min(izA, R - 1), h, a0, a1);
-        l3_table_sum(FA, FB, FC, R, ixB, iyB, min(izB, R - 1), h, b0, b1);
-        Limbs la, lb;
-        Frags f;
-        f.a10 = A[0];
-        f.c0 = A3[0]; f.c1 = A3[256];
-        l3_split_all(a0, a1, la);
-        for (int l = 0; l < NH; ++l) {
-            const tbf16x8 *Al = A + (long)l * 1024, *A3l = A3 + (long)l * 512;
-            const int ln = min(l + 1, NH - 1);  // the fetch behind the last phase is never used; keep it inside the arrays
-            a0 = lds_bias16(L.bacc, l + 1, h, 0);
-            a1 = lds_bias16(L.bacc, l + 1, h, 1);
-            // A's layer l on the matrix pipe, B's input of layer l through SiLU + split
-            l3_phase<true>(a0, a1, la, b0, b1, lb, f, Al, A3l, Al, A3l);
-            b0 = lds_bias16(L.bacc, l + 1, h, 0);
-            b1 = lds_bias16(L.bacc, l + 1, h, 1);
-            // B's layer l on the matrix pipe, A's output of layer l through SiLU (+ split unless it feeds the last layer)
-            if (l + 1 < NH) l3_phase<true>(b0, b1, lb, a0, a1, la, f, Al, A3l, A + (long)ln * 1024, A3 + (long)ln * 512);
-            else l3_phase<false>(b0, b1, lb, a0, a1, la, f, Al, A3l, A + (long)ln * 1024, A3 + (long)ln * 512);
-        }
-        b0 = silu16_scalar(b0);
-        b1 = silu16_scalar(b1);
-        const float dA = last_dot(L, 0, h, a0, a1);
-        const float dB = last_dot(L, 0, h, b0, b1);
-        if (h == 0 && izA < R) out[((long)ixA * R + iyA) * R + izA] = exp_f(dA + density_bias) + out_add;
-        if (h == 0 && izB < R && haveB) out[((long)ixB * R + iyB) * R + izB] = exp_f(dB + density_bias) + out_add;
     }
 }
 
@@ -1507,43 +1299,19 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
     const float *FB = FA + (size_t)nx * R * 64;
     const float *FC = FB + (size_t)nx * R * 64;
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
-    if (flags & SCULPT_DENSITY_BF16L3) {
-        // A/B knobs (read per call: a debugging aid, not an interface): workgroup size and the in-wave k-step pipeline
+    if ((flags & SCULPT_DENSITY_BF16L3) && n_hidden_64 >= 1) {  // without hidden layers there is nothing to split: fp32 kernel
+        // A/B knobs (read per call: a debugging aid, not an interface): workgroup size, and SCULPT_DENSITY_L3_KSTEP=0 selects
+        // the phase-separated kernel instead of the k-step pipeline
         const int l3_threads = getenv("SCULPT_DENSITY_L3_THREADS") ? atoi(getenv("SCULPT_DENSITY_L3_THREADS")) : 1024;
-        const bool pair = getenv("SCULPT_DENSITY_L3_PAIR") && atoi(getenv("SCULPT_DENSITY_L3_PAIR")) != 0;
-        if (pair && n_hidden_64 >= 1) {
-            const int ntp = l3_threads == 256 ? 256 : (l3_threads == 768 ? 768 : 512);
-            auto kp = ntp == 256 ? density_grid_l3p_kernel<256> : (ntp == 768 ? density_grid_l3p_kernel<768> : density_grid_l3p_kernel<512>);
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int nw = ntp / 64;
-            const int grid = (int)std::min<long>((ntiles + 2 * nw - 1) / (2 * nw), num_cus());
-            hipLaunchKernelGGL(kp, dim3(grid), dim3(ntp), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
-                               density_bias, out_add, out);
-            SC_LAUNCH_CHECK();
-            return 0;
-        }
-        const int kpipe = getenv("SCULPT_DENSITY_L3_KSTEP") ? atoi(getenv("SCULPT_DENSITY_L3_KSTEP")) : 0;
-        if (kpipe && n_hidden_64 >= 1) {
-            const int ntk = l3_threads == 512 ? 512 : (l3_threads == 768 ? 768 : 1024);
-            auto kk = ntk == 512 ? density_grid_l3k_kernel<512> : (ntk == 768 ? density_grid_l3k_kernel<768> : density_grid_l3k_kernel<1024>);
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int nw = ntk / 64;
-            const int grid = (int)std::min<long>((ntiles + nw - 1) / nw, num_cus());
-            hipLaunchKernelGGL(kk, dim3(grid), dim3(ntk), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
-                               density_bias, out_add, out);
-            SC_LAUNCH_CHECK();
-            return 0;
-        }
-        const bool pipe = !(getenv("SCULPT_DENSITY_L3_PIPE") && atoi(getenv("SCULPT_DENSITY_L3_PIPE")) == 0);
+        const bool kstep = !(getenv("SCULPT_DENSITY_L3_KSTEP") && atoi(getenv("SCULPT_DENSITY_L3_KSTEP")) == 0);
         const int nt = l3_threads == 768 ? 768 : (l3_threads == 512 ? 512 : 1024);
-        auto kern = nt == 1024 ? (pipe ? density_grid_l3_kernel<1024, 1> : density_grid_l3_kernel<1024, 0>)
-                  : nt == 768  ? (pipe ? density_grid_l3_kernel<768, 1> : density_grid_l3_kernel<768, 0>)
-                               : (pipe ? density_grid_l3_kernel<512, 1> : density_grid_l3_kernel<512, 0>);
+        auto kern = kstep ? (nt == 1024 ? density_grid_l3k_kernel<1024> : nt == 768 ? density_grid_l3k_kernel<768> : density_grid_l3k_kernel<512>)
+                          : (nt == 1024 ? density_grid_l3_kernel<1024> : nt == 768 ? density_grid_l3_kernel<768> : density_grid_l3_kernel<512>);
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nwave = nt / 64;
         const int grid = (int)std::min<long>((ntiles + nwave - 1) / nwave, num_cus());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
-                           density_bias, out_add, out, getenv("SCULPT_DENSITY_L3_SCHED") ? atoi(getenv("SCULPT_DENSITY_L3_SCHED")) : 0);
+                           density_bias, out_add, out);
         SC_LAUNCH_CHECK();
         return 0;
     }

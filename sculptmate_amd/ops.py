@@ -145,8 +145,9 @@ def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begi
     """density_act (+ out_add) over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]
     (TSR.extract_mesh's dense query, system.py:171-183; out_add=-threshold folds system.py:184).
     events: optional (start, stop) torch.cuda.Event pair recorded around the fused MLP launch only.
-    precision: "fp32" (exact fp32 MFMA, default), "bf16x3" or "fp16x3" (split-operand 16-bit MFMA: operands
-    represented to ~2^-17 / ~2^-22)."""
+    precision: "fp32" (exact fp32 MFMA; this function's default), "bf16l3" (three exact bf16 limbs per operand, six products,
+    fp32 accumulate: fp32-equivalent, what TSR.extract_meshes uses), or the two-limb experiments "bf16x3" / "fp16x3"
+    (operands represented to ~2^-17 / ~2^-22)."""
     if precision not in _DENSITY_FLAGS:
         raise SculptError("density_grid: precision must be one of %s" % sorted(_DENSITY_FLAGS))
     planes = _req(planes, torch.float32, "planes")

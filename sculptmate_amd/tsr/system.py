@@ -180,17 +180,20 @@ def _f32(x, dev):
 
 
 class TSR(KernelEngine):
-    def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16", decoder_precision="fp32"):
+    def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16", decoder_precision="bf16l3"):
         """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times) or
         "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference).
-        decoder_precision: "fp32" (default: the dense density query on exact-fp32 MFMA), or an optional fast mode with
-        the hidden layers on split-operand 16-bit MFMA: "fp16x3" (operands to ~2^-22: same measured error vs the CPU
-        oracle as the fp32 kernel, 2.2x faster; needs |hidden activation|, |weight| < 65504) or "bf16x3" (~2^-17:
-        3e-4 relative density error, 2.4x faster)."""
+        decoder_precision: how the 64x64 hidden layers of the dense density query (extract_mesh's 256^3 grid) are evaluated.
+          "bf16l3" (default): fp32-equivalent -- both operands split EXACTLY into three bf16 limbs (24 significant bits, fp32
+                   exponent range), six exact products per weight on the bf16 matrix pipe, fp32 accumulation; no range
+                   limit and no fallback; measured error against the CPU oracle = the fp32 kernel's own.
+          "fp32":  the exact-fp32 MFMA kernel (a k-ordered fmaf chain, 1.5x slower): the parity mode.
+          "fp16x3" / "bf16x3": two-limb experiments with 22 / 16-bit operands (fp16x3 needs |activation| < 65504 and falls
+                   back to fp32 when the volume comes out non-finite); kept for A/B only, never the default."""
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
-        if decoder_precision not in ("fp32", "bf16x3", "fp16x3"):
-            raise ValueError("decoder_precision must be 'fp32', 'fp16x3' or 'bf16x3'")
+        if decoder_precision not in ("fp32", "bf16l3", "bf16x3", "fp16x3"):
+            raise ValueError("decoder_precision must be 'bf16l3', 'fp32', 'fp16x3' or 'bf16x3'")
         self.decoder_precision = decoder_precision
         self.cfg = cfg or DEFAULT_CFG
         self.pos_embed_mode = pos_embed_mode
@@ -527,9 +530,9 @@ class TSR(KernelEngine):
                 v_pos, t_pos_idx = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
                                                       vert_mul=r - (-r), vert_add=-r)
             except _lib.SculptError as e:
-                if e.code != _lib.ERR_MC_NAN or self.decoder_precision == "fp32":
-                    raise
-                # a 16-bit split mode left its range (|hidden activation| >= 65504): redo this grid in exact fp32
+                if e.code != _lib.ERR_MC_NAN or self.decoder_precision != "fp16x3":
+                    raise  # fp32 and the bf16 limb modes have the fp32 range: a NaN there is a NaN of the model
+                # the fp16 split left its range (|hidden activation| >= 65504): redo this grid in exact fp32
                 vol = ops.density_grid(planes, self.decoder, R, radius=r, density_bias=self.renderer.cfg.density_bias,
                                        out_add=-threshold, out=vol)
                 v_pos, t_pos_idx = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
@@ -551,7 +554,8 @@ class TSR(KernelEngine):
 
         r = self.renderer.cfg.radius
         planes = scene_code.contiguous()
-        kw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, threshold=threshold)
+        kw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, threshold=threshold,
+                  precision="fp32" if self.decoder_precision == "fp16x3" else self.decoder_precision)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             part = slab.extract_slab(planes, self.decoder, resolution, dist.get_rank(), dist.get_world_size(), **kw)
             v_pos, t_pos_idx = slab.gather_and_assemble(part, planes.device)

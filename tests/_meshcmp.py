@@ -32,3 +32,16 @@ def assert_mesh_close(v, f, rv, rf, tol, count_slack=None):
     assert max(far) <= count_slack, "topology differs; %s vertices have no counterpart within %.3e (slack %d)" % (far, tol, count_slack)
     inl = np.concatenate([d_ab[d_ab < tol], d_ba[d_ba < tol]])
     return {"same_topology": False, "max_dist": float(inl.max()), "unmatched": far}
+
+
+def mesh_distance(v, rv, extent=1.74):
+    """Two-sided nearest-vertex distance between two meshes, as fractions of `extent` (the scene box edge): what the
+    bf16-transformer mode is quoted with against the fp32 CPU mesh."""
+    from scipy.spatial import cKDTree
+
+    v, rv = np.asarray(v, np.float64), np.asarray(rv, np.float64)
+    d_ab, _ = cKDTree(rv).query(v)
+    d_ba, _ = cKDTree(v).query(rv)
+    d = np.concatenate([d_ab, d_ba]) / extent
+    return {"max": float(d.max()), "p999": float(np.quantile(d, 0.999)), "p99": float(np.quantile(d, 0.99)), "mean": float(d.mean()),
+            "vertices": [int(len(v)), int(len(rv))]}

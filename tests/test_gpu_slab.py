@@ -46,7 +46,7 @@ def test_density_and_mc_in_slabs_equal_single_pass(cuda):
     mlp = ops.PackedMLP(Ws, bs, cuda)
     planes = torch.from_numpy(synth.smooth_triplane(seed=52, scale=3.0)).to(cuda)
     thr = float(ops.density_grid(planes, mlp, R).median())
-    vol = ops.density_grid(planes, mlp, R, out_add=-thr).view(R, R, R)
+    vol = ops.density_grid(planes, mlp, R, out_add=-thr, precision="bf16l3").view(R, R, R)
     fv, ff = ops.marching_cubes(vol, 0.0, reference_order=True, vert_div=R - 1.0, vert_mul=1.74, vert_add=-0.87)
     for world in (2, 8):
         v, f = slab.extract_mesh_slabs_local(planes, mlp, R, world, threshold=thr)
@@ -88,7 +88,7 @@ def test_config5_at_512_cubed_slabs_equal_single_pass_and_oracle(cuda):
     del v, f
     # rank 3's slab as a stand-alone volume against the oracle (vertices in index units, skimage's face order)
     c0, c1 = slab.slab_ranges(R, world)[3]
-    vol = ops.density_grid(planes, mlp, R, x_begin=c0, x_end=c1 + 1, out_add=-thr).view(c1 - c0 + 1, R, R)
+    vol = ops.density_grid(planes, mlp, R, x_begin=c0, x_end=c1 + 1, out_add=-thr, precision="bf16l3").view(c1 - c0 + 1, R, R)
     sv, sf = ops.marching_cubes(vol, 0.0, reference_order=True, vert_div=1.0)
     rv, rf = capi.marching_cubes(vol.cpu().numpy(), 0.0)
     assert np.array_equal(sf.cpu().numpy(), rf[:, [1, 0, 2]].astype(np.int64))

@@ -335,7 +335,7 @@ def test_end_to_end_run_returns_meshes(cuda):
     img = synth.composite_rgb(synth.image_rgba(seed=42, size=S))
     codes = m([img], device=cuda)
     R = 48
-    dens = ops.density_grid(codes[0].contiguous(), m.decoder, R)
+    dens = ops.density_grid(codes[0].contiguous(), m.decoder, R, precision=m.decoder_precision)  # the mode m.run uses
     # random weights never reach the threshold 25: use the median density as the iso level
     thr = float(dens.median())
     meshes = m.run([img], mc_resolution=R, threshold=thr, enable_texture=True)
@@ -477,6 +477,10 @@ def test_forward_accepts_large_uint8_images(cuda):
     assert _rel(codes[0], ref)[0] < 1e-2
 
 
+# bounds of the bf16-mode mesh against the fp32 CPU mesh at 128^3, fractions of the scene extent (see the test below)
+BF16_MESH_MEAN, BF16_MESH_P99, BF16_MESH_P999, BF16_MESH_MAX = 4e-4, 2e-3, 5e-2, 1e-1
+
+
 def test_full_size_tsr_forward_vs_oracle(cuda):
     """BASELINE config 2 size: the real architecture (ViT-B/16 @ 1025 tokens, 16 blocks @ 3072 tokens,
     419 M parameters, seeded random init) through the HIP kernels vs the torch-fp32 oracle on the host."""
@@ -529,6 +533,19 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     v, f = mesh.vertices.cpu().numpy(), mesh.faces.cpu().numpy()
     info = assert_mesh_close(v, f, rv, rf, tol=1e-4 * 1.74)  # unconditional: same topology or not
     print("image -> mesh at %d^3: %d vertices, %d faces, %s" % (R, len(v), len(f), info))
+    # The DEFAULT mode (bf16 transformer, what bench.py times) against the same fp32 CPU mesh: the scene code is 0.8 % away
+    # (bf16 weights and activations through 28 layers), so the iso-surface moves; how far is stated here and in bench.py's
+    # `parity.bf16_mesh_vs_fp32_cpu` as two-sided nearest-vertex distances over the 1.74 extent.  Measured on MI355X
+    # (random-init weights, iso level = the 97 % quantile): mean 1.5e-4, p99 7.9e-4, p99.9 2.2e-2, max 3.9e-2 -- 99 % of the
+    # vertices sit within a tenth of a 128^3 voxel (7.9e-3 of the extent) of the fp32 mesh; the tail is small closed components
+    # of this rough random field that exist on one side only (a few voxels away from anything).  Bounds = those with ~2.5x margin.
+    # The 1e-4 vertex tolerance of north_star holds in fp32 mode (above) or given the same scene code -- not in this mode.
+    from _meshcmp import mesh_distance
+
+    mesh_bf = m32.extract_meshes(codes, resolution=R, threshold=thr)[0]
+    dist = mesh_distance(mesh_bf.vertices.cpu().numpy(), rv)
+    print("bf16-mode mesh vs fp32 CPU mesh at %d^3 (fractions of the 1.74 extent): %s" % (R, dist))
+    assert dist["mean"] < BF16_MESH_MEAN and dist["p99"] < BF16_MESH_P99 and dist["p999"] < BF16_MESH_P999 and dist["max"] < BF16_MESH_MAX, dist
 
 
 def test_gemm_f32_and_softmax(cuda):

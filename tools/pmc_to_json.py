@@ -1,17 +1,26 @@
-"""profiles/pmc_density_grid.json from the --pmc passes of tools/profile_bench.sh: HBM-side bytes of ONE full 256^3
-density_grid_kernel launch (median over the full-size launches; the 64^3 calibration probe is excluded by size)."""
+"""profiles/pmc_density_grid.json from the --pmc passes of tools/profile_bench.sh: HBM-side bytes of ONE full 256^3 launch of
+the dominant dense-density kernel of the bench (the default mode's density_grid_l3k_kernel, or density_grid_kernel with
+--decoder-precision fp32): median over the full-size launches of the kernel with the most of them."""
 import csv, glob, json, os, sys
 
 out = sys.argv[1]
 dst = sys.argv[2]
 
 
+import collections
+
+NAME = {}
+
+
 def per_launch(sub, counter):
-    vals = []
+    byk = collections.defaultdict(list)
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "density_grid_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                vals.append(float(r["Counter_Value"]))
+            if "density_grid_" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                byk[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    name = max(byk, key=lambda k: len(byk[k]))
+    NAME["kernel"] = name
+    vals = byk[name]
     big = [v for v in vals if v > 0.5 * max(vals)]
     big.sort()
     return big[len(big) // 2], len(big)
@@ -22,14 +31,15 @@ write_kb, nw = per_launch("pmc_write", "WRITE_SIZE")
 R = 256
 alg = R ** 3 * 4 + 3 * R * R * 64 * 4 + 3 * 40 * 64 * 64 * 4 // 1  # density out + FA/FB/FC tables read once (+ planes upstream)
 res = {
-    "kernel": "sculpt::density_grid_kernel (256^3 launch)",
+    "kernel": NAME["kernel"].split("(")[0] + " (256^3 launch)",
+    "mode": "bf16l3" if "l3" in NAME["kernel"] else "fp32",
     "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb, "full_size_launches": [nf, nw],
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",
     "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
     "algorithmic_bytes_per_launch": int(R ** 3 * 4 + 3 * R * R * 64 * 4),
     "note": "L2-miss traffic: the (iy, iz) table FC (16.8 MB) is streamed by every one of the 8 XCDs, FA/FB bands once, the 128 KiB "
-            "weight blob once per workgroup (33 MB); served largely by the 256 MB Infinity Cache, ~30 GB/s of HBM bandwidth",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-optional-modes --no-extras`, tools/profile_bench.sh, round 2",
+            "W1|W2 blob once per workgroup (33 MB) and the 64 KiB of third limbs through L2; served largely by the 256 MB Infinity Cache",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-optional-modes --no-extras`, tools/profile_bench.sh, round 3",
 }
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res))
