@@ -67,25 +67,9 @@ def build_model(device, seed):
 
 def calibrate(model, sd, img_dev, inside=0.015):
     """Shift decoder.layers.18.bias[0] so that `inside` of the voxels exceed the threshold."""
-    from sculptmate_amd import ops, synth
+    from sculptmate_amd import synth
 
-    ctx, _ = model.image_tokens(img_dev)
-    _, outb = model.backbone_tokens(ctx)
-    planes = model.scene_code(outb)
-    # 64^3 lattice probe through the point-query kernel (query_triplane's path): keeps the rocprof row of the dense-grid kernel
-    # to full-size launches only
-    g = ops.grid_axis_coords(64, model.renderer.cfg.radius).to(planes.device)
-    pts = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
-    probe = ops.triplane_query(planes, model.decoder, pts, radius=model.renderer.cfg.radius,
-                               density_bias=model.renderer.cfg.density_bias, want=("density",))["density"].reshape(-1)
-    pre = probe.cpu().numpy().astype(np.float64)                    # density before the -1 bias
-    shift = synth.calibrate_density_bias(pre, inside_fraction=inside, threshold=THRESHOLD)
-    k = "decoder.layers.18.bias"
-    b = sd[k].copy()
-    b[0] += np.float32(shift)
-    sd[k] = b
-    model.load_state_dict(sd)
-    return shift
+    return synth.calibrate_tsr_density_bias(model, sd, img_dev, inside, THRESHOLD)
 
 
 DECODER_PRECISION = "bf16l3"  # TSR's default; --decoder-precision fp32 times the exact-fp32 kernel instead
@@ -413,6 +397,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional-modes", action="store_true",
                     help="skip the informational split-operand rates (profiling runs: keeps the kernel rows to the default path)")
+    ap.add_argument("--no-siblings", action="store_true",
+                    help="skip the exact-fp32 kernel's sibling measurement and the kernel-parity pass (profiling runs)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys measured after the timed region (boundary, slab512, sf3d)")
     ap.add_argument("--decoder-precision", choices=("bf16l3", "fp32", "fp16x3", "bf16x3"), default="bf16l3",
@@ -439,8 +425,10 @@ def main():
         raise SystemExit("rank %d has no GPU of its own (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    from sculptmate_amd import parallel, synth
+    from sculptmate_amd import batch, parallel, synth
 
+    if world > 1:
+        batch.cap_host_threads(world)  # N ranks synthesise 1.7 GB of weights on one host at once
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"  # keep stdout to the one JSON line (RCCL prints its banner there)
 
@@ -529,7 +517,7 @@ def main():
             out["transformer_roofline"] = {"bound": "mfma", "achieved": 2.96 / (out["transformer_ms"] * 1e-3), "peak": PEAK_BF16_MFMA_TFLOPS,
                                            "unit": "TFLOP/s", "frac": 2.96 / (out["transformer_ms"] * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
             single = args.gpus == 1 and DECODER_PRECISION == "bf16l3"
-            if single:
+            if single and not args.no_siblings:
                 out["fp32_exact"] = fp32_exact_sibling(model, imgs, args.steps)
                 out["parity"] = {"kernel_vs_fp32_kernel": kernel_parity(model, imgs[0])}
             if single and not args.no_extras:

@@ -243,12 +243,16 @@ int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, 
  *   Vt [heads*64][ldvt] bf16 = V transposed (row = h*64 + d, column = key); ldvt >= round_up(Tk, 64)
  *   and the columns >= Tk must hold finite values (they are multiplied by exact zeros);
  *   O [Tq][ldo] bf16.  Head dim is 64.
- *   scale == 0: Q already carries softmax_scale * log2(e) (folded into the query projection before its bf16 rounding),
- *   i.e. O = softmax_2(Q K^T) V with 2^x in place of e^x: the kernel then subtracts the running maximum inside the matrix
- *   product and skips one VALU multiply-add per score (1.1-1.2x faster). */
+ *   scale must be positive.  Row extents must stay below 2 GiB (round_up(Tk,128) * ldk * 2 B and 64 * ldvt * 2 B): the K / V
+ *   tiles are fetched with 32-bit buffer offsets. */
 int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
                           int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, float scale,
                           sculpt_stream_t stream);
+/* The same with queries that ALREADY carry softmax_scale * log2(e) (folded into the query projection before its bf16
+ * rounding): O = softmax_2(Q K^T) V with 2^x in place of e^x; the kernel subtracts the running maximum inside the matrix
+ * product and skips one VALU multiply-add per score (1.1-1.2x faster).  What the bf16 transformers use. */
+int sculpt_attention_bf16_prescaled(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
+                                    int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, sculpt_stream_t stream);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (rows x cols), x fp32 or bf16, y bf16 */
 int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const float *gamma,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_attention_bf16_prescaled": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "sculpt_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp]),
     "sculpt_groupnorm_tokens": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sculpt_transpose_add": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

@@ -1,0 +1,175 @@
+"""A batch of images over the GPUs of one node: one process per GPU, image i -> rank i mod world, no data-path collective.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m sculptmate_amd.batch \
+        --images DIR_OR_FILES... --checkpoint CKPT_DIR --out OUT_DIR [--resolution 256] [--threshold 25] [--format obj|ply]
+    python -m sculptmate_amd.batch --synthetic 16 --out OUT_DIR          (random-init weights, synthetic images: smoke runs)
+
+The reference generates one mesh per call (TripoSR/generate.py:32-43 wraps ONE image; the add-on loops); BASELINE.json's
+north_star splits a batch one image per GPU.  `run_sharded` is that split as a library call: every rank holds a full weight
+replica, takes `parallel.shard_indices(n, rank, world)`, runs TSR.run_async on its images (the device -> host copy of mesh i
+under the kernels of image i + 1), keeps / writes its own meshes, and the ranks exchange only the (index, vertices, faces)
+counts -- `torch.distributed` (backend "nccl" = RCCL, "gloo" in CPU tests) is not on the data path.
+"""
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+
+from . import parallel
+
+
+def run_sharded(model, images, mc_resolution=256, threshold=25.0, enable_texture=False, out_dir=None, names=None, fmt="obj",
+                keep=True):
+    """images: the WHOLE batch, identical on every rank (a list of host arrays / PIL images, or callables returning one, so
+    that a rank only loads the files it owns).  Returns (local, summary):
+      local   {index: Mesh} of the images this rank owns (empty dict with keep=False: meshes are only written);
+      summary [(index, rank, n_vertices, n_faces)] for ALL images, sorted by index, the same list on every rank.
+    Each image is processed by exactly one rank; meshes are bit-identical to a single-process TSR.run of the same image."""
+    import torch.distributed as dist
+
+    have_dist = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if have_dist else 0
+    world = dist.get_world_size() if have_dist else 1
+    n = len(images)
+    mine = parallel.shard_indices(n, rank, world)
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+    local, counts = {}, []
+
+    def finish(i, pending):
+        m = pending.result()
+        counts.append((i, int(m.vertices.shape[0]), int(m.faces.shape[0])))
+        if out_dir is not None:
+            name = names[i] if names is not None else "mesh_%05d" % i
+            _write(os.path.join(out_dir, "%s.%s" % (name, fmt)), m, fmt)
+        if keep:
+            local[i] = m
+
+    prev = None
+    for i in mine:
+        im = images[i]() if callable(images[i]) else images[i]
+        cur = (i, model.run_async(im, mc_resolution, threshold, enable_texture))
+        if prev is not None:
+            finish(*prev)  # mesh i - 1 is collected while image i runs
+        prev = cur
+    if prev is not None:
+        finish(*prev)
+    # the only exchange: per-rank (index, n_vertices, n_faces), padded to the largest shard
+    per = (n + world - 1) // world if n else 0
+    flat = []
+    for k in range(per):
+        flat.extend(counts[k] if k < len(counts) else (-1, 0, 0))
+    device = "cpu"
+    if have_dist and dist.get_backend() == "nccl":
+        device = model.device
+    gathered = parallel.gather_counts(flat, device) if per else [[] for _ in range(world)]
+    summary = []
+    for r, row in enumerate(gathered):
+        for k in range(0, len(row), 3):
+            if row[k] >= 0:
+                summary.append((int(row[k]), r, int(row[k + 1]), int(row[k + 2])))
+    summary.sort()
+    assert [s[0] for s in summary] == list(range(n)), "run_sharded: an image was processed twice or not at all"
+    return local, summary
+
+
+def _write(path, mesh, fmt):
+    from . import meshio
+
+    if fmt == "ply":
+        meshio.write_ply(path, mesh.vertices, mesh.faces, mesh.vertex_colors)
+    elif fmt == "obj":
+        meshio.write_obj(path, mesh.vertices, mesh.faces, mesh.vertex_colors)
+    else:
+        raise ValueError("format must be 'obj' or 'ply'")
+
+
+def cap_host_threads(world):
+    """N ranks on one host must not each run torch's CPU work (weight conversion / synthesis at start-up) on every core."""
+    import torch
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, cores // max(world, 1)))
+
+
+def _load_image(path):
+    """File -> float32 HWC RGB in [0,1], RGBA composited on grey like the add-on's preprocessing (preprocessing.py:122)."""
+    from PIL import Image
+
+    a = np.asarray(Image.open(path)).astype(np.float32) / 255.0
+    if a.ndim == 2:
+        a = np.stack([a] * 3, -1)
+    if a.shape[-1] == 4:
+        a = a[..., :3] * a[..., 3:4] + (1.0 - a[..., 3:4]) * 0.5
+    return np.ascontiguousarray(a[..., :3])
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--images", nargs="*", default=[], help="image files, directories or glob patterns")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic 512x512 images and random-init weights instead")
+    ap.add_argument("--checkpoint", default=None, help="directory with model.ckpt + config.yaml (TSR.from_pretrained)")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--resolution", type=int, default=256)
+    ap.add_argument("--threshold", type=float, default=25.0)
+    ap.add_argument("--format", choices=("obj", "ply"), default="obj")
+    ap.add_argument("--texture", action="store_true", help="vertex colours (TSR.extract_mesh's enable_texture)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
+    args = ap.parse_args(argv)
+
+    import torch
+
+    rank, local_rank, world = parallel.env_rank_world()
+    cap_host_threads(world)
+    if not torch.cuda.is_available():
+        raise SystemExit("sculptmate_amd.batch needs MI355X GPUs: there is no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU of its own (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = parallel.init(args.backend or "nccl", device) if world > 1 else None
+
+    from . import synth
+    from .tsr import TSR
+
+    if args.synthetic:
+        model = TSR(pos_embed_mode="scale_factor")
+        sd_syn = synth.tsr_state(seed=0)
+        model.load_state_dict(sd_syn)
+        images = [(lambda i=i: synth.composite_rgb(synth.image_rgba(seed=100 + i))) for i in range(args.synthetic)]
+        names = ["synthetic_%05d" % i for i in range(args.synthetic)]
+    else:
+        if not args.checkpoint:
+            raise SystemExit("--checkpoint DIR (model.ckpt + config.yaml) or --synthetic N")
+        model = TSR.from_pretrained(args.checkpoint, "config.yaml", "model.ckpt")
+        files = []
+        for spec in args.images:
+            if os.path.isdir(spec):
+                files += sorted(os.path.join(spec, f) for f in os.listdir(spec) if f.lower().endswith((".png", ".jpg", ".jpeg", ".webp")))
+            else:
+                files += sorted(glob.glob(spec)) or [spec]
+        if not files:
+            raise SystemExit("no input images")
+        images = [(lambda p=p: _load_image(p)) for p in files]
+        names = [os.path.splitext(os.path.basename(p))[0] for p in files]
+    model.to(device)
+    with torch.no_grad():
+        if args.synthetic:  # random weights never reach the threshold: calibrate the density bias on image 0 (every rank alike)
+            synth.calibrate_tsr_density_bias(model, sd_syn, torch.from_numpy(images[0]()).to(device), threshold=args.threshold)
+        try:
+            _, summary = run_sharded(model, images, args.resolution, args.threshold, args.texture, args.out, names, args.format, keep=False)
+        finally:
+            if dist is not None:
+                dist.barrier()
+    if rank == 0:
+        for i, r, nv, nf in summary:
+            print("%s  rank %d  %d vertices  %d faces" % (names[i], r, nv, nf))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -339,13 +339,19 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
 
 using namespace sculpt;
 
-extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
-                                     int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, float scale,
-                                     sculpt_stream_t stream) {
+static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt, int ldvt, uint16_t *O,
+                            int ldo, int Tq, int Tk, int heads, float scale, bool prescaled, sculpt_stream_t stream) {
     SC_REQUIRE(Q && K && Vt && O, "attention: null argument");
     SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
     SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
+    // K / V tiles are staged with buffer addressing: 32-bit per-lane byte offsets from the head's base.  Past 2 GiB an offset
+    // wraps or leaves the descriptor's range, and an out-of-range buffer load returns zeros silently -- refuse such shapes.
+    {
+        const long tk128 = (long)((Tk + 127) / 128) * 128;
+        SC_REQUIRE(tk128 * ldk * 2 < 0x7fffffffL, "attention: K extent %ld x %d x 2 B is beyond the 2 GiB buffer range", tk128, ldk);
+        SC_REQUIRE((long)64 * ldvt * 2 + tk128 * 2 < 0x7fffffffL, "attention: V^T extent 64 x %d x 2 B is beyond the 2 GiB buffer range", ldvt);
+    }
     // Queries per workgroup: 128, 192 or 256 (8 / 12 / 16 waves, 2 - 4 per SIMD).  A workgroup's time grows with its query
     // count, a launch lasts ceil(workgroups / CUs) rounds (the 16-wave form fits one per CU; smaller ones are counted the same
     // way: a second resident workgroup shares the CU's matrix pipe).  3072 queries x 16 heads: 192 workgroups of 256 (3/4 of
@@ -366,7 +372,7 @@ extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t 
     const dim3 grid(cdiv(Tq, 32 * nqb), heads), block(128 * nqb);
 #define SCULPT_ATTN_LAUNCH(NQB, PRE, SC) \
     hipLaunchKernelGGL((attention_kernel<NQB, PRE>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, SC)
-    if (scale == 0.f) {  // Q carries scale * log2(e) already
+    if (prescaled) {  // Q carries scale * log2(e) already
         if (nqb == 8) SCULPT_ATTN_LAUNCH(8, true, 1.0f);
         else if (nqb == 6) SCULPT_ATTN_LAUNCH(6, true, 1.0f);
         else SCULPT_ATTN_LAUNCH(4, true, 1.0f);
@@ -378,4 +384,17 @@ extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t 
 #undef SCULPT_ATTN_LAUNCH
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
+                                     int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, float scale,
+                                     sculpt_stream_t stream) {
+    SC_REQUIRE(scale > 0.f && scale == scale, "attention: scale must be positive (pre-scaled queries: sculpt_attention_bf16_prescaled)");
+    return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, heads, scale, false, stream);
+}
+
+extern "C" int sculpt_attention_bf16_prescaled(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
+                                               int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads,
+                                               sculpt_stream_t stream) {
+    return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, heads, 1.0f, true, stream);
 }

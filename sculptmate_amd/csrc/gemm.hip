@@ -24,6 +24,8 @@
 // only 192 tiles for 256 CUs).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace sculpt {
@@ -502,8 +504,10 @@ static const uint16_t *zero_page() {
     // 256 KiB of zeros per device: the out-of-image taps of the implicit convolution and the stand-in for a missing per-column
     // vector (allocated once, never freed)
     static const uint16_t *pages[64] = {nullptr};
+    static std::mutex mu;  // first use from several host threads at once
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!pages[dev]) {
         void *p = nullptr;
         if (hipMalloc(&p, ZERO_FLOATS * 4) != hipSuccess || hipMemset(p, 0, ZERO_FLOATS * 4) != hipSuccess) return nullptr;
@@ -568,6 +572,9 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     if (n_store <= 0 || n_store > N) n_store = N;
     SC_REQUIRE(n_store % 4 == 0, "gemm_bf16: n_store=%d must be a multiple of 4", n_store);
     SC_REQUIRE(n_store == N || (epilogue != SCULPT_EPI_GEGLU && !out_bf16_t), "gemm_bf16: n_store is for plain outputs only");
+    // the epilogue fetches the residual of every column sub-tile before it knows which ones are stored: with a narrower
+    // output slice that would read past the residual's last row
+    SC_REQUIRE(!residual || n_store == N, "gemm_bf16: a residual needs n_store == N");
     GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
                w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
     SC_REQUIRE(w_rows <= ZERO_FLOATS, "gemm_bf16: N=%d too large", N);

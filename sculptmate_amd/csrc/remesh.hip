@@ -1,6 +1,8 @@
 // C ABI of the host-side mesh operations (csrc/remesh_host.h): sculpt_mesh_subdivide / _decimate / _remesh_botsch.
 // HOST pointers in, an opaque result object out (the output size is not known beforehand).  No GPU work here: the reference
 // runs this step on the CPU through gpytoolbox (StableFast/sf3d/models/mesh.py:175-237); see remesh_host.h for the algorithms.
+#include <exception>
+#include <memory>
 #include <new>
 
 #include "common.h"
@@ -12,6 +14,13 @@ struct sculpt_host_mesh {
 };
 
 using namespace sculpt;
+
+// No C++ exception may cross the C ABI (it would terminate the host process -- Blender): out of memory, std::length_error from
+// a vector that cannot grow, std::system_error from a thread that cannot be created, ... all become status codes.
+#define SCULPT_MESH_CATCH(who)                                                     \
+    catch (const std::bad_alloc &) { SC_REQUIRE(false, who ": out of memory"); }    \
+    catch (const std::exception &e) { SC_REQUIRE(false, who ": %s", e.what()); }    \
+    catch (...) { SC_REQUIRE(false, who ": unknown C++ exception"); }
 
 namespace {
 int check_in(const double *V, size_t nv, const int32_t *F, size_t nf, sculpt_host_mesh_t **out, const char *who) {
@@ -32,14 +41,13 @@ extern "C" int sculpt_mesh_subdivide(const double *V, size_t nv, const int32_t *
     for (int i = 0; i < iters; ++i) faces *= 4;
     SC_REQUIRE(faces < 1.5e9, "mesh_subdivide: %zu faces x 4^%d does not fit int32 indices", nf, iters);
     try {
-        sculpt_host_mesh *m = new sculpt_host_mesh;
+        std::unique_ptr<sculpt_host_mesh> m(new sculpt_host_mesh);
         m->V.assign(V, V + 3 * nv);
         m->F.assign(F, F + 3 * nf);
         for (int i = 0; i < iters; ++i) remesh::subdivide_once(m->V, m->F);
-        *out = m;
-    } catch (const std::bad_alloc &) {
-        SC_REQUIRE(false, "mesh_subdivide: out of memory");
+        *out = m.release();
     }
+    SCULPT_MESH_CATCH("mesh_subdivide")
     return 0;
 }
 
@@ -51,12 +59,11 @@ extern "C" int sculpt_mesh_decimate(const double *V, size_t nv, const int32_t *F
         const std::string err = M.build(V, nv, F, nf);
         SC_REQUIRE(err.empty(), "mesh_decimate: %s", err.c_str());
         remesh::decimate(M, target_faces);
-        sculpt_host_mesh *m = new sculpt_host_mesh;
+        std::unique_ptr<sculpt_host_mesh> m(new sculpt_host_mesh);
         M.compact(m->V, m->F);
-        *out = m;
-    } catch (const std::bad_alloc &) {
-        SC_REQUIRE(false, "mesh_decimate: out of memory");
+        *out = m.release();
     }
+    SCULPT_MESH_CATCH("mesh_decimate")
     return 0;
 }
 
@@ -70,12 +77,11 @@ extern "C" int sculpt_mesh_remesh_botsch(const double *V, size_t nv, const int32
         const std::string err = M.build(V, nv, F, nf);
         SC_REQUIRE(err.empty(), "mesh_remesh_botsch: %s", err.c_str());
         remesh::remesh_botsch(M, iters, h, project != 0);
-        sculpt_host_mesh *m = new sculpt_host_mesh;
+        std::unique_ptr<sculpt_host_mesh> m(new sculpt_host_mesh);
         M.compact(m->V, m->F);
-        *out = m;
-    } catch (const std::bad_alloc &) {
-        SC_REQUIRE(false, "mesh_remesh_botsch: out of memory");
+        *out = m.release();
     }
+    SCULPT_MESH_CATCH("mesh_remesh_botsch")
     return 0;
 }
 

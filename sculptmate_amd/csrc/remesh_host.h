@@ -663,13 +663,29 @@ static inline void parallel_ranges(size_t n, Fn fn) {
         fn((size_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
+    // A worker must not let an exception escape (std::terminate), and a thread that cannot be created (process thread limit)
+    // must not lose its range: failures are collected and the ranges that did not run are done on the calling thread.
     const size_t chunk = (n + nt - 1) / nt;
+    std::vector<std::thread> th;
+    std::vector<char> failed(nt, 0);
+    size_t started = 0;
     for (size_t t = 0; t < nt; ++t) {
         const size_t a = t * chunk, b = std::min(n, a + chunk);
-        if (a < b) th.emplace_back([=]() { fn(a, b); });
+        if (a >= b) { started = t + 1; continue; }
+        try {
+            th.emplace_back([=, &failed]() {
+                try { fn(a, b); } catch (...) { failed[t] = 1; }
+            });
+            started = t + 1;
+        } catch (...) {  // std::system_error: no more threads
+            break;
+        }
     }
     for (auto &x : th) x.join();
+    for (size_t t = 0; t < nt; ++t) {
+        const size_t a = t * chunk, b = std::min(n, a + chunk);
+        if (a < b && (t >= started || failed[t])) fn(a, b);  // serial fallback (rethrows on this thread if it fails again)
+    }
 }
 
 static inline void tangential_relaxation(Mesh &M, const SurfaceGrid *surface) {
@@ -706,6 +722,21 @@ static inline void tangential_relaxation(Mesh &M, const SurfaceGrid *surface) {
         Q[u] = surface ? surface->closest(p) : p;
     }
     });
+    // Second pass: the fold-over test above saw the OLD neighbours and the position BEFORE the projection; with every vertex
+    // moving at once (Jacobi) and then being pulled onto the surface a face can still turn over.  Moves that flip a face of
+    // their 1-ring against the old orientation are taken back, most displaced first would be finer -- taking back every
+    // vertex of an inverted face is enough and order-independent.
+    std::vector<char> undo(nv, 0);
+    bool any = false;
+    for (size_t f = 0; f < M.F.size(); ++f)
+        if (M.falive[f]) {
+            const V3 a = Q[M.F[f][0]], b = Q[M.F[f][1]], c = Q[M.F[f][2]];
+            if (dot(M.face_normal_raw((int)f), cross(b - a, c - a)) <= 0)
+                for (int k = 0; k < 3; ++k) { undo[M.F[f][k]] = 1; any = true; }
+        }
+    if (any)
+        for (size_t u = 0; u < nv; ++u)
+            if (undo[u]) Q[u] = M.P[u];
     M.P.swap(Q);
 }
 

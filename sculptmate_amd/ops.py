@@ -289,9 +289,14 @@ def row_slice_stats(x, stats, x_bf16=None, rows=None):
 
 
 def attention(Q, K, Vt, O, Tq, Tk, heads, scale):
-    """O = softmax(Q K^T scale) V per head (D=64); Vt is V transposed [heads*64][ld >= round_up(Tk,64)]."""
-    check(lib.sculpt_attention_bf16(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O),
-                                    O.stride(0), Tq, Tk, heads, float(scale), _stream()))
+    """O = softmax(Q K^T scale) V per head (D=64); Vt is V transposed [heads*64][ld >= round_up(Tk,64)].
+    scale=None: the queries already carry softmax_scale * log2(e) (sculpt_attention_bf16_prescaled)."""
+    if scale is None:
+        check(lib.sculpt_attention_bf16_prescaled(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O),
+                                                  O.stride(0), Tq, Tk, heads, _stream()))
+    else:
+        check(lib.sculpt_attention_bf16(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O),
+                                        O.stride(0), Tq, Tk, heads, float(scale), _stream()))
 
 
 def layernorm(x, gamma, beta, eps, y=None, y_f32=None, rows=None):

@@ -341,8 +341,8 @@ class SF3D(KernelEngine):
         return (W @ cond.astype(np.float64) + b).astype(np.float32)
 
     def _attn_scale(self, scale):
-        """bf16 mode: the query projections carry scale * log2(e) (ln_linear in _prepare) -> sculpt_attention_bf16's scale = 0 entry."""
-        return 0.0 if self.precision == "bf16" else scale
+        """bf16 mode: the query projections carry scale * log2(e) (ln_linear in _prepare) -> sculpt_attention_bf16_prescaled (scale None)."""
+        return None if self.precision == "bf16" else scale
 
     def _prepare(self, dev):
         sd, cfg = self._sd, self.cfg
@@ -350,7 +350,7 @@ class SF3D(KernelEngine):
             if e is not None:
                 e.to(dev)
         wt = _bf if self.precision == "bf16" else _f32
-        pre = self.precision == "bf16"   # query projections carry softmax_scale * log2(e) (sculpt_attention_bf16, scale = 0 entry)
+        pre = self.precision == "bf16"   # query projections carry softmax_scale * log2(e) (sculpt_attention_bf16_prescaled)
 
         def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, head_dim=1):
             """A Linear fed by a LayerNorm: folded into the GEMM in bf16 mode (engine.prepare_ln_linear), with the

@@ -211,3 +211,29 @@ def u2net_state(seed=0):
             wshape = sd[name[:-4] + "weight"].shape
             sd[name] = _uniform(rng, shape, 1.0 / math.sqrt(float(np.prod(wshape[1:]))))
     return sd
+
+
+def calibrate_tsr_density_bias(model, sd, img_dev, inside=0.015, threshold=25.0):
+    """Random-init weights never reach the reference's threshold of 25: shift decoder.layers.18.bias[0] so that `inside` of the
+    voxels exceed it for this image, reload the weights into `model` and return the shift.  `sd` is updated."""
+    import torch
+
+    from . import ops
+
+    ctx, _ = model.image_tokens(img_dev)
+    _, outb = model.backbone_tokens(ctx)
+    planes = model.scene_code(outb)
+    # 64^3 lattice probe through the point-query kernel (query_triplane's path): keeps the rocprof row of the dense-grid kernel
+    # to full-size launches only
+    g = ops.grid_axis_coords(64, model.renderer.cfg.radius).to(planes.device)
+    pts = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    probe = ops.triplane_query(planes, model.decoder, pts, radius=model.renderer.cfg.radius,
+                               density_bias=model.renderer.cfg.density_bias, want=("density",))["density"].reshape(-1)
+    pre = probe.cpu().numpy().astype(np.float64)                    # density before the -1 bias
+    shift = calibrate_density_bias(pre, inside_fraction=inside, threshold=threshold)
+    k = "decoder.layers.18.bias"
+    b = sd[k].copy()
+    b[0] += np.float32(shift)
+    sd[k] = b
+    model.load_state_dict(sd)
+    return shift

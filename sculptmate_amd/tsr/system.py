@@ -68,11 +68,12 @@ class _PinnedPool:
         n = 1
         for d in shape:
             n *= int(d)
-        nbytes = max(n * torch.empty((), dtype=dtype).element_size(), 1)
-        cap = 1 << (nbytes - 1).bit_length()
+        esize = torch.empty((), dtype=dtype).element_size()
+        nbytes = n * esize
+        cap = 1 << (max(nbytes, 16) - 1).bit_length()   # at least one element of any dtype: an empty mesh array gets a real buffer
         lst = self.free.get(cap)
         buf = lst.pop() if lst else torch.empty(cap, dtype=torch.uint8, pin_memory=True)
-        view = buf[:nbytes].view(dtype).view(shape)
+        view = buf[:max(nbytes, esize)].view(dtype)[:n].view(shape)
         return _PinnedLease(self, cap, buf), view
 
     def give(self, cap, buf):
@@ -108,6 +109,7 @@ class PendingMesh:
         self._host = host_tensors
         self._done = done_event
         self._leases = leases
+        self._mesh = None
 
     def done(self) -> bool:
         return self._done.query()
@@ -115,12 +117,16 @@ class PendingMesh:
     def result(self) -> Mesh:
         """The arrays are views of pinned host buffers; a buffer returns to the pool when its array -- and every view or
         slice taken from it -- has been released (it does not matter whether the Mesh object itself is kept)."""
-        self._done.synchronize()
-        arrays = [None if t is None else t.numpy() for t in self._host]
-        for lease, a in zip(self._leases, [a for a in arrays if a is not None]):
-            lease.hand_over(a)
-        self._leases = ()
-        return Mesh(*arrays)
+        if self._mesh is None:
+            self._done.synchronize()
+            arrays = [None if t is None else t.numpy() for t in self._host]
+            for lease, a in zip(self._leases, [a for a in arrays if a is not None]):
+                lease.hand_over(a)
+            # later calls return the SAME Mesh: a second set of views would carry no lease, and the buffers could go back to
+            # the pool (and be overwritten by a later run_async) while it is still alive
+            self._leases, self._host = (), None
+            self._mesh = Mesh(*arrays)
+        return self._mesh
 
 
 class MarchingCubeHelper:
@@ -372,8 +378,8 @@ class TSR(KernelEngine):
         return ctx, ctx32
 
     def _attn_scale(self, scale):
-        """bf16 mode: the query projections carry scale * log2(e) (ln_linear q_scale) -> sculpt_attention_bf16's scale = 0 entry."""
-        return 0.0 if self.precision == "bf16" else scale
+        """bf16 mode: the query projections carry scale * log2(e) (ln_linear q_scale) -> sculpt_attention_bf16_prescaled (scale None)."""
+        return None if self.precision == "bf16" else scale
 
     def _self_attention(self, st, L):
         """h += attn1(LN1(h)) of one BasicTransformerBlock (basic_transformer_block.py:149-167)."""
@@ -483,6 +489,33 @@ class TSR(KernelEngine):
         ops.upsample_scatter(g, w["up_b"], planes, S, Co)
         return planes
 
+    def _upload(self, t: torch.Tensor) -> torch.Tensor:
+        """Host image -> HBM without blocking the host: a pageable source makes hipMemcpyAsync synchronous (the host waits for
+        the stream to drain and for the copy), so it is first copied into one of three pinned staging buffers (a 3 MB host
+        memcpy) and sent from there; a slot is reused once the copy that read it has completed."""
+        if t.device.type != "cpu":
+            return t.to(self.device, non_blocking=True)
+        if t.is_pinned():
+            return t.to(self.device, non_blocking=True)
+        ring = getattr(self, "_stage", None)
+        if ring is None:
+            ring = self._stage = {"i": 0, "slots": [[None, None] for _ in range(3)]}
+        slot = ring["slots"][ring["i"] % 3]
+        ring["i"] += 1
+        n = t.numel()
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < n:
+            slot[0] = torch.empty(max(n, 3 * 512 * 512), dtype=torch.float32, pin_memory=True)
+        stage = slot[0][:n].view(t.shape)
+        # a plain single-threaded memcpy: torch's CPU copy_ is an OpenMP parallel_for, and waking the (sleeping) worker threads of
+        # a 256-core host once per image costs ~20 ms -- measured: 11.4 -> 31 ms per step
+        np.copyto(stage.numpy(), t.numpy() if t.is_contiguous() else t.contiguous().numpy())
+        d = stage.to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
+        return d
+
     def forward(self, image, device=None) -> torch.Tensor:
         """system.py:82-115: image(s) -> scene_codes fp32 [B, 3, 40, 64, 64] on the device."""
         if self._w is None:
@@ -495,7 +528,7 @@ class TSR(KernelEngine):
         for im in _as_image_list(image):
             # ImagePreprocessor (tsr/utils.py:62-112): uint8/PIL -> float/255 on the host, then the
             # antialiased bilinear resize to cond_image_size -- on the GPU (sculpt_resize_aa_bilinear)
-            img = _to_float_hwc(im).to(self.device, non_blocking=True).contiguous()
+            img = self._upload(_to_float_hwc(im)).contiguous()
             if img.shape[-1] != 3:
                 raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
             if img.shape[0] != size or img.shape[1] != size:
@@ -616,6 +649,18 @@ class TSR(KernelEngine):
         copy of mesh i overlaps the kernels of image i + 1 (run_async)."""
         pending = [self.run_async(im, mc_resolution, threshold, enable_texture) for im in _as_image_list(images)]
         return [p.result() for p in pending]
+
+
+def _run_sharded(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False, **kw):
+    """A batch over the ranks of the default process group, one image per GPU at a time (sculptmate_amd/batch.py): returns
+    ({index: Mesh} for this rank's images, [(index, rank, n_vertices, n_faces)] for all of them)."""
+    from .. import batch
+
+    with torch.no_grad():
+        return batch.run_sharded(self, images, mc_resolution, threshold, enable_texture, **kw)
+
+
+TSR.run_sharded = _run_sharded
 
 
 def _as_image_list(image):

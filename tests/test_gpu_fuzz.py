@@ -103,7 +103,7 @@ def test_attention_random_shapes(cuda):
         o = torch.empty(Tq, D, dtype=BF, device=cuda)
         if it % 2:  # the pre-scaled entry (scale = 0): q carries softmax_scale * log2(e), rounded to bf16 once
             q = (q.float() * (0.125 * 1.4426950408889634)).to(BF)
-            ops.attention(q.to(cuda), k.to(cuda), vt.to(cuda), o, Tq, Tk, heads, 0.0)
+            ops.attention(q.to(cuda), k.to(cuda), vt.to(cuda), o, Tq, Tk, heads, None)
             q = (q.float() / (0.125 * 1.4426950408889634))  # the reference sees the same rounded queries
         else:
             ops.attention(q.to(cuda), k.to(cuda), vt.to(cuda), o, Tq, Tk, heads, 0.125)

@@ -106,7 +106,7 @@ def test_gemm_layernorm_fold_vs_fp32_reference(cuda, M, D, N, epi):
 
 @pytest.mark.parametrize("Tq,Tk,heads", [(3072, 3072, 16), (3072, 1025, 16), (1025, 1025, 12), (200, 77, 2), (257, 640, 3)])
 def test_attention_prescaled_q_with_forced_rescales(cuda, Tq, Tk, heads):
-    """sculpt_attention_bf16's scale = 0 entry (Q carries scale * log2 e; the running maximum is subtracted inside the MFMA and
+    """sculpt_attention_bf16_prescaled (Q carries scale * log2 e; the running maximum is subtracted inside the MFMA and
     may lag by up to 2^10) against an fp64 softmax over the SAME bf16 operands.  The rescale branch is rare on random data,
     so it is forced: single keys are spiked against single queries so that the row maximum jumps by far more than the
     threshold at chosen tiles (first, middle, last, and in the ragged tail), one query sees a huge NEGATIVE first tile, and
@@ -131,7 +131,7 @@ def test_attention_prescaled_q_with_forced_rescales(cuda, Tq, Tk, heads):
     vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=cuda)
     vt[:, :Tk] = vf.to(BF).t().to(cuda)
     o = torch.empty(Tq, D, dtype=BF, device=cuda)
-    ops.attention(qs, k, vt, o, Tq, Tk, heads, 0.0)
+    ops.attention(qs, k, vt, o, Tq, Tk, heads, None)
     qh = qs.double().cpu().view(Tq, heads, 64).transpose(0, 1)
     kh = k.double().cpu().view(Tk, heads, 64).transpose(0, 1)
     vh = vt[:, :Tk].t().double().cpu().view(Tk, heads, 64).transpose(0, 1)
@@ -409,6 +409,26 @@ def test_run_async_pipeline_and_pinned_buffer_lifetime(cuda):
     gc.collect()
     m.run([imgs[2]], mc_resolution=32, threshold=thr)
     assert np.array_equal(view, snapshot[:10])  # a slice keeps its buffer out of the pool just as well
+    # result() twice hands out the SAME Mesh (a second set of views would not own its buffers), and it survives later runs
+    p = m.run_async(imgs[3], 32, thr)
+    r1 = p.result()
+    r2 = p.result()
+    assert r1 is r2
+    snap = r1.vertices.copy()
+    del r1
+    gc.collect()
+    for im in imgs:
+        m.run([im], mc_resolution=32, threshold=thr)
+    assert np.array_equal(r2.vertices, snap)
+    # the pool hands out zero-element arrays of any dtype (a mesh without colours / an empty slab)
+    from sculptmate_amd.tsr.system import _PinnedPool
+
+    lease, h = _PinnedPool().take((0, 3), torch.int64)
+    assert h.shape == (0, 3) and h.dtype == torch.int64 and h.is_pinned()
+    # a pageable host image goes through the pinned staging ring: more images than slots, results unchanged
+    more = [m.run_async(imgs[i % 4], 32, thr) for i in range(7)]
+    for i, q in enumerate(more):
+        assert np.array_equal(q.result().vertices, want[i % 4][0])
 
 
 def test_generator_facade_end_to_end(cuda, tmp_path):

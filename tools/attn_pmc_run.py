@@ -9,5 +9,5 @@ for (Tq, Tk, heads) in ((3072, 3072, 16), (3072, 1025, 16)):
     q = (torch.randn(Tq, D, device=dev) * 0.18).to(BF); k = torch.randn(Tk, D, device=dev).to(BF)
     vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=dev); vt[:, :Tk] = torch.randn(D, Tk, device=dev).to(BF)
     o = torch.empty(Tq, D, dtype=BF, device=dev)
-    for _ in range(12): ops.attention(q, k, vt, o, Tq, Tk, heads, 0.0)
+    for _ in range(12): ops.attention(q, k, vt, o, Tq, Tk, heads, None)
     torch.cuda.synchronize()

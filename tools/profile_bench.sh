@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd $R
-BENCH="python3 bench.py --no-cpu-baseline --no-optional-modes --no-extras"
+BENCH="python3 bench.py --no-cpu-baseline --no-optional-modes --no-extras --no-siblings"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 10 --warmup 2 > $OUT/bench_under_trace.log 2>&1
 find $OUT/trace -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 3 --warmup 1 > $OUT/pmc_fetch.log 2>&1

@@ -24,7 +24,7 @@ for (Tq, Tk, heads, gain) in ((3072, 3072, 16, 1.0), (3072, 1025, 16, 1.0), (102
     vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=dev); vt[:, :Tk] = vf.to(BF).t()
     o0 = torch.empty(Tq, D, dtype=BF, device=dev); o1 = torch.empty_like(o0)
     t0 = timeit(lambda: ops.attention(q, k, vt, o0, Tq, Tk, heads, 0.125))
-    t1 = timeit(lambda: ops.attention(qs, k, vt, o1, Tq, Tk, heads, 0.0))
+    t1 = timeit(lambda: ops.attention(qs, k, vt, o1, Tq, Tk, heads, None))
     # fp64 reference from the bf16 operands each kernel really gets
     def ref(qq, scale):
         qh = qq.double().view(Tq, heads, 64).transpose(0, 1); kh = k.double().view(Tk, heads, 64).transpose(0, 1)

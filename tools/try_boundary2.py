@@ -1,0 +1,53 @@
+"""Which part of TSR.run_async costs time over the resident step?  Interleaved rounds in ONE process (clock drift between
+separate runs is of the size of the effect)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from sculptmate_amd import synth
+
+dev = torch.device("cuda:0")
+model, sd = bench.build_model(dev, 0)
+imgs_np = [synth.composite_rgb(synth.image_rgba(seed=100 + i)) for i in range(4)]
+imgs = [torch.from_numpy(a).to(dev) for a in imgs_np]
+bench.calibrate(model, sd, imgs[0])
+N = 24
+
+def timed(fn, n=N):
+    fn(0); fn(1); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n): fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+copy = torch.cuda.Stream(dev)
+res = {}
+with torch.no_grad():
+    v, f = bench.one_step(model, imgs[0]); torch.cuda.synchronize()
+    hv = [torch.empty((v.shape[0] + 100000, 3), dtype=v.dtype, pin_memory=True) for _ in range(2)]
+    hf = [torch.empty((f.shape[0] + 200000, 3), dtype=f.dtype, pin_memory=True) for _ in range(2)]
+    def b(i, what="vf", src=imgs):
+        v, f = bench.one_step(model, src[i % 4])
+        ev = torch.cuda.Event(); ev.record()
+        with torch.cuda.stream(copy):
+            copy.wait_event(ev)
+            if "v" in what: hv[i % 2][:v.shape[0]].copy_(v, non_blocking=True)
+            if "f" in what: hf[i % 2][:f.shape[0]].copy_(f, non_blocking=True)
+        v.record_stream(copy); f.record_stream(copy)
+    prev = [None]
+    def pipe(i, src=imgs):
+        cur = model.run_async(src[i % 4], 256, 25.0)
+        if prev[0] is not None: prev[0].result()
+        prev[0] = cur
+    cases = [("A resident, mesh stays in HBM", lambda i: bench.one_step(model, imgs[i % 4])),
+             ("A' host image in, mesh stays in HBM", lambda i: bench.one_step(model, imgs_np[i % 4])),
+             ("B A + D2H verts+faces on a copy stream (fixed pinned)", b),
+             ("D A + event + record_stream only", lambda i: b(i, "")),
+             ("F run_async pipelined, resident in", pipe),
+             ("G run_async pipelined, host in", lambda i: pipe(i, imgs_np))]
+    for rnd in range(4):
+        for name, fn in cases:
+            res.setdefault(name, []).append(timed(fn))
+    base = np.median(res[cases[0][0]])
+    for name, _ in cases:
+        print("%-58s median %.3f ms (%+.3f)  all %s" % (name, np.median(res[name]), np.median(res[name]) - base, ["%.2f" % x for x in res[name]]))
