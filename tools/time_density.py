@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--l3-pipe", default="1")
     ap.add_argument("--l3-sched", default="0")
     ap.add_argument("--l3-pair", default="0")
-    ap.add_argument("--l3-kstep", default="0")
+    ap.add_argument("--l3-kstep", default="1")
+    ap.add_argument("--l3-two", default="0")
+    ap.add_argument("--l3-grid", default="256")
     ap.add_argument("--modes", default="fp32,fp16x3,bf16x3,bf16l3")
     args = ap.parse_args()
     from oracle import capi
@@ -46,9 +48,10 @@ def main():
                     for sc in args.l3_sched.split(","):
                         for pr in args.l3_pair.split(","):
                             for ks in args.l3_kstep.split(","):
-                                variants.append((m, {"SCULPT_DENSITY_L3_THREADS": nt, "SCULPT_DENSITY_L3_PIPE": pk,
-                                                     "SCULPT_DENSITY_L3_SCHED": sc, "SCULPT_DENSITY_L3_PAIR": pr,
-                                                     "SCULPT_DENSITY_L3_KSTEP": ks}))
+                                for tw in args.l3_two.split(","):
+                                    for gr in args.l3_grid.split(","):
+                                        variants.append((m, {"SCULPT_DENSITY_L3_THREADS": nt, "SCULPT_DENSITY_L3_KSTEP": ks,
+                                                             "SCULPT_DENSITY_L3_TWO": tw, "SCULPT_DENSITY_L3_GRID": gr}))
         else:
             variants.append((m, {}))
     out = torch.empty(R ** 3, dtype=torch.float32, device=dev)
