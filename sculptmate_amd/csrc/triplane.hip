@@ -940,14 +940,13 @@ __device__ __forceinline__ void l3_table_sum(const float *FA, const float *FB, c
 
 // One k-step of ONE tile (the k-step software pipeline of density_grid_l3k_kernel): twelve MFMAs with the limbs p1 / p2 / p3
 // of k-step g, and behind them (VALU = true) the SiLU + split chunks of the values already placed in `s` (k-step g + 1).
-// MODE: 0 = MFMAs only, 1 = SiLU + split chunks behind them, 2 = SiLU chunks only (input of the last layer: no limbs needed)
+// MODE: 0 = MFMAs only, 1 = SiLU + split chunks behind them
 template <int MODE>
 __device__ __forceinline__ void l3_kstep(f32x16 &acc0, f32x16 &acc1, const tbf16x8 &p1, const tbf16x8 &p2, const tbf16x8 &p3,
                                          VState &s, Frags &f, const tbf16x8 *Ag, const tbf16x8 *An, const tbf16x8 *A3n) {
 #define L3_SLOT(CH, ACC, AOP, BOP, PREFETCH)                 \
     ACC = mfma16(AOP, BOP, ACC);                             \
     if (MODE == 1) vchunk<CH, true>(s);                      \
-    if (MODE == 2) vchunk<CH, false>(s);                     \
     PREFETCH;                                                \
     __builtin_amdgcn_sched_barrier(0);
     tbf16x8 a11, a20, a21;
@@ -1058,136 +1057,6 @@ __global__ __launch_bounds__(NT) void density_grid_l3k_kernel(
         x1 = silu16_scalar(x1);
         const float d = last_dot(L, 0, h, x0, x1);
         if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// TWO tiles per wave (density_grid_l3k2_kernel).  In the one-tile pipeline above two pieces of every layer have nothing of
-// their own tile to pair with: the SiLU + split of k-step 0 (76 vector instructions, needs the previous layer complete) and the
-// twelve MFMAs of k-step 3 -- and the matrix phase of one wave does NOT overlap the vector phase of another wave of the same
-// SIMD (tools/micro/mfma_phase.hip: 2 301 cycles per {48 MFMA ; 304 VALU} round at four waves per SIMD whatever the priorities
-// or the stagger, 1 790 when every wave interleaves the two itself).  So a wave holds tiles A and B and runs their layers
-// alternately: A's layer l, then B's layer l; behind the MFMAs of A's LAST k-step go the k-step-0 chunks of B's layer input,
-// and behind B's last k-step those of A's next layer -- every MFMA of the loop has vector work of its own wave behind it.
-// ---------------------------------------------------------------------------------------------
-// One layer of one tile.  x0 / x1: the tile's pending values (previous layer's result; k-steps 1..3 are taken from them here) and,
-// on return, this layer's result.  p1..p3: limbs of ITS k-step 0 (made by the other tile's previous call).  y0: the OTHER tile's
-// pending first 16 values; OTHER = 1: their first 8 go through SiLU + split behind this tile's last k-step -> q1..q3 (the other
-// tile's k-step 0 limbs); OTHER = 2: SiLU only, written back into y0[0..7] (the other tile's next layer is the output layer).
-template <int OTHER>
-__device__ __forceinline__ void l3_layer(const LdsView &L, int l, int h, f32x16 &x0, f32x16 &x1, tbf16x8 &p1, tbf16x8 &p2,
-                                         tbf16x8 &p3, f32x16 &y0, tbf16x8 &q1, tbf16x8 &q2, tbf16x8 &q3, Frags &f,
-                                         const tbf16x8 *Al, const tbf16x8 *A3l, const tbf16x8 *Anext, const tbf16x8 *A3next) {
-    f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
-    f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        VState s;
-        if (g < 3) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s.x[i] = (g + 1 < 2 ? x0 : x1)[8 * ((g + 1) & 1) + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s.x[i] = y0[i];
-        }
-        const tbf16x8 *Ag = Al + g * 64;
-        const tbf16x8 *An = g < 3 ? Al + (g + 1) * 64 : Anext;
-        const tbf16x8 *A3n = g < 3 ? A3l + (g + 1) * 64 : A3next;
-        if (g < 3) {
-            l3_kstep<1>(acc0, acc1, p1, p2, p3, s, f, Ag, An, A3n);
-            vstate_limbs(s, p1, p2, p3);
-        } else {
-            l3_kstep<OTHER>(acc0, acc1, p1, p2, p3, s, f, Ag, An, A3n);
-            if (OTHER == 1) vstate_limbs(s, q1, q2, q3);
-            if (OTHER == 2) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) y0[i] = s.x[i];
-            }
-        }
-    }
-    x0 = acc0;
-    x1 = acc1;
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void density_grid_l3k2_kernel(
-    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
-    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
-    const int NH = hd.NH;  // >= 1 (the launcher sends NH == 0 to the plain kernel)
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + hd.off_x3);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
-        float *bacc = smem + NH * 4096;
-        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
-        float *wl = bacc + (NH + 1) * 64;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
-        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
-        __syncthreads();
-    }
-    const LdsView L = lds_view(smem, NH);
-    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = lane & 31, h = lane >> 5;
-    const int nzb = (R + 31) / 32;
-    const long ntiles = (long)nx * nzb * R;
-    const long nw_total = (long)gridDim.x * nwave;
-    long wid = (long)blockIdx.x * nwave + wave;
-    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
-    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
-    int iy = (int)(t_begin % R);
-    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
-    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
-    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
-
-    for (long t = t_begin; t < t_end; t += 2) {
-        // tile A = t, tile B = t + 1 (the next iy of the same (ix, z block) row; at the odd end of the range B repeats A, unstored)
-        const bool haveB = t + 1 < t_end;
-        const int iyA = iy, zbA = zb, ixA = ixl;
-        if (haveB && ++iy == R) {
-            iy = 0;
-            if (++zb == nzb) { zb = 0; ++ixl; }
-        }
-        const int iyB = iy, zbB = zb, ixB = ixl;
-        if (++iy == R) {
-            iy = 0;
-            if (++zb == nzb) { zb = 0; ++ixl; }
-        }
-        const int izA = zbA * 32 + p, izB = zbB * 32 + p;
-        f32x16 a0, a1, b0, b1;  // pending values (layer input before SiLU) / results of tiles A and B
-        l3_table_sum(FA, FB, FC, R, ixA, iyA, min(izA, R - 1), h, a0, a1);
-        l3_table_sum(FA, FB, FC, R, ixB, iyB, min(izB, R - 1), h, b0, b1);
-        Frags f;
-        f.a10 = A[0];
-        f.c0 = A3[0]; f.c1 = A3[256];
-        tbf16x8 pa1, pa2, pa3, pb1, pb2, pb3;
-        {   // A's very first k-step: nothing to run behind (once per tile pair)
-            VState s;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s.x[i] = a0[i];
-            vchunk<0, true>(s); vchunk<1, true>(s); vchunk<2, true>(s); vchunk<3, true>(s); vchunk<4, true>(s); vchunk<5, true>(s);
-            vchunk<6, true>(s); vchunk<7, true>(s); vchunk<8, true>(s); vchunk<9, true>(s); vchunk<10, true>(s); vchunk<11, true>(s);
-            vstate_limbs(s, pa1, pa2, pa3);
-        }
-        for (int l = 0; l < NH; ++l) {
-            const tbf16x8 *Al = A + (long)l * 1024, *A3l = A3 + (long)l * 512;
-            const int ln = min(l + 1, NH - 1);  // the fetch behind the very last k-step is never used; keep it inside the arrays
-            l3_layer<1>(L, l, h, a0, a1, pa1, pa2, pa3, b0, pb1, pb2, pb3, f, Al, A3l, Al, A3l);
-            // ONE code path for every layer: with a separate last-layer variant under an if / else hipcc hoists the vector chunks
-            // the two variants have in common above the branch -- a lump of 150 vector instructions and 36 bare MFMAs.  Behind
-            // the last layer's last k-step the limbs of A's "next layer" are computed and never used (12 of 768 chunks).
-            l3_layer<1>(L, l, h, b0, b1, pb1, pb2, pb3, a0, pa1, pa2, pa3, f, Al, A3l, A + (long)ln * 1024, A3 + (long)ln * 512);
-        }
-        a0 = silu16_scalar(a0);
-        a1 = silu16_scalar(a1);
-        b0 = silu16_scalar(b0);
-        b1 = silu16_scalar(b1);
-        const float dA = last_dot(L, 0, h, a0, a1);
-        const float dB = last_dot(L, 0, h, b0, b1);
-        if (h == 0 && izA < R) out[((long)ixA * R + iyA) * R + izA] = exp_f(dA + density_bias) + out_add;
-        if (h == 0 && izB < R && haveB) out[((long)ixB * R + iyB) * R + izB] = exp_f(dB + density_bias) + out_add;
     }
 }
 
@@ -1436,18 +1305,6 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
         // the phase-separated kernel instead of the k-step pipeline
         const int l3_threads = getenv("SCULPT_DENSITY_L3_THREADS") ? atoi(getenv("SCULPT_DENSITY_L3_THREADS")) : 1024;
         const bool kstep = !(getenv("SCULPT_DENSITY_L3_KSTEP") && atoi(getenv("SCULPT_DENSITY_L3_KSTEP")) == 0);
-        const bool two = getenv("SCULPT_DENSITY_L3_TWO") && atoi(getenv("SCULPT_DENSITY_L3_TWO")) != 0;
-        if (two) {
-            const int nt2 = l3_threads == 256 ? 256 : (l3_threads == 768 ? 768 : 512);
-            auto k2 = nt2 == 256 ? density_grid_l3k2_kernel<256> : (nt2 == 768 ? density_grid_l3k2_kernel<768> : density_grid_l3k2_kernel<512>);
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int nw2 = nt2 / 64;
-            const int grid2 = (int)std::min<long>((ntiles + 2 * nw2 - 1) / (2 * nw2), num_cus());
-            hipLaunchKernelGGL(k2, dim3(grid2), dim3(nt2), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
-                               density_bias, out_add, out);
-            SC_LAUNCH_CHECK();
-            return 0;
-        }
         const int nt = l3_threads == 768 ? 768 : (l3_threads == 512 ? 512 : 1024);
         auto kern = kstep ? (nt == 1024 ? density_grid_l3k_kernel<1024> : nt == 768 ? density_grid_l3k_kernel<768> : density_grid_l3k_kernel<512>)
                           : (nt == 1024 ? density_grid_l3_kernel<1024> : nt == 768 ? density_grid_l3_kernel<768> : density_grid_l3_kernel<512>);

@@ -2,7 +2,7 @@
 """Dense density grid at 256^3, every decoder mode side by side in ONE process (interleaved rounds, guide rule 24):
 launch time by HIP events and max |log d - log d_oracle| on a sample of lattice points.
 
-    python tools/time_density.py [--rounds 5] [--R 256] [--l3-threads 1024,768,512] [--l3-pk 0,1]
+    python tools/time_density.py [--rounds 5] [--R 256] [--l3-threads 1024,768,512] [--l3-kstep 0,1] [--l3-grid 256,128,64]
 """
 import argparse
 import os
@@ -20,11 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--R", type=int, default=256)
     ap.add_argument("--l3-threads", default="1024")
-    ap.add_argument("--l3-pipe", default="1")
-    ap.add_argument("--l3-sched", default="0")
-    ap.add_argument("--l3-pair", default="0")
     ap.add_argument("--l3-kstep", default="1")
-    ap.add_argument("--l3-two", default="0")
     ap.add_argument("--l3-grid", default="256")
     ap.add_argument("--modes", default="fp32,fp16x3,bf16x3,bf16l3")
     args = ap.parse_args()
@@ -44,14 +40,9 @@ def main():
     for m in args.modes.split(","):
         if m == "bf16l3":
             for nt in args.l3_threads.split(","):
-                for pk in args.l3_pipe.split(","):
-                    for sc in args.l3_sched.split(","):
-                        for pr in args.l3_pair.split(","):
-                            for ks in args.l3_kstep.split(","):
-                                for tw in args.l3_two.split(","):
-                                    for gr in args.l3_grid.split(","):
-                                        variants.append((m, {"SCULPT_DENSITY_L3_THREADS": nt, "SCULPT_DENSITY_L3_KSTEP": ks,
-                                                             "SCULPT_DENSITY_L3_TWO": tw, "SCULPT_DENSITY_L3_GRID": gr}))
+                for ks in args.l3_kstep.split(","):
+                    for gr in args.l3_grid.split(","):
+                        variants.append((m, {"SCULPT_DENSITY_L3_THREADS": nt, "SCULPT_DENSITY_L3_KSTEP": ks, "SCULPT_DENSITY_L3_GRID": gr}))
         else:
             variants.append((m, {}))
     out = torch.empty(R ** 3, dtype=torch.float32, device=dev)
