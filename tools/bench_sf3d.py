@@ -12,7 +12,8 @@ from sculptmate_amd.sf3d.spec import DEFAULT_CFG  # noqa: E402
 from sculptmate_amd.sf3d.system import SF3D  # noqa: E402
 
 dev = torch.device("cuda:0")
-res = int(sys.argv[1]) if len(sys.argv) > 1 else DEFAULT_CFG["isosurface_resolution"]
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+res = int(_pos[0]) if _pos else DEFAULT_CFG["isosurface_resolution"]
 cfg = dict(DEFAULT_CFG, isosurface_resolution=res)
 t0 = time.time()
 sd = synth.sf3d_state(0, cfg)
@@ -122,3 +123,17 @@ try:
     print("texture bake at 512^2 (rasterize + interpolate + 3 heads at the texels + material + dilate, incl. the PIL hand-off): %.2f ms" % tb)
 except Exception as e:  # noqa: BLE001  (a timing tool: report, do not hide the stages above)
     print("texture bake: failed (%s: %s)" % (type(e).__name__, e))
+
+
+def remesh_time():
+    """Mesh.triangle_remesh on the host (native decimate + Botsch-Kobbelt, sf3d/remesh.py) on the full raw mesh, 'high' setting
+    (vertex_count = 0.75 x vertices, like generate_mesh)."""
+    t0 = time.perf_counter()
+    out = m.remesher(mesh, "triangle", round(0.75 * mesh.v_pos.shape[0]))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3, out
+
+
+if "--remesh" in sys.argv:
+    tr, rm = remesh_time()
+    print("triangle remesh on the host (%d -> %d vertices): %.1f ms" % (mesh.v_pos.shape[0], rm.v_pos.shape[0], tr))
