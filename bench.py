@@ -94,7 +94,6 @@ def boundary_rate(model, imgs_host, steps):
         prev.result()
         prev = cur
     prev.result()
-    prev = model.run_async(imgs_host[0], MC_RES, THRESHOLD)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nbytes = 0
