@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -487,6 +488,295 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 along the weight rows x 4 along the activation rows: a wave owns 128 x 64 = 8 x 4 MFMA tiles, 128
+// accumulator registers), one workgroup per CU, for the two big LayerNorm-folded projections of a backbone block (the fused
+// Q|K|V^T projection and FF1 + GEGLU).  Why a second kernel: the 128-row tiles above move 768 B of LDS fragments per MFMA (wave
+// tile 32 x 64) and their K loop runs at the rate at which a CU's LDS can be filled while it is being read; a
+// 128 x 64 wave tile needs 384 B per MFMA -- but with only two waves per SIMD nothing hides a fragment read or a DMA round
+// trip unless the loop does it itself.  So the K-tile (BK = 64) is cut into four phases of 16 MFMAs (one 64 x 32 quadrant of
+// the wave tile x K = 64), and the loop is pipelined at FRAGMENT granularity:
+//   phase 0  Q(A0, B0)   reads B1 of this K-tile            DMA: units 6, 7 of K-tile kt + 1
+//   phase 1  Q(A0, B1)   reads A1 (into the A0 registers as they die)
+//            -- lgkmcnt(0) + barrier: every wave has finished reading this K-tile's buffer --
+//   phase 2  Q(A1, B1)                                      DMA: units 0 - 2 of K-tile kt + 2 (into the buffer just freed)
+//            -- counted vmcnt (never 0 while a later K-tile is in flight) + barrier: K-tile kt + 1 has landed --
+//   phase 3  Q(A1, B0)   reads A0, B0 of K-tile kt + 1      DMA: units 3 - 5 of K-tile kt + 2
+// (A0 / A1 = the wave's weight sub-tiles 0-3 / 4-7, B0 / B1 = its activation sub-tiles 0-1 / 2-3; a DMA "unit" = one
+// global_load_lds_dwordx4 per thread = 64 rows of one operand; 8 units per K-tile.)  A fragment is overwritten by the read
+// of its successor right after its last MFMA, so the fragments take 64 registers, not 128; every LDS read is issued at least
+// eight MFMAs before its first use, every DMA at least two phases before the barrier that publishes it; two barriers per K-tile.
+// The epilogue is the one of the kernel above (TI = 8, TJ = 4): LayerNorm fold, bias, GEGLU, the Q|K / V^T column split.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
+    constexpr int BW = 256, BM = 256, NW = 8, NWC = 4, TI = 8, TJ = 4;
+    constexpr int WT = BW * 128, AT = BM * 128;  // 32 KiB each
+    constexpr int XCH = 2 * (WT + AT);           // two K-tile buffers
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XCH + 2 * BM * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / NWC, wc = wave % NWC;
+    constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? BW / 2 : BW;
+    const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int n0 = (g.n_major ? tile / gridDim.y : tile % gridDim.x) * NOUT;
+    const int m0 = (g.n_major ? tile % gridDim.y : tile / gridDim.x) * BM;
+
+    // staging: wave w fills rows 32 w .. 32 w + 31 of both operand tiles, 8 rows (1 KiB) per wave instruction; the LDS image is
+    // lane-linear, the (row >> 1) & 7 chunk swizzle is applied to the per-lane SOURCE address and to the read address
+    const int srow = lane >> 3, sslot = lane & 7;
+    // per-lane BYTE offsets (32 bits) from the operands' uniform bases: the DMA takes an SGPR base + VGPR offset, 8 registers of
+    // addresses instead of 16 (the launcher checks that both operands stay below 4 GiB)
+    unsigned woff[4], aof[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 8 * (wave * 4 + q) + srow;
+        int wrow = n0 + r;
+        if (EPI == SCULPT_EPI_GEGLU) {
+            const int sub = r >> 4, within = r & 15;  // 16-row sub-tiles alternate value / gate rows
+            wrow = ((sub & 1) ? g.N : 0) + n0 + (sub >> 1) * 16 + within;
+        }
+        woff[q] = ((unsigned)wrow * (unsigned)g.ldw + ((sslot ^ ((r >> 1) & 7)) << 3)) * 2u;
+        aof[q] = ((unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + ((sslot ^ ((r >> 1) & 7)) << 3)) * 2u;
+    }
+    const char *Wb = reinterpret_cast<const char *>(g.W), *Ab = reinterpret_cast<const char *>(g.A);
+    const int sdst = wave * 4096;  // wave-uniform byte offset inside an operand tile
+#define G256_STAGE(buf, kt, u)                                                                                                   \
+    do {                                                                                                                         \
+        unsigned char *tb = smem + (buf) * (WT + AT) + ((u) >= 4 ? WT : 0) + sdst + ((u) & 3) * 1024;                            \
+        const char *src = ((u) >= 4 ? Ab + aof[(u) & 3] : Wb + woff[(u) & 3]) + (size_t)(kt) * (BK * 2);                         \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)tb, 16, 0, 0);                                               \
+    } while (0)
+
+    const int nk = g.K / BK;
+    // prologue: K-tile 0 entirely, units 0 - 5 of K-tile 1 (its units 6, 7 are issued by phase 0 of K-tile 0 like everyone's)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) G256_STAGE(0, 0, u);
+    if (nk > 1) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) G256_STAGE(1, 1, u);
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // LayerNorm fold: (mean, rstd) of the wave's 64 activation rows from the producer's slice statistics, BEFORE the K loop here
+    // (the 16 float2 per lane the other kernel carries across its loop do not fit beside 128 accumulators); wr = 0 computes,
+    // wr = 1 receives through LDS.  These plain loads make hipcc wait vmcnt(0), which also waits for the prologue's DMA: wanted.
+    float ln_mean[TJ], ln_rstd[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) { ln_mean[j] = 0.f; ln_rstd[j] = 1.f; }
+    float2 *xch = reinterpret_cast<float2 *>(smem + XCH);  // [BM rows]
+    if (g.ln_stats) {
+        if (wr == 0) {
+            constexpr int MAXU = 4;
+            const float inv_slots = 1.0f / (float)g.ln_slots;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int m = min(m0 + wc * 64 + j * 16 + fr, g.M - 1);
+                const float2 *sp = reinterpret_cast<const float2 *>(g.ln_stats) + m;
+                float2 sv[MAXU];
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) sv[u] = sp[(long)min(fq + 4 * u, g.ln_slots - 1) * g.stats_ld];
+                float sm = 0.f;
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) sm += (fq + 4 * u < g.ln_slots) ? sv[u].x : 0.f;
+                sm += __shfl_xor(sm, 16, 64);
+                sm += __shfl_xor(sm, 32, 64);
+                const float mean = sm * inv_slots;
+                float m2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < MAXU; ++u) {
+                    const float d = sv[u].x - mean;
+                    m2 += (fq + 4 * u < g.ln_slots) ? fmaf((float)LN_SLOT * d, d, sv[u].y) : 0.f;
+                }
+                m2 += __shfl_xor(m2, 16, 64);
+                m2 += __shfl_xor(m2, 32, 64);
+                ln_mean[j] = mean;
+                ln_rstd[j] = rsqrtf(m2 * inv_slots * (1.0f / LN_SLOT) + g.ln_eps);
+                if (fq == 0) xch[wc * 64 + j * 16 + fr] = make_float2(ln_mean[j], ln_rstd[j]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const float2 v = xch[wc * 64 + j * 16 + fr];
+                ln_mean[j] = v.x;
+                ln_rstd[j] = v.y;
+            }
+        }
+    }
+
+    f32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes) of sub-tiles 0-3 (A) / 0-1 (B) for ks = 0; the second half of the wave tile is + 64 rows
+    // (A: + 8192 B) / + 32 rows (B: + 4096 B) -- a multiple of 16 rows leaves the swizzle term unchanged; ks = 1 is ^ 64
+    int aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = lds_off(wr * 128 + i * 16 + fr, fq);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) boff[j] = WT + lds_off(wc * 64 + j * 16 + fr, fq);
+    bf16x8_t af[4][2], bq[4][2];  // af: the current A half; bq[0..1]: B0, bq[2..3]: B1
+#define G256_LDA(buf, ih, i, ks) af[i][ks] = *reinterpret_cast<const bf16x8_t *>(smem + (buf) * (WT + AT) + (ih) * 8192 + (aoff[i] ^ ((ks) << 6)))
+#define G256_LDB(buf, jh, j, ks) bq[2 * (jh) + (j)][ks] = *reinterpret_cast<const bf16x8_t *>(smem + (buf) * (WT + AT) + (jh) * 4096 + (boff[j] ^ ((ks) << 6)))
+#define G256_MF(ih, jh, i, j, ks) \
+    acc[4 * (ih) + (i)][2 * (jh) + (j)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bq[2 * (jh) + (j)][ks], acc[4 * (ih) + (i)][2 * (jh) + (j)], 0, 0, 0)
+#define G256_FENCE __builtin_amdgcn_sched_barrier(0)
+
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G256_LDA(0, 0, i, ks);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) G256_LDB(0, 0, j, ks);
+    }
+
+    // One K-tile.  MORE1 / MORE2: K-tiles kt + 1 / kt + 2 exist -- compile-time, so that the steady-state body is ONE basic
+    // block (a run-time test around every DMA and fragment read cut the phases into a dozen blocks with a branch each)
+    auto ktile = [&](int kt, auto more1_t, auto more2_t) __attribute__((always_inline)) {
+        constexpr bool MORE1 = decltype(more1_t)::value, MORE2 = decltype(more2_t)::value;
+        const int buf = kt & 1, nbuf = buf ^ 1;
+        // ---- phase 0: Q(A0, B0); read B1 of this K-tile; DMA units 6, 7 of K-tile kt + 1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                G256_MF(0, 0, i, 0, ks);
+                G256_MF(0, 0, i, 1, ks);
+                if (i < 2) G256_LDB(buf, 1, i, ks);
+                if (ks == 0 && i >= 2 && MORE1) G256_STAGE(nbuf, kt + 1, 4 + i);
+                G256_FENCE;
+            }
+        // ---- phase 1: Q(A0, B1); every A0 fragment is replaced by its A1 successor right after its last MFMA
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                G256_MF(0, 1, i, 0, ks);
+                G256_MF(0, 1, i, 1, ks);
+                G256_LDA(buf, 1, i, ks);
+                G256_FENCE;
+            }
+        // every wave is done reading buffer `buf`: it may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: Q(A1, B1); DMA units 0 - 2 of K-tile kt + 2 into `buf`
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                G256_MF(1, 1, i, 0, ks);
+                G256_MF(1, 1, i, 1, ks);
+                if (ks == 0 && i < 3 && MORE2) G256_STAGE(buf, kt + 2, i);
+                G256_FENCE;
+            }
+        // K-tile kt + 1 has landed: this wave's pieces by the counted wait (the three DMAs just issued stay in flight),
+        // everybody's by the barrier
+        if (MORE2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: Q(A1, B0); read A0 and B0 of K-tile kt + 1; DMA units 3 - 5 of K-tile kt + 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                G256_MF(1, 0, i, 0, ks);
+                G256_MF(1, 0, i, 1, ks);
+                if (MORE1) G256_LDA(nbuf, 0, i, ks);
+                if (MORE1 && i == 3) {  // the B0 fragments of this k-step are dead now
+                    G256_LDB(nbuf, 0, 0, ks);
+                    G256_LDB(nbuf, 0, 1, ks);
+                }
+                if (ks == 0 && i < 3 && MORE2) G256_STAGE(buf, kt + 2, 3 + i);
+                G256_FENCE;
+            }
+    };
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
+        ktile(kt, std::false_type{}, std::false_type{});
+    }
+#undef G256_STAGE
+#undef G256_LDA
+#undef G256_LDB
+#undef G256_MF
+#undef G256_FENCE
+
+    // ---- epilogue (as in gemm_bf16_kernel): acc[i][j][r] = out[m = m0 + wc*64 + j*16 + fr][tile row = wr*128 + i*16 + fq*4 + r]
+    const float *biasp = g.bias ? g.bias : g.zeros;
+    const float *csp = g.ln_stats ? g.ln_colsum : g.zeros;
+    auto f4 = [](const float4 &v, int r) -> float { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
+    if (EPI == SCULPT_EPI_GEGLU) {
+#pragma unroll
+        for (int ip = 0; ip < TI / 2; ++ip) {
+            const int wv = n0 + (wr * (TI / 2) + ip) * 16 + fq * 4;  // value row; the gate row is N further
+            const float4 bv = *reinterpret_cast<const float4 *>(biasp + wv), bg = *reinterpret_cast<const float4 *>(biasp + g.N + wv);
+            const float4 cv = *reinterpret_cast<const float4 *>(csp + wv), cg = *reinterpret_cast<const float4 *>(csp + g.N + wv);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int m = m0 + wc * 64 + j * 16 + fr;
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = ln_rstd[j] * (acc[2 * ip][j][r] - ln_mean[j] * f4(cv, r)) + f4(bv, r);
+                    const float gt = ln_rstd[j] * (acc[2 * ip + 1][j][r] - ln_mean[j] * f4(cg, r)) + f4(bg, r);
+                    o[r] = v * gelu_erf(gt);
+                }
+                if (m < g.M) {
+                    if (g.out_bf16) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + wv) = pk;
+                    }
+                    if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + wv) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int n = n0 + wr * 128 + i * 16 + fq * 4;
+            const float4 b4 = *reinterpret_cast<const float4 *>(biasp + n), c4 = *reinterpret_cast<const float4 *>(csp + n);
+            const bool tpart = n >= g.n_split;  // wave-uniform per sub-tile (n_split is a multiple of 16)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int m = m0 + wc * 64 + j * 16 + fr;
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = ln_rstd[j] * (acc[i][j][r] - ln_mean[j] * f4(c4, r)) + f4(b4, r);
+                    if (EPI == SCULPT_EPI_GELU) v = gelu_erf(v);
+                    o[r] = v;
+                }
+                if (m >= g.M) continue;
+                if (!tpart) {
+                    if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (g.out_bf16) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
+                    }
+                }
+                if (g.out_t && (tpart || g.n_split >= g.N)) {
+                    const int nt0 = tpart ? n - g.n_split : n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g.out_t[(long)(nt0 + r) * g.ldt + m] = f32_to_bf16(o[r]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace sculpt
 
 using namespace sculpt;
@@ -598,6 +888,30 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     }
     const int mt = cdiv(M, BM_DEFAULT);
     hipStream_t st = as_stream(stream);
+    // The 256 x 256 tile (gemm256_kernel) where it wins: launches of at least two full rounds of CUs -- StableFast-3D's 27 648-token
+    // FF1 + GEGLU (622 -> 500 us), wide plain projections (8192 x 8192 x 1024: 205 -> 168 us).  Its K loop runs at 1.14 us per
+    // K-tile (80 % of the matrix peak at two waves per SIMD), but a tile costs ~10-14 us besides (pipeline fill, and an epilogue
+    // that nothing overlaps with one workgroup per CU: 128 accumulators per lane through LayerNorm fold + GEGLU is ~6 us), so
+    // TripoSR's own launches -- FF1 is 384 such tiles = 1.5 rounds, the fused QKV 144 -- stay on the 128-row tiles
+    // (tools/time_gemm256.py: 72.8 vs 60.7 us, 38.1 vs 34.9 us; outputs bit-identical).  No residual / statistics / n_store.
+    {
+        const char *e256 = getenv("SCULPT_GEMM_256");  // 0: never, 1 (default): by the rule below, 2: whenever legal (tests, A/B)
+        const int p256 = e256 ? atoi(e256) : 1;
+        const int nout = epilogue == SCULPT_EPI_GEGLU ? 128 : 256;
+        const long tiles = (long)(N / nout) * cdiv(M, 256);
+        const bool pays = tiles >= 2L * num_cus() && (epilogue == SCULPT_EPI_GEGLU || N >= 4096) && (M % 256 == 0 || M % 256 >= 128);
+        const bool fits = p256 && !residual && !g.stats_out && n_store == N && N % nout == 0 && K >= 2 * BK &&
+                          (epilogue == SCULPT_EPI_GEGLU || epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_GELU) &&
+                          n_split % 16 == 0 && (long)w_rows * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L && (p256 >= 2 || pays);
+        if (fits) {
+            const dim3 grid(N / nout, cdiv(M, 256));
+            if (epilogue == SCULPT_EPI_GEGLU) hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_GEGLU>), grid, dim3(512), 0, st, g);
+            else if (epilogue == SCULPT_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_GELU>), grid, dim3(512), 0, st, g);
+            else hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_NONE>), grid, dim3(512), 0, st, g);
+            SC_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     // 8-wave workgroups (wave tile 32 x BW/2) measured 5-13 % faster than 4-wave ones (64 x BW/2) on every shape of
     // the two transformers except the deep-K 64-row-tile case (K = 4096, N = 1024: -4 %), which keeps 4 waves
     // ... unless the launch has fewer workgroups than CUs (the ViT's 1025 x 768 x 3072): then 8 waves are the only

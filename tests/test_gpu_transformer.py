@@ -150,6 +150,43 @@ def test_attention_prescaled_q_with_forced_rescales(cuda, Tq, Tk, heads):
     assert float((o2.double().cpu() - ref).norm() / ref.norm()) < 8e-3
 
 
+@pytest.mark.parametrize("M,K,N,epi,split", [(3072, 1024, 4096, 2, 0), (3072, 1024, 3072, 0, 2048), (1025, 768, 2304, 0, 1536),
+                                             (300, 128, 512, 1, 0), (517, 64, 256, 0, 0)])
+def test_gemm256_tile_kernel_is_bit_identical_to_the_128_row_tiles(cuda, monkeypatch, M, K, N, epi, split):
+    """gemm256_kernel (256 x 256 tile, fragment-level pipeline, DMA in flight across barriers by counted vmcnt) accumulates in
+    the same k order with the same MFMA and runs the same epilogue arithmetic as gemm_bf16_kernel: every output bit must match --
+    LayerNorm fold, GELU / GEGLU, the Q|K / V^T column split, ragged M, K of 1 / 2 / many K-tiles.  Repeated launches screen the
+    counted-wait structure for races (a stale tile shows up as a mismatch)."""
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M + K + N)
+    rows = 2 * N if epi == 2 else N
+    A = torch.randn(M, K, generator=g).to(BF).to(cuda)
+    W = (torch.randn(rows, K, generator=g) / math.sqrt(K)).to(BF).to(cuda)
+    bias = torch.randn(rows, generator=g).to(cuda)
+    cs = W.float().sum(1).contiguous()
+    stats = torch.randn(K // 64, M, 2, generator=g).abs().to(cuda) + 0.5
+    Mp = (M + 63) // 64 * 64
+
+    def run(mode):
+        monkeypatch.setenv("SCULPT_GEMM_256", mode)
+        if split:
+            o = torch.zeros(M, split, dtype=BF, device=cuda)
+            ot = torch.zeros(N - split, Mp, dtype=BF, device=cuda)
+            ops.gemm(A, W, bias=bias, out_bf16=o, out_t=ot, n_split=split, epilogue=epi, ln_stats=stats, ln_colsum=cs, ln_eps=1e-5)
+            return o, ot
+        o = torch.zeros(M, N, dtype=BF, device=cuda)
+        of = torch.zeros(M, N, device=cuda)
+        ops.gemm(A, W, bias=bias, out_bf16=o, out_f32=of, epilogue=epi, ln_stats=stats, ln_colsum=cs, ln_eps=1e-5)
+        return o, of
+
+    ref = run("0")
+    assert torch.isfinite(ref[1].float()).all()
+    for rep in range(6):
+        got = run("2")
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), rep
+
+
 def test_gemm_gelu_and_geglu_epilogues(cuda):
     from sculptmate_amd import _lib, ops
 
