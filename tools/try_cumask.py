@@ -31,7 +31,8 @@ def forward_plain(img):
 
 def mesh_of(planes):
     r = model.renderer.cfg.radius
-    vol = ops.density_grid(planes, model.decoder, 256, radius=r, density_bias=model.renderer.cfg.density_bias, out_add=-25.0)
+    vol = ops.density_grid(planes, model.decoder, 256, radius=r, density_bias=model.renderer.cfg.density_bias, out_add=-25.0,
+                           precision=model.decoder_precision)
     return ops.marching_cubes(vol.view(256, 256, 256), 0.0, reference_order=True, vert_div=255.0, vert_mul=2 * r, vert_add=-r)
 
 
@@ -49,7 +50,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     serial = (time.perf_counter() - t0) / N * 1e3
     print("serial, one stream, 256 CUs: %.3f ms/image  %.1f meshes/s" % (serial, 1e3 / serial))
-    for d in (256, 240, 224, 208, 192, 176, 160, 128):
+    for d in (256, 224, 192, 176, 160, 144, 128, 112, 96):
+        os.environ["SCULPT_DENSITY_L3_GRID"] = str(d)   # one density workgroup per CU of the mask (the kernel splits its tiles over any grid)
         if d == 256:   # two unmasked streams: the overlap r1 measured (tools/try_pipeline.py)
             sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
             ha = hb = None
