@@ -508,10 +508,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 // eight MFMAs before its first use, every DMA at least two phases before the barrier that publishes it; two barriers per K-tile.
 // The epilogue is the one of the kernel above (TI = 8, TJ = 4): LayerNorm fold, bias, GEGLU, the Q|K / V^T column split.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int EPI>
+// BM = 256 or 192 activation rows per tile (TJ = 4 or 3 sub-tiles of 16 per wave; with 192 the second activation half B1 is one
+// sub-tile and phases 1 / 2 have 8 MFMAs): 3072 rows are 12 tiles of 256 or 16 of 192 -- 512 instead of 384 FF1 tiles, i.e.
+// two FULL rounds of 256 CUs instead of one and a half.
+template <int EPI, int BM>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
-    constexpr int BW = 256, BM = 256, NW = 8, NWC = 4, TI = 8, TJ = 4;
-    constexpr int WT = BW * 128, AT = BM * 128;  // 32 KiB each
+    static_assert(BM == 256 || BM == 192, "activation rows per tile");
+    constexpr int BW = 256, NW = 8, NWC = 4, TI = 8, TJ = BM / 64, WROWS = BM / 4;  // WROWS: activation rows per wave (64 / 48)
+    constexpr int JB1 = TJ - 2, AU = BM / 64;  // sub-tiles in B1; DMA units of the activation tile (one per 8 rows per wave)
+    constexpr int NU = 4 + AU;                 // DMA units per K-tile: 8 or 7
+    constexpr int WT = BW * 128, AT = BM * 128;  // 32 KiB, 32 / 24 KiB
     constexpr int XCH = 2 * (WT + AT);           // two K-tile buffers
     __shared__ __attribute__((aligned(16))) unsigned char smem[XCH + 2 * BM * 8];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -531,27 +537,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = 8 * (wave * 4 + q) + srow;
+        const int ra = 8 * (wave * AU + (q < AU ? q : AU - 1)) + srow;  // activation tile: AU row groups per wave
         int wrow = n0 + r;
         if (EPI == SCULPT_EPI_GEGLU) {
             const int sub = r >> 4, within = r & 15;  // 16-row sub-tiles alternate value / gate rows
             wrow = ((sub & 1) ? g.N : 0) + n0 + (sub >> 1) * 16 + within;
         }
         woff[q] = ((unsigned)wrow * (unsigned)g.ldw + ((sslot ^ ((r >> 1) & 7)) << 3)) * 2u;
-        aof[q] = ((unsigned)min(m0 + r, g.M - 1) * (unsigned)g.lda + ((sslot ^ ((r >> 1) & 7)) << 3)) * 2u;
+        aof[q] = ((unsigned)min(m0 + ra, g.M - 1) * (unsigned)g.lda + ((sslot ^ ((ra >> 1) & 7)) << 3)) * 2u;
     }
     const char *Wb = reinterpret_cast<const char *>(g.W), *Ab = reinterpret_cast<const char *>(g.A);
-    const int sdst = wave * 4096;  // wave-uniform byte offset inside an operand tile
+    const int sdst = wave * 4096, sdsta = wave * (AU * 1024);  // wave-uniform byte offsets inside the operand tiles
 #define G256_STAGE(buf, kt, u)                                                                                                   \
     do {                                                                                                                         \
-        unsigned char *tb = smem + (buf) * (WT + AT) + ((u) >= 4 ? WT : 0) + sdst + ((u) & 3) * 1024;                            \
+        unsigned char *tb = smem + (buf) * (WT + AT) + ((u) >= 4 ? WT + sdsta : sdst) + ((u) & 3) * 1024;                        \
         const char *src = ((u) >= 4 ? Ab + aof[(u) & 3] : Wb + woff[(u) & 3]) + (size_t)(kt) * (BK * 2);                         \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)tb, 16, 0, 0);                                               \
     } while (0)
 
     const int nk = g.K / BK;
-    // prologue: K-tile 0 entirely, units 0 - 5 of K-tile 1 (its units 6, 7 are issued by phase 0 of K-tile 0 like everyone's)
+    // prologue: K-tile 0 entirely, units 0 - 5 of K-tile 1 (its last one or two are issued by phase 0 of K-tile 0 like everyone's)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) G256_STAGE(0, 0, u);
+    for (int u = 0; u < NU; ++u) G256_STAGE(0, 0, u);
     if (nk > 1) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) G256_STAGE(1, 1, u);
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             const float inv_slots = 1.0f / (float)g.ln_slots;
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const int m = min(m0 + wc * 64 + j * 16 + fr, g.M - 1);
+                const int m = min(m0 + wc * WROWS + j * 16 + fr, g.M - 1);
                 const float2 *sp = reinterpret_cast<const float2 *>(g.ln_stats) + m;
                 float2 sv[MAXU];
 #pragma unroll
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                 m2 += __shfl_xor(m2, 32, 64);
                 ln_mean[j] = mean;
                 ln_rstd[j] = rsqrtf(m2 * inv_slots * (1.0f / LN_SLOT) + g.ln_eps);
-                if (fq == 0) xch[wc * 64 + j * 16 + fr] = make_float2(ln_mean[j], ln_rstd[j]);
+                if (fq == 0) xch[wc * WROWS + j * 16 + fr] = make_float2(ln_mean[j], ln_rstd[j]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         if (wr == 1) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const float2 v = xch[wc * 64 + j * 16 + fr];
+                const float2 v = xch[wc * WROWS + j * 16 + fr];
                 ln_mean[j] = v.x;
                 ln_rstd[j] = v.y;
             }
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) aoff[i] = lds_off(wr * 128 + i * 16 + fr, fq);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) boff[j] = WT + lds_off(wc * 64 + j * 16 + fr, fq);
+    for (int j = 0; j < 2; ++j) boff[j] = WT + lds_off(wc * WROWS + j * 16 + fr, fq);
     bf16x8_t af[4][2], bq[4][2];  // af: the current A half; bq[0..1]: B0, bq[2..3]: B1
 #define G256_LDA(buf, ih, i, ks) af[i][ks] = *reinterpret_cast<const bf16x8_t *>(smem + (buf) * (WT + AT) + (ih) * 8192 + (aoff[i] ^ ((ks) << 6)))
 #define G256_LDB(buf, jh, j, ks) bq[2 * (jh) + (j)][ks] = *reinterpret_cast<const bf16x8_t *>(smem + (buf) * (WT + AT) + (jh) * 4096 + (boff[j] ^ ((ks) << 6)))
@@ -650,8 +657,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             for (int i = 0; i < 4; ++i) {
                 G256_MF(0, 0, i, 0, ks);
                 G256_MF(0, 0, i, 1, ks);
-                if (i < 2) G256_LDB(buf, 1, i, ks);
-                if (ks == 0 && i >= 2 && MORE1) G256_STAGE(nbuf, kt + 1, 4 + i);
+                if (i < JB1) G256_LDB(buf, 1, i, ks);
+                if (ks == 0 && i >= 2 && 4 + i < NU && MORE1) G256_STAGE(nbuf, kt + 1, 4 + i);
                 G256_FENCE;
             }
         // ---- phase 1: Q(A0, B1); every A0 fragment is replaced by its A1 successor right after its last MFMA
@@ -660,7 +667,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 G256_MF(0, 1, i, 0, ks);
-                G256_MF(0, 1, i, 1, ks);
+                if (JB1 == 2) G256_MF(0, 1, i, 1, ks);
                 G256_LDA(buf, 1, i, ks);
                 G256_FENCE;
             }
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 G256_MF(1, 1, i, 0, ks);
-                G256_MF(1, 1, i, 1, ks);
+                if (JB1 == 2) G256_MF(1, 1, i, 1, ks);
                 if (ks == 0 && i < 3 && MORE2) G256_STAGE(buf, kt + 2, i);
                 G256_FENCE;
             }
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             const float4 cv = *reinterpret_cast<const float4 *>(csp + wv), cg = *reinterpret_cast<const float4 *>(csp + g.N + wv);
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const int m = m0 + wc * 64 + j * 16 + fr;
+                const int m = m0 + wc * WROWS + j * 16 + fr;
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             const bool tpart = n >= g.n_split;  // wave-uniform per sub-tile (n_split is a multiple of 16)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                const int m = m0 + wc * 64 + j * 16 + fr;
+                const int m = m0 + wc * WROWS + j * 16 + fr;
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -904,10 +911,21 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                           (epilogue == SCULPT_EPI_GEGLU || epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_GELU) &&
                           n_split % 16 == 0 && (long)w_rows * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L && (p256 >= 2 || pays);
         if (fits) {
-            const dim3 grid(N / nout, cdiv(M, 256));
-            if (epilogue == SCULPT_EPI_GEGLU) hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_GEGLU>), grid, dim3(512), 0, st, g);
-            else if (epilogue == SCULPT_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_GELU>), grid, dim3(512), 0, st, g);
-            else hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_NONE>), grid, dim3(512), 0, st, g);
+            // 192-row tiles (SCULPT_GEMM_192=1; 16 instead of 12 row tiles for 3072 rows: FF1 becomes 512 tiles = two full rounds):
+            // measured 61.0 vs 62.2 us on FF1 and 32.5 vs 35.5 on the fused QKV against the 128-row tiles, within the box-to-box
+            // spread, so the default keeps 256 rows and the rule above
+            const char *e192 = getenv("SCULPT_GEMM_192");
+            const bool bm192 = e192 && atoi(e192) != 0;
+            const dim3 grid(N / nout, bm192 ? cdiv(M, 192) : cdiv(M, 256));
+#define SCULPT_G256(E)                                                                                     \
+    do {                                                                                                   \
+        if (bm192) hipLaunchKernelGGL((gemm256_kernel<E, 192>), grid, dim3(512), 0, st, g);                \
+        else hipLaunchKernelGGL((gemm256_kernel<E, 256>), grid, dim3(512), 0, st, g);                      \
+    } while (0)
+            if (epilogue == SCULPT_EPI_GEGLU) SCULPT_G256(SCULPT_EPI_GEGLU);
+            else if (epilogue == SCULPT_EPI_GELU) SCULPT_G256(SCULPT_EPI_GELU);
+            else SCULPT_G256(SCULPT_EPI_NONE);
+#undef SCULPT_G256
             SC_LAUNCH_CHECK();
             return 0;
         }

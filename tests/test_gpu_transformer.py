@@ -182,9 +182,11 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_128_row_tiles(cuda, monkeyp
 
     ref = run("0")
     assert torch.isfinite(ref[1].float()).all()
-    for rep in range(6):
-        got = run("2")
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), rep
+    for bm192 in ("0", "1"):  # 256- and 192-row tiles
+        monkeypatch.setenv("SCULPT_GEMM_192", bm192)
+        for rep in range(5):
+            got = run("2")
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (bm192, rep)
 
 
 def test_gemm_gelu_and_geglu_epilogues(cuda):

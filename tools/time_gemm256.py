@@ -31,8 +31,9 @@ def case(name, M, K, N, epi, split=0):
     res = {}
     outs = {}
     for rnd in range(4):
-        for mode in ("0", "2"):
-            os.environ["SCULPT_GEMM_256"] = mode
+        for mode in ("0", "2", "192"):
+            os.environ["SCULPT_GEMM_256"] = "2" if mode == "192" else mode
+            os.environ["SCULPT_GEMM_192"] = "1" if mode == "192" else "0"
             for _ in range(3): f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,15 +42,15 @@ def case(name, M, K, N, epi, split=0):
             e1.record(); torch.cuda.synchronize()
             res.setdefault(mode, []).append(e0.elapsed_time(e1) / 20 * 1e3)
             outs[mode] = (o.clone(), None if ot is None else ot.clone())
-    same = torch.equal(outs["0"][0], outs["2"][0]) and (ot is None or torch.equal(outs["0"][1], outs["2"][1]))
+    same = all(torch.equal(outs["0"][0], outs[m][0]) and (ot is None or torch.equal(outs["0"][1], outs[m][1])) for m in ("2", "192"))
     fl = 2.0 * M * rows * K
-    t0, t2 = np.median(res["0"]), np.median(res["2"])
-    print("%-28s M=%d K=%d N=%d: 128-row tiles %.1f us (%.0f TF/s) | 256^2 tiles %.1f us (%.0f TF/s) | identical output: %s"
-          % (name, M, K, N, t0, fl / t0 / 1e6, t2, fl / t2 / 1e6, same))
+    t0, t2, t3 = np.median(res["0"]), np.median(res["2"]), np.median(res["192"])
+    print("%-28s M=%d K=%d N=%d: 128-row tiles %.1f us (%.0f TF/s) | 256 x 256 %.1f us (%.0f TF/s) | 192 x 256 %.1f us (%.0f TF/s) | identical outputs: %s"
+          % (name, M, K, N, t0, fl / t0 / 1e6, t2, fl / t2 / 1e6, t3, fl / t3 / 1e6, same))
 
 
 case("FF1 + GEGLU", 3072, 1024, 4096, _lib.EPI_GEGLU)
 case("fused Q|K|V^T", 3072, 1024, 3072, _lib.EPI_NONE, split=2048)
 case("cross-attention q", 3072, 1024, 1024, _lib.EPI_NONE)
 case("K/V of all layers", 1025, 768, 32768, _lib.EPI_NONE, split=16384)
-case("ViT MLP 1 + GELU", 1025, 768, 3072, _lib.EPI_GELU)
+case("SF3D FF1 + GEGLU", 27648, 1024, 4096, _lib.EPI_GEGLU)
