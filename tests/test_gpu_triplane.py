@@ -199,6 +199,29 @@ def test_density_grid_bf16l3_vs_oracle(cuda, R):
     np.testing.assert_allclose(np.log(out), np.log(ref), rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("n_hidden_layers", [1, 2, 3, 5])
+def test_density_grid_bf16l3_other_depths(cuda, n_hidden_layers):
+    """Decoders with 0 / 1 / 2 / 4 hidden 64x64 layers (the three-limb kernel's layer loop, its fragment prefetch past the last
+    layer, and the no-hidden-layer case that falls back to the fp32 kernel) against the oracle, every mode and kernel form."""
+    from sculptmate_amd import ops
+
+    R = 33
+    Ws, bs = synth.decoder_lists(synth.decoder_state(seed=20 + n_hidden_layers, n_hidden_layers=n_hidden_layers))
+    mlp = ops.PackedMLP(Ws, bs, cuda)
+    tri_np = synth.smooth_triplane(seed=21, scale=3.0)
+    tri = torch.from_numpy(tri_np).to(cuda)
+    ref = np.log(capi.density_grid(tri_np, Ws, bs, R))
+    for prec in ("fp32", "bf16l3"):
+        out = ops.density_grid(tri, mlp, R, precision=prec).cpu().numpy()
+        np.testing.assert_allclose(np.log(out), ref, rtol=0, atol=5e-5, err_msg=prec)
+    os.environ["SCULPT_DENSITY_L3_KSTEP"] = "0"   # the phase-separated form of the same arithmetic
+    try:
+        out0 = ops.density_grid(tri, mlp, R, precision="bf16l3").cpu().numpy()
+    finally:
+        del os.environ["SCULPT_DENSITY_L3_KSTEP"]
+    np.testing.assert_allclose(np.log(out0), ref, rtol=0, atol=5e-5)
+
+
 def test_density_grid_bf16l3_full_size_error_not_above_fp32_kernel(cuda):
     """256^3 (BASELINE config 2 size): deterministic, slabs bitwise consistent, and the measured max |log d - log d_oracle|
     on 200k sampled lattice points is not above the exact-fp32 kernel's own on the same points."""
