@@ -19,15 +19,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "attention_tile.h"
 
 namespace sculpt {
-
-typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 abf16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void *alds_ptr_t;
-typedef const __attribute__((address_space(1))) void *agbl_ptr_t;
-
-__device__ __forceinline__ int a_lds_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 // One workgroup = 2*NQB waves = NQB*32 queries of one head.  Wave w: query block qi = w % NQB (32 queries),
 // key half kh = w / NQB.  Each iteration stages a PAIR of 64-key tiles; the kh = 0 waves consume the first, the
@@ -41,23 +35,7 @@ __device__ __forceinline__ int a_lds_off(int r, int c) { return r * 128 + ((c ^ 
 // Register budget is 128 VGPRs (4 waves per SIMD): everything address-like that is wave-uniform lives in SGPRs
 // (the staging source is a scalar base plus one of four per-lane 32-bit offsets), because a single spill puts a
 // scratch load -- and with it an s_waitcnt vmcnt(0) that also waits for the LDS-DMA prefetch -- into the loop.
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;  // v_max3_f32 without the canonicalising v_max(x, x) the compiler adds around fmaxf of MFMA results
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 typedef float af32x2 __attribute__((ext_vector_type(2)));
-
-// PRE: Q already carries softmax_scale * log2(e) (folded into the projection that produced it, before its bf16 rounding), so
-// the MFMA result is the exponent of 2 directly, and the running maximum M is subtracted INSIDE the matrix product: a fifth
-// k-step multiplies a constant [1, 1, 0, ...] row fragment with (-M_hi, -M_lo, 0, ...) on the query's lane, M = M_hi + M_lo
-// split into two bf16 values (16 significant bits; M itself is kept quantised to that sum, so the rescale factors stay
-// exact).  That removes the `s * scale - m * scale` v_pk_fma of every score -- the loop is VALU-bound (640 VALU vs 512 MFMA
-// cycles per 64-key tile and wave), FMA-class VALU does not overlap the MFMAs of a co-resident wave -- for 2 more of the 16
-// MFMAs per tile.  M is allowed to lag the true maximum by up to PRE_THR (p <= 2^PRE_THR: bf16 keeps its relative precision,
-// the sums are fp32), so the rescale branch is taken on the first tile and then only on a jump of more than 2^PRE_THR.
-static constexpr float PRE_THR = 10.0f;
 
 template <int NQB, bool PRE = false>
 __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t *__restrict__ Q, int ldq,
@@ -372,7 +350,11 @@ static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int l
     const dim3 grid(cdiv(Tq, 32 * nqb), heads), block(128 * nqb);
 #define SCULPT_ATTN_LAUNCH(NQB, PRE, SC) \
     hipLaunchKernelGGL((attention_kernel<NQB, PRE>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, SC)
-    if (prescaled) {  // Q carries scale * log2(e) already
+    const char *epipe = getenv("SCULPT_ATTN_PIPE");  // 0: the phase-separated loop for pre-scaled queries too (A/B); read per call
+    const bool pipe = prescaled && nqb != 8 && !(epipe && atoi(epipe) == 0);
+    if (pipe) {
+        attention_pipe_launch(nqb, grid, block, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk);
+    } else if (prescaled) {  // Q carries scale * log2(e) already
         if (nqb == 8) SCULPT_ATTN_LAUNCH(8, true, 1.0f);
         else if (nqb == 6) SCULPT_ATTN_LAUNCH(6, true, 1.0f);
         else SCULPT_ATTN_LAUNCH(4, true, 1.0f);
