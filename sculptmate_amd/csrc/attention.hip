@@ -342,7 +342,10 @@ static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int l
     long best = cost8 * 100;
     for (int c : {6, 4}) {
         const long wgs = (long)cdiv(Tq, 32 * c) * heads, cost = cdiv(wgs, (long)num_cus()) * c;
-        if (cost * 115 < best) { best = cost * 115; nqb = c; }
+        // pre-scaled queries run the pipelined loop at 128 / 192 queries (attention_pipe.hip: ~0.85 of the time per unit) -- SF3D's
+        // 27 648 x 3089: 373 us with 192 (54 units) against 393 us with 256 (56 units)
+        const long w = prescaled ? 98 : 115;
+        if (cost * w < best) { best = cost * w; nqb = c; }
     }
     if (force == 4 || force == 6 || force == 8) nqb = force;
     const float sl = scale * 1.44269504088896340736f;

@@ -150,6 +150,41 @@ def test_attention_prescaled_q_with_forced_rescales(cuda, Tq, Tk, heads):
     assert float((o2.double().cpu() - ref).norm() / ref.norm()) < 8e-3
 
 
+@pytest.mark.parametrize("Tq,heads", [(3072, 16), (1025, 12), (130, 2)])
+def test_attention_pipelined_loop_against_the_phase_separated_loop(cuda, monkeypatch, Tq, heads):
+    """attention_pipe_kernel (pre-scaled queries: softmax of tile t in the MFMA shadows of the scores of t + 1 and of P.V of t, K
+    rows read in a permuted order, one score tile computed ahead) against attention_kernel<., true> (SCULPT_ATTN_PIPE=0) and the
+    fp64 softmax of the same bf16 operands -- at every key count around the tile boundaries: the look-ahead tile is missing,
+    ragged, belongs to the other key half only, or is a complete pair."""
+    from sculptmate_amd import ops
+
+    D = heads * 64
+    g = torch.Generator().manual_seed(Tq + heads)
+    c = 0.125 * 1.4426950408889634
+    for Tk in (1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 384, 385, 1025):
+        qs = (torch.randn(Tq, D, generator=g) * c).to(BF).to(cuda)
+        kf = torch.randn(Tk, D, generator=g)
+        kf[Tk - 1, :64] *= 6.0                     # a late maximum jump in head 0: the rescale decided one tile ahead
+        k = kf.to(BF).to(cuda)
+        vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=cuda)
+        vt[:, :Tk] = torch.randn(Tk, D, generator=g).to(BF).t().to(cuda)
+        outs = []
+        for pipe in ("1", "0"):
+            monkeypatch.setenv("SCULPT_ATTN_PIPE", pipe)   # read per call
+            o = torch.full((Tq, D), float("nan"), dtype=BF, device=cuda)
+            ops.attention(qs, k, vt, o, Tq, Tk, heads, None)
+            outs.append(o.double().cpu())
+        qh = qs.double().cpu().view(Tq, heads, 64).transpose(0, 1)
+        kh = k.double().cpu().view(Tk, heads, 64).transpose(0, 1)
+        vh = vt[:, :Tk].t().double().cpu().view(Tk, heads, 64).transpose(0, 1)
+        ref = (torch.softmax(qh @ kh.transpose(1, 2) * math.log(2.0), -1) @ vh).transpose(0, 1).reshape(Tq, D)
+        for o in outs:
+            assert torch.isfinite(o).all(), Tk
+            assert float((o - ref).norm() / ref.norm()) < 4e-3, Tk
+            assert float((o - ref).abs().max()) < 0.05, Tk
+        assert float((outs[0] - outs[1]).abs().max()) < 0.04, Tk   # both round p and O to bf16; the row sums differ in order
+
+
 @pytest.mark.parametrize("M,K,N,epi,split", [(3072, 1024, 4096, 2, 0), (3072, 1024, 3072, 0, 2048), (1025, 768, 2304, 0, 1536),
                                              (300, 128, 512, 1, 0), (517, 64, 256, 0, 0)])
 def test_gemm256_tile_kernel_is_bit_identical_to_the_128_row_tiles(cuda, monkeypatch, M, K, N, epi, split):
