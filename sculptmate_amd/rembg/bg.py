@@ -1,7 +1,8 @@
 """Background removal entry point with the signature and results of the reference's `rembg.bg.remove`
 (rembg/bg.py:149-238), running U^2-Net on the MI355X.  Cut-outs are assembled with the same PIL primitives the
-reference uses, so given the same mask the pixels are identical (tests/golden/rembg_prepost.npz).  Alpha matting
-(pymatting) and `post_process_mask` (OpenCV morphology) are outside this package and raise."""
+reference uses, so given the same mask the pixels are identical (tests/golden/rembg_prepost.npz).  `post_process_mask` is
+restated in numpy from the three OpenCV calls the reference makes (OpenCV is not in this image: that piece is parity-unpinned,
+tested against scipy.ndimage); alpha matting (pymatting's closed-form solver) is outside this package and raises."""
 import io
 from enum import Enum
 from typing import Any, List, Optional, Tuple, Union
@@ -58,6 +59,50 @@ def fix_image_orientation(img: Image.Image) -> Image.Image:
     return ImageOps.exif_transpose(img)
 
 
+# ------------------------------------------------------------------------------------------------ mask post-processing
+_GAUSS5_SIGMA2_Q8 = np.array([39, 57, 64, 57, 39], dtype=np.int64)  # exp(-x^2 / 8) / sum, x = -2..2, in 1/256 (sums to 256)
+
+
+def _shift_fill(a: np.ndarray, dy: int, dx: int, fill: int) -> np.ndarray:
+    """a moved by (dy, dx) with `fill` where the source lies outside the image."""
+    out = np.full_like(a, fill)
+    h, w = a.shape
+    ys, yd = (slice(0, h - dy), slice(dy, h)) if dy >= 0 else (slice(-dy, h), slice(0, h + dy))
+    xs, xd = (slice(0, w - dx), slice(dx, w)) if dx >= 0 else (slice(-dx, w), slice(0, w + dx))
+    out[yd, xd] = a[ys, xs]
+    return out
+
+
+def post_process(mask: np.ndarray) -> np.ndarray:
+    """The reference's mask clean-up (rembg/bg.py:98-108), uint8 [H, W] -> uint8 {0, 255}:
+      1. morphological opening with the 3 x 3 elliptic structuring element -- which at that size is the 4-neighbour cross --
+         erosion then dilation, pixels outside the image never winning (OpenCV's default morphology border);
+      2. 5 x 5 Gaussian blur, sigma 2, mirrored border without the edge pixel (BORDER_REFLECT_101), in the 8-bit fixed-point form
+         OpenCV uses for uint8 images: weights [39 57 64 57 39] / 256 per axis, one rounding at the end;
+      3. threshold: below 127 -> 0, else 255.
+    Restated from the published behaviour of morphologyEx / GaussianBlur; cv2 is not available here to pin it."""
+    m = np.ascontiguousarray(mask)
+    if m.ndim != 2:
+        raise ValueError("post_process expects a single-channel mask")
+    m = m.astype(np.uint8)
+    cross = ((0, 0), (-1, 0), (1, 0), (0, -1), (0, 1))
+    er = m
+    for dy, dx in cross[1:]:
+        er = np.minimum(er, _shift_fill(m, dy, dx, 255))
+    op = er
+    for dy, dx in cross[1:]:
+        op = np.maximum(op, _shift_fill(er, dy, dx, 0))
+    acc = op.astype(np.int64)
+    for axis in (1, 0):  # rows, then columns; reflect-101 padding of two pixels
+        pad = [(0, 0), (0, 0)]
+        pad[axis] = (2, 2)
+        padded = np.pad(acc, pad, mode="reflect") if acc.shape[axis] > 1 else np.pad(acc, pad, mode="edge")
+        n = acc.shape[axis]
+        acc = sum(int(w) * np.take(padded, range(k, k + n), axis=axis) for k, w in enumerate(_GAUSS5_SIGMA2_Q8))
+    blurred = (acc + 32768) >> 16
+    return np.where(blurred < 127, 0, 255).astype(np.uint8)
+
+
 # ------------------------------------------------------------------------------------------------ entry point
 def _decode(data) -> Tuple[ReturnType, Image.Image]:
     if isinstance(data, Image.Image):
@@ -88,13 +133,13 @@ def remove(data: Union[bytes, Image.Image, np.ndarray], alpha_matting: bool = Fa
     kind, img = _decode(data)
     if alpha_matting:
         raise NotImplementedError("alpha matting needs pymatting (not part of this package)")
-    if post_process_mask:
-        raise NotImplementedError("post_process_mask needs OpenCV morphology (not part of this package)")
     as_alpha = kwargs.pop("putalpha", False)
     img = fix_image_orientation(img)
     session = session if session is not None else new_session("u2net", *args, **kwargs)
     pieces = []
     for mask in session.predict(img, *args, **kwargs):
+        if post_process_mask:
+            mask = Image.fromarray(post_process(np.array(mask)))
         if only_mask:
             pieces.append(mask)
         else:
