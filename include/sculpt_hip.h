@@ -47,6 +47,9 @@ extern "C" {
 typedef void *sculpt_stream_t;
 
 int sculpt_version(void);
+/* sha256 (first 32 hex digits) of the HIP sources, headers and compile flags this library was built from
+ * (sculptmate_amd/build.py: source_digest); "unknown" when built by hand without -DSCULPT_SOURCE_DIGEST. */
+const char *sculpt_source_digest(void);
 const char *sculpt_last_error(void);
 /* number of visible HIP devices (0 if none); never fails */
 int sculpt_device_count(void);

@@ -23,7 +23,39 @@ if not os.path.exists(SO_PATH):
         "sculptmate_amd: %s is missing -- build it with `python -m sculptmate_amd.build` "
         "(or __graft_entry__.build()); there is no CPU fallback." % SO_PATH)
 
-lib = ctypes.CDLL(SO_PATH)
+
+def _load_matching_library():
+    """Load the library and make sure it was built from the sources it sits beside (sculpt_source_digest(), compared by content).
+    A stale library is rebuilt once, under a file lock (N ranks may import at the same time); if that is not possible the import
+    fails -- never a silently outdated kernel.  SCULPT_ALLOW_STALE_LIB=1 skips the check (debugging a hand-built .so)."""
+    from . import build as _build
+
+    if os.environ.get("SCULPT_ALLOW_STALE_LIB") == "1":
+        return ctypes.CDLL(SO_PATH)
+    want = _build.source_digest()
+    if _build.built_digest() != want:
+        import fcntl
+        import sys
+
+        with open(SO_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if _build.built_digest() != want:  # nobody rebuilt it while we waited
+                sys.stderr.write("sculptmate_amd: libsculpt_hip.so does not match the HIP sources beside it -- rebuilding\n")
+                _build.build()
+    handle = ctypes.CDLL(SO_PATH)
+    try:
+        fn = handle.sculpt_source_digest
+    except AttributeError:
+        raise ImportError("sculptmate_amd: %s predates sculpt_source_digest(); rebuild with `python -m sculptmate_amd.build --force`" % SO_PATH)
+    fn.restype = ctypes.c_char_p
+    have = (fn() or b"").decode()
+    if have != want:
+        raise ImportError("sculptmate_amd: %s was built from other sources (digest %s, sources %s); rebuild with "
+                          "`python -m sculptmate_amd.build --force`" % (SO_PATH, have, want))
+    return handle
+
+
+lib = _load_matching_library()
 
 _vp, _i, _i64, _f, _sz, _u = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float,
                               ctypes.c_size_t, ctypes.c_uint)
@@ -34,6 +66,7 @@ _pi64 = ctypes.POINTER(ctypes.c_int64)
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "sculpt_version": (_i, []),
+    "sculpt_source_digest": (ctypes.c_char_p, []),
     "sculpt_last_error": (ctypes.c_char_p, []),
     "sculpt_device_count": (_i, []),
     "sculpt_stream_create_cu_mask": (_i, [_i, _i, _pp]),

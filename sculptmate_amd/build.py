@@ -35,8 +35,45 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 kernels)")
 
 
+def source_digest(flags_text=None):
+    """sha256 over every HIP source, header and the compile flags: what the library was built FROM.  It is compiled into the
+    library (sculpt_source_digest(), csrc/api.hip) and written beside it, so that a stale .so is detected by content, not by
+    file times (a snapshot copy does not keep them), and `_lib` refuses a library that does not match the sources it sits in."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(_deps(), key=lambda q: os.path.basename(q)):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update((flags_text if flags_text is not None else _flags_text()).encode())
+    return h.hexdigest()[:32]
+
+
+def _flags():
+    extra = os.environ.get("SCULPT_EXTRA_HIPCC_FLAGS", "").split()
+    return ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wno-unused-result"] + extra
+
+
+def _flags_text():
+    return " ".join(_flags()) + " | " + repr(sorted(PER_FILE_FLAGS.items()))
+
+
+DIGEST_FILE = SO + ".digest"
+
+
+def built_digest():
+    """The digest recorded when the library beside this file was linked ('' if there is none)."""
+    try:
+        with open(DIGEST_FILE) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def is_fresh():
-    return os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in _deps())
+    return os.path.exists(SO) and built_digest() == source_digest()
 
 
 def _headers():
@@ -52,18 +89,20 @@ def build(force=False, verbose=False):
 
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    extra = os.environ.get("SCULPT_EXTRA_HIPCC_FLAGS", "").split()
-    flags = ["-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wno-unused-result"] + extra
+    flags = _flags()
     stamp = os.path.join(objdir, "flags.txt")
-    stamp_text = " ".join(flags) + " | " + repr(sorted(PER_FILE_FLAGS.items()))
+    stamp_text = _flags_text()
     if not os.path.exists(stamp) or open(stamp).read() != stamp_text:
         force = True
+    digest = source_digest(stamp_text)
     hdr_time = max(os.path.getmtime(h) for h in _headers())
     jobs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            jobs.append([hipcc()] + flags + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
+        is_api = os.path.basename(src) == "api.hip"  # carries the digest: recompiled whenever anything changed
+        if force or is_api or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc()] + flags + PER_FILE_FLAGS.get(os.path.basename(src), [])
+                        + (['-DSCULPT_SOURCE_DIGEST="%s"' % digest] if is_api else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -78,6 +117,10 @@ def build(force=False, verbose=False):
     link = [hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", SO + ".tmp"] + objs
     run(link)
     os.replace(SO + ".tmp", SO)
+    with open(DIGEST_FILE, "w") as f:
+        f.write(digest + "\n")
+    if verbose:
+        print("linked %s from %d objects (%d compiled now), source digest %s" % (SO, len(objs), len(jobs), digest))
     return SO
 
 

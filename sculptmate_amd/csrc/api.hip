@@ -32,6 +32,11 @@ extern "C" {
 
 int sculpt_version(void) { return SCULPT_ABI_VERSION; }
 
+#ifndef SCULPT_SOURCE_DIGEST
+#define SCULPT_SOURCE_DIGEST "unknown"
+#endif
+const char *sculpt_source_digest(void) { return SCULPT_SOURCE_DIGEST; }
+
 const char *sculpt_last_error(void) { return sculpt::g_err.c_str(); }
 
 int sculpt_device_count(void) {

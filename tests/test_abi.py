@@ -36,6 +36,19 @@ def test_version_and_error_string():
     assert _lib.lib.sculpt_device_count() >= 0
 
 
+def test_library_was_built_from_the_sources_beside_it():
+    """sculpt_source_digest(): the library carries the sha256 of the HIP sources, headers and flags it was compiled from;
+    `_lib` refuses (or rebuilds) a library that does not match, so a stale kernel cannot be what the tests measured."""
+    from sculptmate_amd import _lib, build
+
+    have = _lib.lib.sculpt_source_digest().decode()
+    assert re.fullmatch(r"[0-9a-f]{32}", have), have
+    assert have == build.source_digest() == build.built_digest()
+    assert build.is_fresh()
+    # the digest moves with any source byte and with the flags
+    assert build.source_digest("other flags") != have
+
+
 def test_no_cpu_fallback_for_cpu_tensors():
     import pytest
     import torch
