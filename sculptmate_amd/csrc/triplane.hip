@@ -645,7 +645,20 @@ __device__ __forceinline__ void split16(const f32x16 &x, tf16x8 hi[2], tf16x8 lo
         lo[q] = __builtin_bit_cast(tf16x8, pl);
     }
 }
+#ifdef SCULPT_L3_SHAPE_EXPERIMENT
+// TIMING EXPERIMENT ONLY (wrong values): every 32x32x16 bf16 MFMA replaced by two 16x16x32 ones of the same FLOPs on the same
+// operand registers -- the wall-clock effect of the small shape on this kernel's real instruction stream, before rewriting it
+__device__ __forceinline__ f32x16 mfma16(tbf16x8 a, tbf16x8 b, f32x16 c) {
+    typedef float f32x4e __attribute__((ext_vector_type(4)));
+    f32x4e lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3]; c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+    return c;
+}
+#else
 __device__ __forceinline__ f32x16 mfma16(tbf16x8 a, tbf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+#endif
 __device__ __forceinline__ f32x16 mfma16(tf16x8 a, tf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <typename V8>  // tbf16x8 (bf16x3) or tf16x8 (fp16x3)
