@@ -104,6 +104,29 @@ def boundary_rate(model, imgs_host, steps):
         prev = cur
     m = prev.result()
     dt = time.perf_counter() - t0
+    # the batch form of the same boundary (TSR.run / run_sharded): the image tokenizer of image i + 1 queued on a second stream
+    # beside the backbone / density grid / marching cubes of image i (TSR.tokens_async), same meshes bit for bit
+    nxt = model.tokens_async(imgs_host[0])
+    prev = None
+    for i in range(4):   # warm-up: streams, token slots
+        cur_tok, nxt = nxt, model.tokens_async(imgs_host[(i + 1) % len(imgs_host)])
+        cur = model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD, tokens=cur_tok)
+        if prev is not None:
+            prev.result()
+        prev = cur
+    prev.result()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    prev = None
+    for i in range(steps):   # the tokens of image `steps` (the look-ahead of the last iteration) are extra work inside the region
+        cur_tok, nxt = nxt, model.tokens_async(imgs_host[(i + 5) % len(imgs_host)])
+        cur = model.run_async(imgs_host[(i + 4) % len(imgs_host)], MC_RES, THRESHOLD, tokens=cur_tok)
+        if prev is not None:
+            prev.result()
+        prev = cur
+    prev.result()
+    torch.cuda.synchronize()
+    dt_look = time.perf_counter() - t1
     # latency of ONE image with nothing to overlap: host image in -> host mesh out
     lat = []
     for i in range(3):
@@ -113,6 +136,9 @@ def boundary_rate(model, imgs_host, steps):
         lat.append((time.perf_counter() - t1) * 1e3)
     return {"entry": "TSR.run_async(host fp32 HWC 512x512 image) -> host (pinned) vertices + int64 faces",
             "meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "latency_ms_single_image": float(np.median(lat)),
+            "tokenizer_lookahead": {"entry": "TSR.tokens_async(image i + 1) beside TSR.run_async(image i, tokens=...) -- what TSR.run / "
+                                             "run_sharded do with several images; same meshes",
+                                    "meshes_per_s": steps / dt_look, "ms_per_step": dt_look / steps * 1e3},
             "h2d_bytes_per_image": int(imgs_host[0].nbytes), "d2h_bytes_per_mesh": int(nbytes)}
 
 

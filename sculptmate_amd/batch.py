@@ -47,12 +47,27 @@ def run_sharded(model, images, mc_resolution=256, threshold=25.0, enable_texture
         if keep:
             local[i] = m
 
-    prev = None
-    for i in mine:
-        im = images[i]() if callable(images[i]) else images[i]
-        cur = (i, model.run_async(im, mc_resolution, threshold, enable_texture))
+    def load(i):
+        return images[i]() if callable(images[i]) else images[i]
+
+    # the image tokenizer of this rank's NEXT image is queued beside the backbone / density grid / marching cubes of the current
+    # one (TSR.tokens_async), and mesh i - 1 is collected while image i runs
+    lookahead = hasattr(model, "tokens_async") and len(mine) > 1
+    prev, im_next, tok_next = None, None, None
+    if lookahead:
+        im_next = load(mine[0])
+        tok_next = model.tokens_async(im_next)
+    for k, i in enumerate(mine):
+        if lookahead:
+            im, tok = im_next, tok_next
+            if k + 1 < len(mine):
+                im_next = load(mine[k + 1])
+                tok_next = model.tokens_async(im_next)
+            cur = (i, model.run_async(im, mc_resolution, threshold, enable_texture, tokens=tok))
+        else:
+            cur = (i, model.run_async(load(i), mc_resolution, threshold, enable_texture))
         if prev is not None:
-            finish(*prev)  # mesh i - 1 is collected while image i runs
+            finish(*prev)
         prev = cur
     if prev is not None:
         finish(*prev)

@@ -129,6 +129,15 @@ class PendingMesh:
         return self._mesh
 
 
+class PendingTokens:
+    """The image tokens of one image, being computed on the tokenizer stream (TSR.tokens_async)."""
+
+    __slots__ = ("ctx", "ready", "_slot")
+
+    def __init__(self, ctx, ready, slot):
+        self.ctx, self.ready, self._slot = ctx, ready, slot
+
+
 class MarchingCubeHelper:
     """tsr/models/isosurface.py:17-54 on the GPU (sculpt_mc_*)."""
 
@@ -463,6 +472,9 @@ class TSR(KernelEngine):
         whose 1025-token launches leave most CUs idle.  Same kernels on the same operands as the sequential calls:
         bit-identical tokens."""
         main = torch.cuda.current_stream(self.device)
+        last_tok = getattr(self, "_tok_last", None)
+        if last_tok is not None:  # tokens_async shares the tokenizer's work buffers: finish it first
+            main.wait_event(last_tok)
         side = getattr(self, "_side_stream", None)
         if side is None:
             side = self._side_stream = torch.cuda.Stream(self.device)
@@ -477,6 +489,59 @@ class TSR(KernelEngine):
         main.wait_event(join)
         st = self._run_blocks(st, ctx, first_self_attention_done=True)
         return self._backbone_tail(st)
+
+    def _preprocess(self, im) -> torch.Tensor:
+        """ImagePreprocessor (tsr/utils.py:62-112): uint8 / PIL -> float / 255 on the host, then the antialiased bilinear resize
+        to cond_image_size on the GPU (sculpt_resize_aa_bilinear)."""
+        size = self.cfg["cond_image_size"]
+        img = self._upload(_to_float_hwc(im)).contiguous()
+        if img.shape[-1] != 3:
+            raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
+        if img.shape[0] != size or img.shape[1] != size:
+            img = ops.resize_aa_bilinear(img, size)
+        return img
+
+    def tokens_async(self, image) -> PendingTokens:
+        """Upload + ImagePreprocessor + DINO image tokenizer of ONE image, queued on a second HIP stream.  The tokenizer is
+        ~1.0 ms of launches of 72 - 200 workgroups that leave most CUs idle; queued here for image i + 1 before the backbone,
+        density grid and marching cubes of image i are queued on the current stream, it runs beside them (11.40 -> 11.08 ms per
+        image, tools/try_vit_prefetch.py) -- same kernels on the same operands, bit-identical tokens.  The tokens land in one
+        of two slots; a slot is rewritten only after the backbone that read it has been through (forward_tokens)."""
+        if self._w is None:
+            raise _lib.SculptError("TSR: call load_state_dict() and to(device) before tokens_async()")
+        tok = getattr(self, "_tok_stream", None)
+        if tok is None:
+            tok = self._tok_stream = torch.cuda.Stream(self.device)
+            self._tok_ring = {"i": 0, "slots": [{"ctx": None, "consumed": None} for _ in range(2)]}
+        slot = self._tok_ring["slots"][self._tok_ring["i"] % 2]
+        self._tok_ring["i"] += 1
+        main = torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(main)  # a serial forward() queued earlier uses the same tokenizer buffers on the current stream
+        with torch.cuda.stream(tok), torch.no_grad():
+            tok.wait_event(fork)
+            if slot["consumed"] is not None:
+                tok.wait_event(slot["consumed"])
+            ctx, _ = self.image_tokens(self._preprocess(image))
+            if slot["ctx"] is None or slot["ctx"].shape != ctx.shape or slot["ctx"].dtype != ctx.dtype:
+                slot["ctx"] = torch.empty_like(ctx)
+            slot["ctx"].copy_(ctx)
+            ready = torch.cuda.Event()
+            ready.record(tok)
+        self._tok_last = ready
+        return PendingTokens(slot["ctx"], ready, slot)
+
+    def forward_tokens(self, tokens: PendingTokens) -> torch.Tensor:
+        """The rest of forward() for one image whose tokens come from tokens_async: backbone + upsampler on the current stream
+        -> scene code fp32 [1, 3, 40, 64, 64]."""
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(tokens.ready)
+        st = self._run_blocks(self._backbone_head(), tokens.ctx)
+        consumed = torch.cuda.Event()
+        consumed.record(main)
+        tokens._slot["consumed"] = consumed
+        _, outb = self._backbone_tail(st)
+        return self.scene_code(outb)[None]
 
     def scene_code(self, tokens_bf16: torch.Tensor):
         """detokenize + TriplaneUpsampleNetwork: tokens [3*S*S, C] -> planes fp32 [3, Co, 2S, 2S]."""
@@ -523,17 +588,9 @@ class TSR(KernelEngine):
                 self.to(device)
             else:
                 raise _lib.SculptError("TSR: call load_state_dict() and to(device) before forward()")
-        size = self.cfg["cond_image_size"]
         codes = []
         for im in _as_image_list(image):
-            # ImagePreprocessor (tsr/utils.py:62-112): uint8/PIL -> float/255 on the host, then the
-            # antialiased bilinear resize to cond_image_size -- on the GPU (sculpt_resize_aa_bilinear)
-            img = self._upload(_to_float_hwc(im)).contiguous()
-            if img.shape[-1] != 3:
-                raise ValueError("TSR.forward expects RGB images (composite RGBA on grey first, preprocessing.py:122)")
-            if img.shape[0] != size or img.shape[1] != size:
-                img = ops.resize_aa_bilinear(img, size)
-            _, outb = self.encode_image(img)
+            _, outb = self.encode_image(self._preprocess(im))
             codes.append(self.scene_code(outb))
         return torch.stack(codes, 0)
 
@@ -611,13 +668,14 @@ class TSR(KernelEngine):
                      None if m.vertex_colors is None else m.vertex_colors.cpu().numpy(), mesh_name)
         return meshes
 
-    def run_async(self, image, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
+    def run_async(self, image, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False, tokens=None):
         """One host image -> PendingMesh.  The image goes host -> HBM, the forward and the mesh extraction are queued on
         the current stream, and the mesh (the reference's `.cpu().numpy()` at system.py:200) is copied device -> pinned
         host memory on a separate copy stream, so the copy of mesh i runs under the kernels of image i + 1.
-        PendingMesh.result() waits for that copy only."""
+        PendingMesh.result() waits for that copy only.  tokens: the PendingTokens of THIS image from tokens_async (then
+        `image` is not touched again): a caller with several images queues the tokens of image i + 1 before this call (run)."""
         with torch.no_grad():
-            codes = self.forward([image], self.device)
+            codes = self.forward([image], self.device) if tokens is None else self.forward_tokens(tokens)
             m = self.extract_meshes(codes, enable_texture, mc_resolution, threshold)[0]
         main = torch.cuda.current_stream(self.device)
         copy = getattr(self, "_copy_stream", None)
@@ -647,8 +705,20 @@ class TSR(KernelEngine):
     def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False) -> List[Mesh]:
         """Headless entry point: images -> list of Mesh with host (NumPy) arrays.  With several images the device -> host
         copy of mesh i overlaps the kernels of image i + 1 (run_async)."""
-        pending = [self.run_async(im, mc_resolution, threshold, enable_texture) for im in _as_image_list(images)]
-        return [p.result() for p in pending]
+        return [p.result() for p in self.run_pipelined(_as_image_list(images), mc_resolution, threshold, enable_texture)]
+
+    def run_pipelined(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
+        """images (host or device) -> list of PendingMesh, with the tokenizer of image i + 1 queued beside the backbone /
+        density grid / marching cubes of image i (tokens_async) and the device -> host copy of mesh i under image i + 1."""
+        images = list(images)
+        if len(images) < 2:
+            return [self.run_async(im, mc_resolution, threshold, enable_texture) for im in images]
+        pending, nxt = [], self.tokens_async(images[0])
+        for i, im in enumerate(images):
+            cur = nxt
+            nxt = self.tokens_async(images[i + 1]) if i + 1 < len(images) else None
+            pending.append(self.run_async(im, mc_resolution, threshold, enable_texture, tokens=cur))
+        return pending
 
 
 def _run_sharded(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False, **kw):

@@ -446,6 +446,44 @@ def test_batch_of_images_equals_one_at_a_time(cuda):
     assert not np.array_equal(batch[0].vertices[:50], batch[1].vertices[:50])  # different images, different meshes
 
 
+def test_tokenizer_lookahead_gives_the_serial_meshes(cuda):
+    """TSR.run on several images queues the image tokenizer of image i + 1 on a second stream beside the backbone / density grid
+    / marching cubes of image i (tokens_async, two token slots).  Same kernels on the same operands: every mesh must equal the
+    one-image-at-a-time result bit for bit -- over more images than slots, in a different order, with serial forward() calls mixed
+    in (they share the tokenizer's work buffers), and for token sets used out of order."""
+    m, sd = _small_model(cuda, seed=45)
+    S = SMALL_CFG["cond_image_size"]
+    imgs = [synth.composite_rgb(synth.image_rgba(seed=90 + i, size=S)) for i in range(7)]
+    from sculptmate_amd import ops
+
+    thr = float(ops.density_grid(m([imgs[0]], device=cuda)[0].contiguous(), m.decoder, 32).median())
+    want = []
+    for im in imgs:
+        w = m.run([im], mc_resolution=32, threshold=thr, enable_texture=True)[0]   # one image: no lookahead
+        want.append((w.vertices.copy(), w.faces.copy(), w.vertex_colors.copy()))
+    assert len({w[0].shape for w in want}) > 1                                      # the images do give different meshes
+
+    def same(got, idx):
+        for g, i in zip(got, idx):
+            assert np.array_equal(want[i][0], g.vertices) and np.array_equal(want[i][1], g.faces) and np.array_equal(want[i][2], g.vertex_colors), i
+
+    same(m.run(imgs, mc_resolution=32, threshold=thr, enable_texture=True), range(7))
+    order = [5, 2, 6, 0, 3]
+    same(m.run([imgs[i] for i in order], mc_resolution=32, threshold=thr, enable_texture=True), order)
+    # serial calls between pipelined ones, and a scene code computed the serial way while tokens are in flight
+    t3 = m.tokens_async(imgs[3])
+    codes_serial = m([imgs[4]], device=cuda)
+    t1 = m.tokens_async(imgs[1])
+    got1 = m.run_async(imgs[1], 32, thr, enable_texture=True, tokens=t1).result()   # the younger token set first
+    got3 = m.run_async(imgs[3], 32, thr, enable_texture=True, tokens=t3).result()
+    same([got1, got3], [1, 3])
+    mesh4 = m.extract_meshes(codes_serial, True, 32, thr)[0]
+    assert np.array_equal(mesh4.vertices.cpu().numpy(), want[4][0]) and np.array_equal(mesh4.faces.cpu().numpy(), want[4][1])
+    # device-resident images take the same path
+    dev_imgs = [torch.from_numpy(im).to(cuda) for im in imgs[:3]]
+    same(m.run(dev_imgs, mc_resolution=32, threshold=thr, enable_texture=True), range(3))
+
+
 def test_run_async_pipeline_and_pinned_buffer_lifetime(cuda):
     """TSR.run_async: several images in flight, results collected later == the one-at-a-time results; and the pinned host
     buffers behind the returned arrays are recycled only when the ARRAYS are gone -- an array kept after its Mesh object was
