@@ -125,3 +125,36 @@ def test_density_grid_random_resolutions(cuda):
         ref = capi.density_grid(tri_np, Ws, bs, R)
         out = ops.density_grid(tri, mlp, R).cpu().numpy()
         assert np.abs(np.log(out) - np.log(ref)).max() < 5e-5, R
+
+
+def test_attention_repeated_launches_are_bit_identical(cuda):
+    """Race screen for the pipelined attention loop (tile DMA issued through inline asm, ring slots refilled one iteration ahead,
+    one barrier per iteration): the same launch repeated must give the same bits every time, while a second stream perturbs the
+    timing.  A stale tile, a slot overwritten early or a missed wait shows up as run-to-run differences (tools/stress_attention.py
+    is the long form)."""
+    from sculptmate_amd import ops
+
+    rng = np.random.default_rng(3)
+    g = torch.Generator().manual_seed(3)
+    noise_stream = torch.cuda.Stream(cuda)
+    na = torch.randn(1024, 1024, device=cuda)
+    shapes = [(3072, 3072, 16), (3072, 1025, 16), (1025, 1025, 12), (3072, 129, 16), (3072, 64, 16), (200, 130, 4)]
+    shapes += [(int(rng.integers(1, 4000)), int(rng.integers(1, 3000)), int(rng.integers(1, 17))) for _ in range(4)]
+    for (Tq, Tk, heads) in shapes:
+        D = heads * 64
+        q = (torch.randn(Tq, D, generator=g) * 0.18).to(BF).to(cuda)
+        k = torch.randn(Tk, D, generator=g).to(BF).to(cuda)
+        vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=cuda)
+        vt[:, :Tk] = torch.randn(D, Tk, generator=g).to(BF).to(cuda)
+        o = torch.empty(Tq, D, dtype=BF, device=cuda)
+        ops.attention(q, k, vt, o, Tq, Tk, heads, None)
+        torch.cuda.synchronize()
+        ref = o.clone()
+        for it in range(40):
+            if it % 3 == 0:
+                with torch.cuda.stream(noise_stream):
+                    torch.mm(na, na)
+            o.fill_(float("nan"))
+            ops.attention(q, k, vt, o, Tq, Tk, heads, None)
+            assert torch.equal(o.view(torch.int16), ref.view(torch.int16)), (Tq, Tk, heads, it)
+        torch.cuda.synchronize()

@@ -42,23 +42,35 @@ with torch.no_grad():
             ev = torch.cuda.Event(); ev.record(side)
         return ev
 
-    def run(n, check=False):
+    def run(n, check=False, late=False):
+        """late: the tokens of image i + 1 start when the density grid of image i starts (beside it, on the CUs a smaller density
+        launch leaves free) instead of when its backbone starts"""
         ev = vit(0)
         for i in range(n):
             main.wait_event(ev)
-            done = torch.cuda.Event()
-            # the next image's tokens may start once this image's backbone has been queued: they share no buffer with it
-            fork = torch.cuda.Event(); fork.record(main)
-            side.wait_event(fork)
-            ev_next = vit(i + 1)
-            m = tail(ctxs[i & 1])
+            if not late:
+                fork = torch.cuda.Event(); fork.record(main)
+                side.wait_event(fork)
+                ev_next = vit(i + 1)
+            st = model._run_blocks(model._backbone_head(), ctxs[i & 1])
+            _, outb = model._backbone_tail(st)
+            codes = model.scene_code(outb)[None]
+            if late:
+                fork = torch.cuda.Event(); fork.record(main)
+                side.wait_event(fork)
+                ev_next = vit(i + 1)
+            m = model.extract_meshes(codes, False, 256, 25.0)
             if check and i == 0:
                 assert torch.equal(m[0].vertices, ref[0].vertices) and torch.equal(m[0].faces, ref[0].faces), "mesh differs"
             ev = ev_next
         torch.cuda.synchronize()
 
-    run(4, check=True)
-    t0 = time.perf_counter()
-    run(N)
-    dt = (time.perf_counter() - t0) / N * 1e3
-    print("ViT of image i+1 on a second stream: %.3f ms / image (x%.3f), mesh identical to the serial path" % (dt, serial / dt))
+    for late in (False, True):
+        for grid in (256, 248, 240, 232, 224, 208, 192):
+            os.environ["SCULPT_DENSITY_L3_GRID"] = str(grid)
+            run(4, check=True, late=late)
+            t0 = time.perf_counter()
+            run(N, late=late)
+            dt = (time.perf_counter() - t0) / N * 1e3
+            print("tokens of image i+1 from the start of image i's %s, density grid on %3d workgroups: %.3f ms / image (x%.3f)"
+                  % ("density grid" if late else "backbone    ", grid, dt, serial / dt), flush=True)
