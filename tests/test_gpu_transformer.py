@@ -635,6 +635,15 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     assert r32 < 3e-2, r32
     ctx, ctx32 = m.image_tokens(torch.from_numpy(img).to(cuda))
     assert _rel(ctx32, col["ctx"])[0] < 2e-2
+    # the tokenizer look-ahead at full size (real launch shapes and timings): several rounds of TSR.run on six images must
+    # reproduce the one-image-at-a-time meshes bit for bit (a race between the two streams would show as a different mesh)
+    six = [synth.composite_rgb(synth.image_rgba(seed=100 + i)) for i in range(6)]
+    thr_l = float(ops.density_grid(codes[0].contiguous(), m.decoder, 64).quantile(0.97))
+    serial = [m.run([im], mc_resolution=64, threshold=thr_l)[0] for im in six]
+    serial = [(w.vertices.copy(), w.faces.copy()) for w in serial]
+    for rnd in range(3):
+        for (wv, wf), got in zip(serial, m.run(six, mc_resolution=64, threshold=thr_l)):
+            assert np.array_equal(wv, got.vertices) and np.array_equal(wf, got.faces), rnd
     # the fp32 parity mode at full size: fp32 rounding only (28 layers deep)
     del m
     torch.cuda.empty_cache()
