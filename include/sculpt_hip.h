@@ -42,7 +42,9 @@
 extern "C" {
 #endif
 
-#define SCULPT_ABI_VERSION 1
+/* 2: sculpt_attention_bf16 no longer takes scale == 0 for pre-scaled queries (sculpt_attention_bf16_prescaled); batched
+ *    attention, host-side PLY face records */
+#define SCULPT_ABI_VERSION 2
 
 typedef void *sculpt_stream_t;
 
@@ -256,6 +258,16 @@ int sculpt_attention_bf16(const uint16_t *Q, int ldq, const uint16_t *K, int ldk
  * product and skips one VALU multiply-add per score (1.1-1.2x faster).  What the bf16 transformers use. */
 int sculpt_attention_bf16_prescaled(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt,
                                     int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads, sculpt_stream_t stream);
+
+/* `batch` independent attentions of the same shape in ONE launch (TSR.forward on a batch of images,
+ * TripoSR/tsr/system.py:82-115: batch_size = rgb_cond.shape[0]; attention.py:629-631 with a leading batch dimension).
+ * Entry b reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs and writes O + b*o_bs (strides in ELEMENTS, multiples of 8; o_bs of 4):
+ * token rows of the entries stacked below each other, V^T either side by side in one [heads*64][ldvt] array (vt_bs = a column
+ * offset, (batch-1)*vt_bs + round_up(Tk,64) <= ldvt) or one array per entry (vt_bs >= heads*64*ldvt).  prescaled != 0: queries
+ * carry softmax_scale * log2(e) (scale ignored), as sculpt_attention_bf16_prescaled; otherwise scale must be positive. */
+int sculpt_attention_bf16_batched(const uint16_t *Q, int ldq, int64_t q_bs, const uint16_t *K, int ldk, int64_t k_bs,
+                                  const uint16_t *Vt, int ldvt, int64_t vt_bs, uint16_t *O, int ldo, int64_t o_bs, int Tq, int Tk,
+                                  int heads, int batch, int prescaled, float scale, sculpt_stream_t stream);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (rows x cols), x fp32 or bf16, y bf16 */
 int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const float *gamma,
@@ -471,6 +483,11 @@ size_t sculpt_mesh_num_vertices(const sculpt_host_mesh_t *m);
 size_t sculpt_mesh_num_faces(const sculpt_host_mesh_t *m);
 int sculpt_mesh_read(const sculpt_host_mesh_t *m, double *V, int32_t *F);
 void sculpt_mesh_free(sculpt_host_mesh_t *m);
+
+/* Mesh hand-off, HOST side (no GPU work): the face block of a binary little-endian PLY file -- per face `uchar 3` followed by
+ * three int32 -- from the int64 faces TSR.run returns (the reference's `t_pos_idx.cpu().numpy()`, TripoSR/tsr/system.py:200).
+ * faces_host int64 [n][3] -> records_host uint8 [n][13].  Thread-safe; callers split n over threads (sculptmate_amd/meshio.py). */
+int sculpt_ply_face_records(const int64_t *faces_host, size_t n, uint8_t *records_host);
 
 #ifdef __cplusplus
 }

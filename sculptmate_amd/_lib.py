@@ -100,6 +100,7 @@ SIGNATURES = {
     "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sculpt_attention_bf16_prescaled": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sculpt_attention_bf16_batched": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _i, _i, _i, _i, _i, _f, _vp]),
     "sculpt_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _vp]),
     "sculpt_groupnorm_tokens": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sculpt_transpose_add": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -141,6 +142,7 @@ SIGNATURES = {
     "sculpt_mesh_num_faces": (_sz, [_vp]),
     "sculpt_mesh_read": (_i, [_vp, _vp, _vp]),
     "sculpt_mesh_free": (None, [_vp]),
+    "sculpt_ply_face_records": (_i, [_vp, _sz, _vp]),
     "rasterize_cpu": (None, [_vp, _sz, _vp, _sz, ctypes.c_longlong, _vp]),
     "interpolate_cpu": (None, [_vp, _sz, _vp, _sz, _vp, ctypes.c_longlong, _vp]),
 }

@@ -76,12 +76,24 @@ def is_fresh():
     return os.path.exists(SO) and built_digest() == source_digest()
 
 
+def _content_hash(paths):
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(paths, key=lambda q: os.path.basename(q)):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def _headers():
     return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "sculpt_hip.h")]
 
 
 def build(force=False, verbose=False):
-    """One object file per .hip source (recompiled only when it or a header changed, up to 8 hipcc processes at a time),
+    """One object file per .hip source (recompiled only when its content, a header or the flags changed, up to 8 hipcc processes at a time),
     then one link.  Objects live in csrc/_obj/ (git-ignored, not needed on the GPU box: the linked .so travels)."""
     if not force and is_fresh():
         return SO
@@ -95,22 +107,36 @@ def build(force=False, verbose=False):
     if not os.path.exists(stamp) or open(stamp).read() != stamp_text:
         force = True
     digest = source_digest(stamp_text)
-    hdr_time = max(os.path.getmtime(h) for h in _headers())
+    hdr_hash = _content_hash(_headers())
     jobs = []
     for src in sources():
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        is_api = os.path.basename(src) == "api.hip"  # carries the digest: recompiled whenever anything changed
-        if force or is_api or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            jobs.append([hipcc()] + flags + PER_FILE_FLAGS.get(os.path.basename(src), [])
-                        + (['-DSCULPT_SOURCE_DIGEST="%s"' % digest] if is_api else []) + ["-c", src, "-o", obj])
+        base = os.path.basename(src)
+        obj = os.path.join(objdir, base[:-4] + ".o")
+        is_api = base == "api.hip"  # carries the digest: recompiled whenever anything changed
+        # An object is reused only when the CONTENT it was compiled from is unchanged (source + every header + flags), recorded
+        # beside it at compile time.  File times are not evidence: a snapshot copy gives old objects new mtimes.
+        want = _content_hash([src]) + hdr_hash + stamp_text + repr(PER_FILE_FLAGS.get(base, []))
+        tag = obj + ".src"
+        have = open(tag).read() if os.path.exists(tag) and os.path.exists(obj) else None
+        if force or is_api or have != want:
+            jobs.append(([hipcc()] + flags + PER_FILE_FLAGS.get(base, [])
+                         + (['-DSCULPT_SOURCE_DIGEST="%s"' % digest] if is_api else []) + ["-c", src, "-o", obj], tag, want))
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
 
+    def compile_one(job):
+        cmd, tag, want = job
+        if os.path.exists(tag):
+            os.remove(tag)
+        run(cmd)
+        with open(tag, "w") as f:
+            f.write(want)
+
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
-        list(ex.map(run, jobs))
+        list(ex.map(compile_one, jobs))
     with open(stamp, "w") as f:
         f.write(stamp_text)
     objs = [os.path.join(objdir, os.path.basename(src)[:-4] + ".o") for src in sources()]

@@ -1,5 +1,6 @@
 // C-ABI plumbing: version, thread-local error string, device query.
 #include <stdarg.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -57,6 +58,17 @@ int sculpt_stream_create_cu_mask(int first_cu, int n_cus, sculpt_stream_t *strea
     hipStream_t st = nullptr;
     SC_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)((total + 31) / 32), mask));
     *stream_out = reinterpret_cast<sculpt_stream_t>(st);
+    return 0;
+}
+
+int sculpt_ply_face_records(const int64_t *faces_host, size_t n, uint8_t *records_host) {
+    SC_REQUIRE(n == 0 || (faces_host && records_host), "ply_face_records: null argument");
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t *r = records_host + 13 * i;
+        const int32_t v[3] = {(int32_t)faces_host[3 * i], (int32_t)faces_host[3 * i + 1], (int32_t)faces_host[3 * i + 2]};
+        r[0] = 3;
+        memcpy(r + 1, v, 12);  // little-endian host (x86-64), unaligned destination
+    }
     return 0;
 }
 

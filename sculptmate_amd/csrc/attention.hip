@@ -42,7 +42,7 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
                                                                   const uint16_t *__restrict__ K, int ldk,
                                                                   const uint16_t *__restrict__ Vt, int ldvt,
                                                                   uint16_t *__restrict__ O, int ldo, int Tq, int Tk,
-                                                                  float scale_log2e) {
+                                                                  float scale_log2e, const AttnBatch ab) {
     constexpr int NW = 2 * NQB;  // waves
     // [stage][K0 | K1 | V0 | V1] sub-tiles of 8 KiB (64 rows x 128 B); reused as merge scratch at the end
     constexpr int SMEM = (NQB * 34 * 64 * 4 > 2 * 4 * 8192) ? NQB * 34 * 64 * 4 : 2 * 4 * 8192;
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
     // each XCD works on whole heads (2 of 16 here): their K/V (0.8 MB per head) stay in that XCD's 4 MB L2 while
     // the head's 24 query blocks re-stage them
     const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int head = tile / gridDim.x;
+    const int bh = tile / gridDim.x, bi = bh / ab.heads;  // scalar: (batch entry, head)
+    const int head = bh - bi * ab.heads;
+    Q += bi * ab.q_bs; K += bi * ab.k_bs; Vt += bi * ab.vt_bs; O += bi * ab.o_bs;
     const int q = (tile % gridDim.x) * (NQB * 32) + qi * 32 + qc;
     const int qld = min(q, Tq - 1);
 
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
                 } else if (vt < ntp) {
                     unsigned char *dst = smem + vbuf * 32768 + sub * 8192 + rg * 1024;
                     const bool last = (vt * 128 + 128 > Tk);
-                    const int col = last ? min(vt * 128 + half * 64, ldvt - 64) : vt * 128 + half * 64;
+                    const int col = last ? min(vt * 128 + half * 64, ab.vt_cols - 64) : vt * 128 + half * 64;  // (columns this ENTRY may read)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (alds_ptr_t)dst, 16, (rg & 1) ? vlane1 : vlane0,
                                                              ((8 * rg) * ldvt + col) * 2, 0, 0);
                 }
@@ -318,13 +320,24 @@ __global__ __launch_bounds__(NQB * 128, 4) void attention_kernel(const uint16_t 
 using namespace sculpt;
 
 static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int ldk, const uint16_t *Vt, int ldvt, uint16_t *O,
-                            int ldo, int Tq, int Tk, int heads, float scale, bool prescaled, sculpt_stream_t stream) {
+                            int ldo, int Tq, int Tk, int heads, float scale, bool prescaled, sculpt_stream_t stream,
+                            int batch = 1, long q_bs = 0, long k_bs = 0, long vt_bs = 0, long o_bs = 0) {
     SC_REQUIRE(Q && K && Vt && O, "attention: null argument");
-    SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
+    SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1 && batch >= 1, "attention: bad shape Tq=%d Tk=%d heads=%d batch=%d", Tq, Tk, heads, batch);
     SC_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attention: row strides must keep 16-byte alignment");
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention: ldvt=%d must be >= round_up(Tk=%d, 64)", ldvt, Tk);
-    // K / V tiles are staged with buffer addressing: 32-bit per-lane byte offsets from the head's base.  Past 2 GiB an offset
-    // wraps or leaves the descriptor's range, and an out-of-range buffer load returns zeros silently -- refuse such shapes.
+    if (batch > 1) {
+        SC_REQUIRE(q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0 && o_bs % 4 == 0 && q_bs >= 0 && k_bs >= 0 && vt_bs >= 0 && o_bs > 0,
+                   "attention: batch strides must keep 16-byte alignment (q %ld, k %ld, vt %ld, o %ld elements)", q_bs, k_bs, vt_bs, o_bs);
+        // V^T of the batch entries: side by side in one [heads * 64][ldvt] array (stride = a column offset) or one array each
+        const long tk64 = (long)((Tk + 63) / 64) * 64;
+        SC_REQUIRE(vt_bs < ldvt ? (batch - 1) * vt_bs + tk64 <= ldvt : vt_bs >= (long)heads * 64 * ldvt,
+                   "attention: V^T batch stride %ld neither keeps %d entries of round_up(Tk, 64) = %ld columns inside ldvt=%d nor skips a whole array",
+                   vt_bs, batch, tk64, ldvt);
+        SC_REQUIRE((long)batch * heads <= 65535, "attention: batch * heads = %ld exceeds the grid", (long)batch * heads);
+    }
+    // K / V tiles are staged with buffer addressing: 32-bit per-lane byte offsets from the (batch entry, head) base.  Past 2 GiB
+    // an offset wraps or leaves the descriptor's range, and an out-of-range buffer load returns zeros silently -- refuse such shapes.
     {
         const long tk128 = (long)((Tk + 127) / 128) * 128;
         SC_REQUIRE(tk128 * ldk * 2 < 0x7fffffffL, "attention: K extent %ld x %d x 2 B is beyond the 2 GiB buffer range", tk128, ldk);
@@ -337,11 +350,12 @@ static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int l
     static const int force = [] { const char *e = getenv("SCULPT_ATTN_NQB"); return e ? atoi(e) : 0; }();
     // (measured: self-attention 51.1 -> 48.8 us, cross 25.2 -> 23.5 us with 192; a smaller workgroup re-stages the head's K / V
     // more often, so it has to win by more than 15 %: SF3D's 27 648 queries, 54 against 56 units, ran 4 % slower with 192)
+    const long bh = (long)heads * batch;
     int nqb = 8;
-    const long cost8 = cdiv((long)cdiv(Tq, 256) * heads, (long)num_cus()) * 8;
+    const long cost8 = cdiv((long)cdiv(Tq, 256) * bh, (long)num_cus()) * 8;
     long best = cost8 * 100;
     for (int c : {6, 4}) {
-        const long wgs = (long)cdiv(Tq, 32 * c) * heads, cost = cdiv(wgs, (long)num_cus()) * c;
+        const long wgs = (long)cdiv(Tq, 32 * c) * bh, cost = cdiv(wgs, (long)num_cus()) * c;
         // pre-scaled queries run the pipelined loop at 128 / 192 queries (attention_pipe.hip: ~0.85 of the time per unit) -- SF3D's
         // 27 648 x 3089: 373 us with 192 (54 units) against 393 us with 256 (56 units)
         const long w = prescaled ? 98 : 115;
@@ -350,13 +364,17 @@ static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int l
     if (force == 4 || force == 6 || force == 8) nqb = force;
     const float sl = scale * 1.44269504088896340736f;
     hipStream_t st = as_stream(stream);
-    const dim3 grid(cdiv(Tq, 32 * nqb), heads), block(128 * nqb);
+    const dim3 grid(cdiv(Tq, 32 * nqb), (unsigned)bh), block(128 * nqb);
+    // the ragged last tile pair clamps its V^T columns to what the entry may read: side by side, the LAST entry's row ends
+    // (batch - 1) * vt_bs columns earlier than ldvt says (a read past it runs into the next row -- past the array on the last one)
+    const int vt_cols = (batch > 1 && vt_bs < ldvt) ? ldvt - (int)((batch - 1) * vt_bs) : ldvt;
+    const AttnBatch ab{heads, vt_cols, q_bs, k_bs, vt_bs, o_bs};
 #define SCULPT_ATTN_LAUNCH(NQB, PRE, SC) \
-    hipLaunchKernelGGL((attention_kernel<NQB, PRE>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, SC)
+    hipLaunchKernelGGL((attention_kernel<NQB, PRE>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, SC, ab)
     const char *epipe = getenv("SCULPT_ATTN_PIPE");  // 0: the phase-separated loop for pre-scaled queries too (A/B); read per call
     const bool pipe = prescaled && nqb != 8 && !(epipe && atoi(epipe) == 0);
     if (pipe) {
-        attention_pipe_launch(nqb, grid, block, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk);
+        attention_pipe_launch(nqb, grid, block, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, ab);
     } else if (prescaled) {  // Q carries scale * log2(e) already
         if (nqb == 8) SCULPT_ATTN_LAUNCH(8, true, 1.0f);
         else if (nqb == 6) SCULPT_ATTN_LAUNCH(6, true, 1.0f);
@@ -382,4 +400,13 @@ extern "C" int sculpt_attention_bf16_prescaled(const uint16_t *Q, int ldq, const
                                                int ldvt, uint16_t *O, int ldo, int Tq, int Tk, int heads,
                                                sculpt_stream_t stream) {
     return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, heads, 1.0f, true, stream);
+}
+
+extern "C" int sculpt_attention_bf16_batched(const uint16_t *Q, int ldq, int64_t q_bs, const uint16_t *K, int ldk, int64_t k_bs,
+                                             const uint16_t *Vt, int ldvt, int64_t vt_bs, uint16_t *O, int ldo, int64_t o_bs,
+                                             int Tq, int Tk, int heads, int batch, int prescaled, float scale,
+                                             sculpt_stream_t stream) {
+    SC_REQUIRE(prescaled || (scale > 0.f && scale == scale), "attention_batched: scale must be positive unless prescaled");
+    return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, heads, prescaled ? 1.0f : scale, prescaled != 0, stream, batch,
+                            (long)q_bs, (long)k_bs, (long)vt_bs, (long)o_bs);
 }

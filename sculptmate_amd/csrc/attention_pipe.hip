@@ -40,7 +40,8 @@ template <int NQB>
 __global__ __launch_bounds__(NQB * 128) void attention_pipe_kernel(const uint16_t *__restrict__ Q, int ldq,
                                                                    const uint16_t *__restrict__ K, int ldk,
                                                                    const uint16_t *__restrict__ Vt, int ldvt,
-                                                                   uint16_t *__restrict__ O, int ldo, int Tq, int Tk) {
+                                                                   uint16_t *__restrict__ O, int ldo, int Tq, int Tk,
+                                                                   const AttnBatch ab) {
     constexpr int NW = 2 * NQB;
     constexpr int SMEM = (NQB * 34 * 64 * 4 > 2 * 4 * 8192) ? NQB * 34 * 64 * 4 : 2 * 4 * 8192;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(NQB * 128) void attention_pipe_kernel(const uint16_
     const int qi = wave % NQB, kh = wave / NQB;
     const int qc = lane & 31, h = lane >> 5;
     const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int head = tile / gridDim.x;
+    const int bh = tile / gridDim.x, bi = bh / ab.heads;  // scalar: (batch entry, head)
+    const int head = bh - bi * ab.heads;
+    Q += bi * ab.q_bs; K += bi * ab.k_bs; Vt += bi * ab.vt_bs; O += bi * ab.o_bs;
     const int q = (tile % gridDim.x) * (NQB * 32) + qi * 32 + qc;
     const int qld = min(q, Tq - 1);
     abf16x8 qf[4];
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(NQB * 128) void attention_pipe_kernel(const uint16_
                 } else if (vt < ntp) {
                     unsigned char *dst = smem + vbuf * 32768 + sub * 8192 + rg * 1024;
                     const bool last = (vt * 128 + 128 > Tk);
-                    const int col = last ? min(vt * 128 + half * 64, ldvt - 64) : vt * 128 + half * 64;
+                    const int col = last ? min(vt * 128 + half * 64, ab.vt_cols - 64) : vt * 128 + half * 64;  // (columns this ENTRY may read)
                     dma16_lds(v_rs, (unsigned)(unsigned long)(alds_ptr_t)dst, (rg & 1) ? vlane1 : vlane0, ((8 * rg) * ldvt + col) * 2);
                 }
             }
@@ -350,10 +353,11 @@ __global__ __launch_bounds__(NQB * 128) void attention_pipe_kernel(const uint16_
     // one iteration: c = S(tp) ready (maximum settled); leaves S(tp+1) in n, ready the same way
     auto body = [&](auto par_t, int tp, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) {
         constexpr int par = decltype(par_t)::value;  // tp & 1: ring slots are compile-time
-        if (tp > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+        // Unconditional, tp == 0 included: the refill below overwrites ring slot `par`, and at tp == 0 that slot holds K(0), which
+        // slower waves may still be reading in the pre-loop qk_plain(0) -- only a barrier AFTER that read orders their ds_reads
+        // against this wave's DMA (one extra barrier per launch).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         // K(tp) [slot par] and V(tp-1) [slot par ^ 1] are dead for every wave: refill them
         if ((tp + 3) * 128 <= Tk) stage_full(par, tp);
         else stage2(par, tp + 2, par ^ 1, tp + 1);
@@ -425,9 +429,9 @@ __global__ __launch_bounds__(NQB * 128) void attention_pipe_kernel(const uint16_
 }
 
 void attention_pipe_launch(int nqb, dim3 grid, dim3 block, hipStream_t st, const uint16_t *Q, int ldq, const uint16_t *K, int ldk,
-                           const uint16_t *Vt, int ldvt, uint16_t *O, int ldo, int Tq, int Tk) {
-    if (nqb == 6) hipLaunchKernelGGL((attention_pipe_kernel<6>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk);
-    else hipLaunchKernelGGL((attention_pipe_kernel<4>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk);
+                           const uint16_t *Vt, int ldvt, uint16_t *O, int ldo, int Tq, int Tk, AttnBatch ab) {
+    if (nqb == 6) hipLaunchKernelGGL((attention_pipe_kernel<6>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, ab);
+    else hipLaunchKernelGGL((attention_pipe_kernel<4>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, ab);
 }
 
 }  // namespace sculpt

@@ -29,8 +29,16 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
 // the sums are fp32), so the rescale branch is taken on the first tile and then only on a jump of more than 2^PRE_THR.
 static constexpr float PRE_THR = 10.0f;
 
+// A batch of independent attentions in one launch (TSR.forward on B images; blockIdx.y = batch * heads + head): element
+// strides from one batch entry to the next -- Q / K / O rows further down, V^T columns further right.
+struct AttnBatch {
+    int heads;
+    int vt_cols;  // V^T columns readable from an entry's first column (ldvt for one entry; ldvt - (batch-1)*vt_bs side by side)
+    long q_bs, k_bs, vt_bs, o_bs;
+};
+
 // attention_pipe.hip: the pipelined loop for pre-scaled queries, 128 (nqb 4) or 192 (nqb 6) queries per workgroup
 void attention_pipe_launch(int nqb, dim3 grid, dim3 block, hipStream_t st, const uint16_t *Q, int ldq, const uint16_t *K, int ldk,
-                           const uint16_t *Vt, int ldvt, uint16_t *O, int ldo, int Tq, int Tk);
+                           const uint16_t *Vt, int ldvt, uint16_t *O, int ldo, int Tq, int Tk, AttnBatch ab);
 
 }  // namespace sculpt

@@ -84,7 +84,26 @@ struct GemmArgs {
     float *stats_out;  // producer side: per-row (mean, M2) of every 32-column slice of the fp32 result, [N/32][stats_ld][2]
     int stats_ld;      // rows per slice plane of both statistics arrays (>= M)
     const float *zeros;  // >= 2N zero floats: stands in for a missing bias / colsum so the epilogue loads are unconditional
+    // Tile order inside an XCD's chunk (0: the 1-D band order chosen by n_major).  gm > 0: tiles are walked in groups of gm
+    // activation-row tiles, weight tile outer, row tile inner (the classic grouped order), so the R workgroups an XCD has
+    // resident at any time form a gm x R/gm block of the tile grid and stream gm row tiles + R/gm weight tiles through its L2
+    // per round, not one row tile + every weight tile (FF1 of a 4-image batch: 6 MB instead of 17 MB per XCD and round).
+    int gm;
 };
+
+// (n tile, m tile) of workgroup-linear index `lin` in a grid of gx weight tiles x gy activation-row tiles
+__device__ __forceinline__ void gemm_tile_of(const GemmArgs &g, int lin, int gx, int gy, int &nt, int &mt) {
+    const int tile = xcd_tile(lin, gx * gy);
+    if (g.gm > 0) {
+        const int per = g.gm * gx, grp = tile / per, first = grp * g.gm, within = tile - grp * per;
+        const int gsz = min(g.gm, gy - first);
+        nt = within / gsz;
+        mt = first + (within - nt * gsz);
+    } else {
+        nt = g.n_major ? tile / gy : tile % gx;
+        mt = g.n_major ? tile % gy : tile / gx;
+    }
+}
 
 static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 tile; one wave of a BW=128 tile)
 
@@ -116,9 +135,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // XCD-aware order: the workgroups of one XCD (private L2) take a contiguous band of the tile grid -- a band of
     // activation rows with every weight tile, or (n_major, when W is the larger operand) a band of weight rows with
     // every activation tile -- so the band's panel is fetched into that L2 once and only the smaller operand streams.
-    const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int n0 = (g.n_major ? tile / gridDim.y : tile % gridDim.x) * NOUT;
-    const int m0 = (g.n_major ? tile % gridDim.y : tile / gridDim.x) * BM;
+    int nt_, mt_;
+    gemm_tile_of(g, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, nt_, mt_);
+    const int n0 = nt_ * NOUT, m0 = mt_ * BM;
 
     // ---- staging addresses.  One wave instruction fills 8 tile rows (1 KiB).  Lane l of the
     // instruction that fills rows 8q..8q+7 writes LDS chunk (row = 8q + l/8, slot = l%8) and must
@@ -524,9 +543,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / NWC, wc = wave % NWC;
     constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? BW / 2 : BW;
-    const int tile = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int n0 = (g.n_major ? tile / gridDim.y : tile % gridDim.x) * NOUT;
-    const int m0 = (g.n_major ? tile % gridDim.y : tile / gridDim.x) * BM;
+    int nt_, mt_;
+    gemm_tile_of(g, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, nt_, mt_);
+    const int n0 = nt_ * NOUT, m0 = mt_ * BM;
 
     // staging: wave w fills rows 32 w .. 32 w + 31 of both operand tiles, 8 rows (1 KiB) per wave instruction; the LDS image is
     // lane-linear, the (row >> 1) & 7 chunk swizzle is applied to the per-lane SOURCE address and to the read address
@@ -895,6 +914,20 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     }
     const int mt = cdiv(M, BM_DEFAULT);
     hipStream_t st = as_stream(stream);
+    // Grouped tile order (GemmArgs::gm): group height ~ sqrt(R * weight rows per tile / activation rows per tile) with R the
+    // workgroups an XCD keeps resident (32 CUs x 1 or 2), as a power of two; launches whose tiles are all resident at once (or
+    // whose grid is shorter than two groups) keep the band order.  SCULPT_GEMM_GM=0 restores the band order everywhere (A/B),
+    // =n forces a group height; read per call.
+    auto group_rows = [&](int w_rows_tile, int a_rows_tile, int wg_per_cu, long tiles, int gy) -> int {
+        const char *e = getenv("SCULPT_GEMM_GM");
+        const int forced = e ? atoi(e) : -1;
+        if (forced >= 0) return forced;
+        const long R = 32L * wg_per_cu;
+        if (tiles <= 8 * R) return 0;
+        int gmv = 1;
+        while ((long)(2 * gmv) * (2 * gmv) * a_rows_tile <= R * w_rows_tile * 2) gmv *= 2;   // gm^2 ~ R * bw / bm, rounded up in log2
+        return gy >= 2 * gmv ? gmv : 0;
+    };
     // The 256 x 256 tile (gemm256_kernel) where it wins: launches of at least two full rounds of CUs -- StableFast-3D's 27 648-token
     // FF1 + GEGLU (622 -> 500 us), wide plain projections (8192 x 8192 x 1024: 205 -> 168 us).  Its K loop runs at 1.14 us per
     // K-tile (80 % of the matrix peak at two waves per SIMD), but a tile costs ~10-14 us besides (pipeline fill, and an epilogue
@@ -902,21 +935,26 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     // TripoSR's own launches -- FF1 is 384 such tiles = 1.5 rounds, the fused QKV 144 -- stay on the 128-row tiles
     // (tools/time_gemm256.py: 72.8 vs 60.7 us, 38.1 vs 34.9 us; outputs bit-identical).  No residual / statistics / n_store.
     {
-        const char *e256 = getenv("SCULPT_GEMM_256");  // 0: never, 1 (default): by the rule below, 2: whenever legal (tests, A/B)
+        const char *e256 = getenv("SCULPT_GEMM_256");  // 0: never, 1 (default): by the rules below, 2: whenever legal (tests, A/B)
         const int p256 = e256 ? atoi(e256) : 1;
         const int nout = epilogue == SCULPT_EPI_GEGLU ? 128 : 256;
-        const long tiles = (long)(N / nout) * cdiv(M, 256);
+        const long tiles = (long)(N / nout) * cdiv(M, 256), tiles192 = (long)(N / nout) * cdiv(M, 192);
         const bool pays = tiles >= 2L * num_cus() && (epilogue == SCULPT_EPI_GEGLU || N >= 4096) && (M % 256 == 0 || M % 256 >= 128);
+        // 192 x 256 tiles (round 4, tools/gemm_order_ab.py, interleaved in one process): wherever 3072-row multiples give them at
+        // least 3/4 of the CUs a tile -- B = 1: FF1 512 tiles 58.8 vs 61.4 us on the 128-row tiles, fused Q|K|V^T 192 tiles 31.3 vs
+        // 35.0; a 4-image batch: Q|K|V^T 93.8 vs 101.0, cross-attention q 33.2 vs 36.6 -- except where the 256-row tile has four
+        // rounds of its own (FF1 of a 4-image batch: 211.9 vs 225.7 us).  SCULPT_GEMM_192=0 / 1 forces never / always.
+        const char *e192 = getenv("SCULPT_GEMM_192");
+        const int f192 = e192 ? atoi(e192) : -1;
+        const bool pays192 = M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus());
         const bool fits = p256 && !residual && !g.stats_out && n_store == N && N % nout == 0 && K >= 2 * BK &&
                           (epilogue == SCULPT_EPI_GEGLU || epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_GELU) &&
-                          n_split % 16 == 0 && (long)w_rows * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L && (p256 >= 2 || pays);
+                          n_split % 16 == 0 && (long)w_rows * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L &&
+                          (p256 >= 2 || pays || (pays192 && f192 != 0));
         if (fits) {
-            // 192-row tiles (SCULPT_GEMM_192=1; 16 instead of 12 row tiles for 3072 rows: FF1 becomes 512 tiles = two full rounds):
-            // measured 61.0 vs 62.2 us on FF1 and 32.5 vs 35.5 on the fused QKV against the 128-row tiles, within the box-to-box
-            // spread, so the default keeps 256 rows and the rule above
-            const char *e192 = getenv("SCULPT_GEMM_192");
-            const bool bm192 = e192 && atoi(e192) != 0;
+            const bool bm192 = f192 >= 0 ? f192 != 0 : pays192;
             const dim3 grid(N / nout, bm192 ? cdiv(M, 192) : cdiv(M, 256));
+            g.gm = group_rows(256, bm192 ? 192 : 256, 1, (long)grid.x * grid.y, grid.y);
 #define SCULPT_G256(E)                                                                                     \
     do {                                                                                                   \
         if (bm192) hipLaunchKernelGGL((gemm256_kernel<E, 192>), grid, dim3(512), 0, st, g);                \
@@ -940,6 +978,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     if (epilogue == SCULPT_EPI_GEGLU) {
         SC_REQUIRE(N % 64 == 0, "gemm_bf16(GEGLU): N=%d must be a multiple of 64", N);
         SC_REQUIRE(!residual && !out_bf16_t, "gemm_bf16(GEGLU): residual/transposed output unsupported");
+        g.gm = group_rows(128, BM_DEFAULT, 2, (long)(N / 64) * mt, mt);
         if (nw8) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GEGLU, 128, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
         else hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GEGLU, 128, 4>), dim3(N / 64, mt), dim3(256), 0, st, g);
     } else {
@@ -948,6 +987,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
         // (128 x 128 tiles for the N = 1024 launches -- 192 workgroups, a third fewer L2 -> LDS bytes -- measured the same at
         // K = 1024 and 10 % slower at K = 4096: one workgroup per CU pulls ~35 GB/s through its LDS-DMA queue, two pull ~57)
         const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
+        g.gm = small ? group_rows(64, BM_DEFAULT, 2, (long)(N / 64) * mt, mt) : group_rows(128, BM_DEFAULT, 2, (long)(N / 128) * mt, mt);
         if (epilogue == SCULPT_EPI_GELU) {
             if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
             else if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 64, 4>), dim3(N / 64, mt), dim3(256), 0, st, g);

@@ -53,11 +53,18 @@ class KernelEngine:
         return ops.gemm_f32(A, W, bias=bias, residual=residual, out=out, out_t=out_t, M=M, epilogue=epilogue,
                             n_split=n_split)
 
-    def _attn(self, Q, K, Vt, O, Tq, Tk, heads, scale):
+    def _attn(self, Q, K, Vt, O, Tq, Tk, heads, scale, batch=1, q_bs=0, k_bs=0, vt_bs=0, o_bs=0):
+        """batch > 1: `batch` independent attentions, entry b at Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (a column offset), O + b*o_bs
+        (elements): one launch in bf16 mode, a loop over the entries in the fp32 parity mode."""
         if self.precision == "bf16":
-            return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale)
+            return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
         scores = self._b("attn_scores", (Tq, ((Tk + 15) // 16) * 16), torch.float32)
-        return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores)
+        if batch == 1:
+            return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores)
+        assert q_bs % Q.stride(0) == 0 and k_bs % K.stride(0) == 0 and o_bs % O.stride(0) == 0 and vt_bs < Vt.stride(0)
+        for b in range(batch):
+            ops.attention_f32(Q[b * q_bs // Q.stride(0):], K[b * k_bs // K.stride(0):], Vt[:, b * vt_bs:], O[b * o_bs // O.stride(0):],
+                              Tq, Tk, heads, scale, scores)
 
     def _ln(self, x, gamma, beta, eps, y):
         if self.precision == "bf16":

@@ -225,28 +225,101 @@ def read_glb(path, uv_origin="bottom_left"):
     }
 
 
-def write_ply(path, vertices, faces, vertex_colors=None):
-    """Binary little-endian PLY: float32 xyz, optional uchar rgb, faces as `uchar 3` + int32 triplets."""
+def _ply_layout(vertices, faces, vertex_colors):
+    """(header bytes, vertex block as a C-contiguous array whose bytes ARE the block, int faces [Nf,3]) of write_ply's file."""
     v = np.ascontiguousarray(vertices, np.float32)
-    f = np.ascontiguousarray(faces, np.int64)
-    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    f = np.asarray(faces)
+    if f.dtype.kind not in "iu":
+        f = f.astype(np.int64)
     head = ["ply", "format binary_little_endian 1.0", "comment sculptmate_amd", "element vertex %d" % len(v),
             "property float x", "property float y", "property float z"]
     if vertex_colors is not None:
-        fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
         head += ["property uchar red", "property uchar green", "property uchar blue"]
-    head += ["element face %d" % len(f), "property list uchar int vertex_indices", "end_header"]
-    vrec = np.empty(len(v), np.dtype(fields))
-    vrec["x"], vrec["y"], vrec["z"] = v[:, 0], v[:, 1], v[:, 2]
-    if vertex_colors is not None:
         c8 = np.round(np.clip(np.asarray(vertex_colors, np.float64), 0, 1) * 255).astype(np.uint8)
-        vrec["red"], vrec["green"], vrec["blue"] = c8[:, 0], c8[:, 1], c8[:, 2]
-    frec = np.empty(len(f), np.dtype([("n", "u1"), ("i", "<i4", (3,))]))
-    frec["n"], frec["i"] = 3, f
+        vblock = np.empty((len(v), 15), np.uint8)          # float32 xyz + uchar rgb, packed
+        vblock[:, :12] = v.view(np.uint8).reshape(len(v), 12)
+        vblock[:, 12:] = c8
+    else:
+        vblock = v                                           # the raw [Nv,3] float32 buffer is the vertex block
+    head += ["element face %d" % len(f), "property list uchar int vertex_indices", "end_header"]
+    return ("\n".join(head) + "\n").encode(), vblock, f
+
+
+_tls = None
+
+
+def _ply_face_records(f):
+    """int [n,3] -> uint8 [n,13]: `uchar 3` + three little-endian int32 per face.  int64 faces (what TSR.run returns) go
+    through the library's host-side packer (sculpt_ply_face_records: one pass, and ctypes drops the GIL around it, so chunks
+    run in parallel); anything else through NumPy.  The result lives in a per-thread scratch buffer that the next call on the
+    same thread overwrites (fresh pages per chunk cost more than the packing: the page faults of all threads serialise)."""
+    global _tls
+    if _tls is None:
+        import threading
+
+        _tls = threading.local()
+    buf = getattr(_tls, "buf", None)
+    if buf is None or len(buf) < len(f):
+        buf = _tls.buf = np.empty((max(len(f), PLY_CHUNK_FACES), 13), np.uint8)
+    rec = buf[:len(f)]
+    if f.dtype == np.int64 and f.flags.c_contiguous and len(f):
+        from . import _lib
+
+        _lib.check(_lib.lib.sculpt_ply_face_records(f.ctypes.data, len(f), rec.ctypes.data))
+        return rec
+    rec[:, 0] = 3
+    rec[:, 1:] = np.ascontiguousarray(f, "<i4").view(np.uint8).reshape(len(f), 12)
+    return rec
+
+
+PLY_CHUNK_FACES = 1 << 18   # faces converted + written per task (3.4 MB of records)
+
+
+def write_ply(path, vertices, faces, vertex_colors=None, pool=None):
+    """Binary little-endian PLY: float32 xyz, optional uchar rgb, faces as `uchar 3` + int32 triplets.
+    The file is laid out up front (header, vertex block, 13-byte face records) and written with positioned writes, the face
+    records converted chunk by chunk; with `pool` (a concurrent.futures executor) the chunks are converted and written in
+    parallel -- NumPy copies and os.pwrite release the GIL -- and the same bytes land in the file either way."""
+    import os
+
+    head, vblock, f = _ply_layout(vertices, faces, vertex_colors)
+    v_off = len(head)
+    f_off = v_off + vblock.nbytes
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.ftruncate(fd, f_off + 13 * len(f))
+
+        def put(data, off):
+            mv = memoryview(data).cast("B")
+            while len(mv):
+                n = os.pwrite(fd, mv, off)
+                mv, off = mv[n:], off + n
+
+        def face_chunk(a):
+            put(_ply_face_records(f[a:a + PLY_CHUNK_FACES]), f_off + 13 * a)
+
+        tasks = [lambda: put(head, 0)]
+        step = 4 << 20                                       # vertex block in 4 MB pieces
+        vb = memoryview(vblock).cast("B")
+        tasks += [lambda a=a: put(vb[a:a + step], v_off + a) for a in range(0, len(vb), step)]
+        tasks += [lambda a=a: face_chunk(a) for a in range(0, len(f), PLY_CHUNK_FACES)]
+        if pool is None:
+            for t in tasks:
+                t()
+        else:
+            for fut in [pool.submit(t) for t in tasks]:
+                fut.result()
+    finally:
+        os.close(fd)
+
+
+def write_npz(path, vertices, faces, vertex_colors=None):
+    """Raw arrays (np.savez, uncompressed): vertices f32, faces as given (int64 from TSR.run), vertex_colors if any."""
+    arrays = {"vertices": np.asarray(vertices, np.float32), "faces": np.asarray(faces)}
+    if vertex_colors is not None:
+        arrays["vertex_colors"] = np.asarray(vertex_colors, np.float32)
     with open(path, "wb") as fh:
-        fh.write(("\n".join(head) + "\n").encode())
-        fh.write(vrec.tobytes())
-        fh.write(frec.tobytes())
+        np.savez(fh, **arrays)
 
 
 def read_ply(path):

@@ -288,10 +288,17 @@ def row_slice_stats(x, stats, x_bf16=None, rows=None):
                                      x_bf16.stride(0) if x_bf16 is not None else 0, _stream()))
 
 
-def attention(Q, K, Vt, O, Tq, Tk, heads, scale):
+def attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch=1, q_bs=0, k_bs=0, vt_bs=0, o_bs=0):
     """O = softmax(Q K^T scale) V per head (D=64); Vt is V transposed [heads*64][ld >= round_up(Tk,64)].
-    scale=None: the queries already carry softmax_scale * log2(e) (sculpt_attention_bf16_prescaled)."""
-    if scale is None:
+    scale=None: the queries already carry softmax_scale * log2(e) (sculpt_attention_bf16_prescaled).
+    batch > 1: that many independent attentions in one launch (sculpt_attention_bf16_batched); entry b reads Q / K rows
+    b*q_bs / b*k_bs ELEMENTS further on, V^T b*vt_bs elements (a column offset inside one array, or a whole array) and writes
+    O + b*o_bs."""
+    if batch > 1:
+        check(lib.sculpt_attention_bf16_batched(_ptr(Q), Q.stride(0), int(q_bs), _ptr(K), K.stride(0), int(k_bs), _ptr(Vt),
+                                                Vt.stride(0), int(vt_bs), _ptr(O), O.stride(0), int(o_bs), Tq, Tk, heads, int(batch),
+                                                1 if scale is None else 0, 0.0 if scale is None else float(scale), _stream()))
+    elif scale is None:
         check(lib.sculpt_attention_bf16_prescaled(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O),
                                                   O.stride(0), Tq, Tk, heads, _stream()))
     else:

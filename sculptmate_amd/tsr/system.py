@@ -222,6 +222,7 @@ class TSR(KernelEngine):
         self.isosurface_helper = None
         self.decoder = None  # ops.PackedMLP after to(device)
         self.mesh_sink = None  # callable(verts, faces, colors, name); default: bpy if importable
+        self.max_batch = 8     # forward(): images per batched pass (system.py:82-115 takes the whole batch at once); 1 = one by one
         self._w = None
         self._pos_cache = {}
         self._buf = {}
@@ -348,38 +349,56 @@ class TSR(KernelEngine):
         return self._pos_cache[n_side]
 
     # ------------------------------------------------------------------ forward
-    def image_tokens(self, image_hwc: torch.Tensor):
-        """DINOSingleImageTokenizer.forward for one [S,S,3] fp32 image on the device ->
-        (ctx bf16 [T, H] for cross attention, ctx fp32 [T, H])."""
+    @staticmethod
+    def _token_stride(T, B):
+        """Rows from one image's tokens to the next in a stacked batch: T itself for one image, else T rounded up to 8 so that
+        every image's rows (and its V^T columns) start 16-byte aligned; the pad rows carry finite values nobody reads."""
+        return T if B == 1 else ((T + 7) // 8) * 8
+
+    def image_tokens(self, image_hwc):
+        """DINOSingleImageTokenizer.forward (tokenizers/image.py:41-60) for one [S,S,3] fp32 device image, or for a LIST of B
+        such images in one pass (the reference's batch dimension, system.py:82-99): every Linear is one launch over the stacked
+        token rows, the attention one launch over B x heads -> (ctx bf16 [rows, H] for cross attention, ctx fp32 [rows, H]);
+        image b's T tokens are rows b*Ts .. b*Ts+T-1, Ts = _token_stride(T, B)."""
+        imgs = list(image_hwc) if isinstance(image_hwc, (list, tuple)) else [image_hwc]
+        B = len(imgs)
         v, w = self.cfg["image_tokenizer"], self._w
         H, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
-        S = image_hwc.shape[0]
+        S = imgs[0].shape[0]
+        if any(tuple(im.shape) != tuple(imgs[0].shape) for im in imgs):
+            raise ValueError("TSR.image_tokens: the images of a batch must have one size")
         n_side = S // P
         npatch = n_side * n_side
         T = npatch + 1
-        Tp = ((T + 63) // 64) * 64
-        patches = self._b("patches", (npatch, 3 * P * P), self.adt)
-        ops.vit_patchify(image_hwc, P, IMAGE_MEAN, IMAGE_STD, patches)
-        pout = self._b("patch_out", (npatch, H), torch.float32)
+        Ts = self._token_stride(T, B)
+        M = B * Ts
+        ldt = ((((B - 1) * Ts + ((T + 63) // 64) * 64) + 63) // 64) * 64   # V^T columns: image b at column b*Ts
+        patches = self._b("patches", (B * npatch, 3 * P * P), self.adt)
+        for b, im in enumerate(imgs):
+            ops.vit_patchify(im, P, IMAGE_MEAN, IMAGE_STD, patches[b * npatch:(b + 1) * npatch])
+        pout = self._b("patch_out", (B * npatch, H), torch.float32)
         self._gemm(patches, w["patch_w"], bias=w["patch_b"], out_f32=pout)
-        h = self._b("vit_h", (T, H), torch.float32)
-        ops.vit_assemble(pout, w["cls"], self._pos(n_side, image_hwc.device), h)
+        h = self._b("vit_h", (M, H), torch.float32, zero=True)
+        pos = self._pos(n_side, imgs[0].device)
+        for b in range(B):
+            ops.vit_assemble(pout[b * npatch:(b + 1) * npatch], w["cls"], pos, h[b * Ts:b * Ts + T])
         st = self._stream_state("vit", h)     # the residual stream + its bf16 copy + slice statistics (LayerNorm fold)
         self._stats_of(st)                    # rows that do not come out of a GEMM: one small kernel
-        qk = self._b("vit_qk", (T, 2 * H), self.adt)
-        vt = self._b("vit_vt", (H, Tp), self.adt, zero=True)
-        att = self._b("vit_att", (T, H), self.adt)
-        ff = self._b("vit_ff", (T, v["intermediate_size"]), self.adt)
+        qk = self._b("vit_qk", (M, 2 * H), self.adt)
+        vt = self._b("vit_vt", (H, ldt), self.adt, zero=True)
+        att = self._b("vit_att", (M, H), self.adt, zero=True)
+        ff = self._b("vit_ff", (M, v["intermediate_size"]), self.adt)
         eps = v["layer_norm_eps"]
         for L in w["vit"]:
             self._ln_gemm(st, L, "qkv_w", eps, out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
-            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(H // nh)))
+            self._attn(qk[:, :H], qk[:, H:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(H // nh)),
+                       B, Ts * 2 * H, Ts * 2 * H, Ts, Ts * H)
             self._res_gemm(st, att, L["o_w"], L["o_b"])
             self._ln_gemm(st, L, "f1_w", eps, out_bf16=ff, epilogue=_lib.EPI_GELU)
             self._res_gemm(st, ff, L["f2_w"], L["f2_b"])
-        ctx32 = self._b("ctx32", (T, H), torch.float32)
+        ctx32 = self._b("ctx32", (M, H), torch.float32)
         if self.precision == "bf16":
-            ctx = self._b("ctx", (T, H), BF16)
+            ctx = self._b("ctx", (M, H), BF16)
             ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y=ctx, y_f32=ctx32)
         else:
             ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y_f32=ctx32)
@@ -390,40 +409,46 @@ class TSR(KernelEngine):
         """bf16 mode: the query projections carry scale * log2(e) (ln_linear q_scale) -> sculpt_attention_bf16_prescaled (scale None)."""
         return None if self.precision == "bf16" else scale
 
-    def _self_attention(self, st, L):
-        """h += attn1(LN1(h)) of one BasicTransformerBlock (basic_transformer_block.py:149-167)."""
+    def _self_attention(self, st, L, batch=1):
+        """h += attn1(LN1(h)) of one BasicTransformerBlock (basic_transformer_block.py:149-167); h holds `batch` images' tokens
+        stacked (attention.py:629-631 with its leading batch dimension)."""
         b = self.cfg["backbone"]
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
-        D, T = nh * hd, st["h"].shape[0]
-        Tp = ((T + 63) // 64) * 64
-        qk = self._b("bb_qk", (T, 2 * D), self.adt)
-        vt = self._b("bb_vt", (D, Tp), self.adt, zero=True)
-        att = self._b("bb_att", (T, D), self.adt)
+        D, M = nh * hd, st["h"].shape[0]
+        T = M // batch
+        Mp = ((M + 63) // 64) * 64
+        qk = self._b("bb_qk", (M, 2 * D), self.adt)
+        vt = self._b("bb_vt", (D, Mp), self.adt, zero=True)
+        att = self._b("bb_att", (M, D), self.adt)
         self._ln_gemm(st, L, "sa_qkv", 1e-5, out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
-        self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(hd)))
+        self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(hd)),
+                   batch, T * 2 * D, T * 2 * D, T, T * D)
         self._res_gemm(st, att, L["sa_o"], L["sa_ob"])
 
-    def _run_blocks(self, st, ctx: torch.Tensor, first_self_attention_done: bool = False):
-        """All BasicTransformerBlocks on the fp32 residual stream h [T, D] (updated in place)."""
+    def _run_blocks(self, st, ctx: torch.Tensor, first_self_attention_done: bool = False, batch: int = 1, ctx_tokens=None):
+        """All BasicTransformerBlocks on the fp32 residual stream h [batch*T, D] (updated in place).  ctx [rows, cross_dim]: the
+        image tokens, image b's ctx_tokens rows starting at row b * (rows // batch) (image_tokens' stacking)."""
         b, w = self.cfg["backbone"], self._w
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
         D = nh * hd
-        T, Tc = st["h"].shape[0], ctx.shape[0]
-        Tcp = ((Tc + 63) // 64) * 64
-        q = self._b("bb_q", (T, D), self.adt)
+        M, Mc = st["h"].shape[0], ctx.shape[0]
+        T, Ts = M // batch, Mc // batch
+        Tc = Ts if ctx_tokens is None else ctx_tokens
+        ldc = ((((batch - 1) * Ts + ((Tc + 63) // 64) * 64) + 63) // 64) * 64
+        q = self._b("bb_q", (M, D), self.adt)
         nL = len(w["blocks"])
-        ck_all = self._b("bb_ck", (Tc, nL * D), self.adt)
-        cvt_all = self._b("bb_cvt", (nL * D, Tcp), self.adt, zero=True)
-        self._gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Tc)
-        att = self._b("bb_att", (T, D), self.adt)
-        ff = self._b("bb_ff", (T, 4 * D), self.adt)
+        ck_all = self._b("bb_ck", (Mc, nL * D), self.adt)
+        cvt_all = self._b("bb_cvt", (nL * D, ldc), self.adt, zero=True)
+        self._gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Mc)
+        att = self._b("bb_att", (M, D), self.adt)
+        ff = self._b("bb_ff", (M, 4 * D), self.adt)
         scale = self._attn_scale(1.0 / math.sqrt(hd))
         for li, L in enumerate(w["blocks"]):
             ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
             if li > 0 or not first_self_attention_done:
-                self._self_attention(st, L)
+                self._self_attention(st, L, batch)
             self._ln_gemm(st, L, "ca_q", 1e-5, out_bf16=q)
-            self._attn(q, ck, cvt, att, T, Tc, nh, scale)
+            self._attn(q, ck, cvt, att, T, Tc, nh, scale, batch, T * D, Ts * nL * D, Ts, T * D)
             self._res_gemm(st, att, L["ca_o"], L["ca_ob"])
             self._ln_gemm(st, L, "ff1", 1e-5, out_bf16=ff, epilogue=_lib.EPI_GEGLU)
             self._res_gemm(st, ff, L["ff2"], L["ff2_b"])
@@ -446,19 +471,66 @@ class TSR(KernelEngine):
             self._gemm(xn, w["pin_w"], bias=w["pin_b"], out_f32=h)
         return st
 
-    def _backbone_tail(self, st):
+    def _backbone_tail(self, st, batch=1):
         w = self._w
         C = self.cfg["tokenizer"]["num_channels"]
         h = st["h"]
-        T, D = h.shape
-        out = self._b("bb_out", (T, C), torch.float32)
+        M, D = h.shape
+        res = w["emb_tc"]                       # the learned tokens: the same residual rows for every image of a batch
+        if batch > 1:
+            key = "emb_tc_x%d" % batch
+            if key not in w:
+                w[key] = res.repeat(batch, 1).contiguous()
+            res = w[key]
+        out = self._b("bb_out", (M, C), torch.float32)
         if self.precision == "bf16":
-            outb = self._b("bb_outb", (T, C), BF16)
-            ops.gemm(st["hb"], w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out_f32=out, out_bf16=outb)  # hb = bf16(h)
+            outb = self._b("bb_outb", (M, C), BF16)
+            ops.gemm(st["hb"], w["pout_w"], bias=w["pout_b"], residual=res, out_f32=out, out_bf16=outb)  # hb = bf16(h)
         else:
-            ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=w["emb_tc"], out=out)
+            ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=res, out=out)
             outb = out
         return out, outb
+
+    def _broadcast_state(self, st1, batch):
+        """The residual stream of ONE image (the image-independent head of the backbone) copied into a stacked state of `batch`."""
+        T, D = st1["h"].shape
+        st = self._stream_state("bb", self._b("bb_h", (batch * T, D), torch.float32))
+        st["h"].view(batch, T, D).copy_(st1["h"][None])
+        if self.precision == "bf16":
+            st["hb"].view(batch, T, D).copy_(st1["hb"][None])
+            st["stats"].view(-1, batch, T, 2).copy_(st1["stats"][:, None])
+        return st
+
+    def encode_images(self, images):
+        """encode_image for a batch (system.py:82-115 with batch_size = len(images)): ONE pass of the tokenizer and the backbone
+        over the stacked token rows of all images -- weight panels are read once per batch, every Linear is one launch of
+        B x 3072 (B x 1025) rows, every attention one launch over B x heads.  The image-independent head of the backbone
+        (GroupNorm, proj_in, first self-attention) is evaluated once, on a second stream under the tokenizer, and copied into
+        the B streams.  Returns the output tokens of all images stacked: (fp32 [B*3*S*S, C], bf16 copy)."""
+        B = len(images)
+        if B == 1:
+            return self.encode_image(images[0])
+        main = torch.cuda.current_stream(self.device)
+        last_tok = getattr(self, "_tok_last", None)
+        if last_tok is not None:
+            main.wait_event(last_tok)
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(self.device)
+        fork, join = torch.cuda.Event(), torch.cuda.Event()
+        fork.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            st1 = self._backbone_head()
+            self._self_attention(st1, self._w["blocks"][0])
+            st = self._broadcast_state(st1, B)
+            join.record(side)
+        ctx, _ = self.image_tokens(list(images))
+        main.wait_event(join)
+        T = self.cfg["image_tokenizer"]
+        n_side = images[0].shape[0] // T["patch_size"]
+        st = self._run_blocks(st, ctx, first_self_attention_done=True, batch=B, ctx_tokens=n_side * n_side + 1)
+        return self._backbone_tail(st, B)
 
     def backbone_tokens(self, ctx: torch.Tensor):
         """Triplane1DTokenizer + Transformer1D for one image; ctx bf16 [Tc, cross_dim].
@@ -543,16 +615,18 @@ class TSR(KernelEngine):
         _, outb = self._backbone_tail(st)
         return self.scene_code(outb)[None]
 
-    def scene_code(self, tokens_bf16: torch.Tensor):
-        """detokenize + TriplaneUpsampleNetwork: tokens [3*S*S, C] -> planes fp32 [3, Co, 2S, 2S]."""
+    def scene_code(self, tokens_bf16: torch.Tensor, batch: int = 1):
+        """detokenize + TriplaneUpsampleNetwork: tokens [batch*3*S*S, C] -> planes fp32 [3, Co, 2S, 2S] ([batch, 3, ...] for batch > 1)."""
         w = self._w
         S = self.cfg["tokenizer"]["plane_size"]
         Co = self.cfg["post_processor"]["out_channels"]
         g = self._b("up_g", (tokens_bf16.shape[0], w["up_w"].shape[0]), torch.float32)
         self._gemm(tokens_bf16, w["up_w"], out_f32=g)
-        planes = torch.empty((3, Co, 2 * S, 2 * S), dtype=torch.float32, device=tokens_bf16.device)
-        ops.upsample_scatter(g, w["up_b"], planes, S, Co)
-        return planes
+        planes = torch.empty((batch, 3, Co, 2 * S, 2 * S), dtype=torch.float32, device=tokens_bf16.device)
+        T = tokens_bf16.shape[0] // batch
+        for b in range(batch):
+            ops.upsample_scatter(g[b * T:(b + 1) * T], w["up_b"], planes[b], S, Co)
+        return planes if batch > 1 else planes[0]
 
     def _upload(self, t: torch.Tensor) -> torch.Tensor:
         """Host image -> HBM without blocking the host: a pageable source makes hipMemcpyAsync synchronous (the host waits for
@@ -588,11 +662,20 @@ class TSR(KernelEngine):
                 self.to(device)
             else:
                 raise _lib.SculptError("TSR: call load_state_dict() and to(device) before forward()")
+        images = [self._preprocess(im) for im in _as_image_list(image)]
         codes = []
-        for im in _as_image_list(image):
-            _, outb = self.encode_image(self._preprocess(im))
-            codes.append(self.scene_code(outb))
-        return torch.stack(codes, 0)
+        step = max(1, int(self.max_batch))
+        for i in range(0, len(images), step):
+            group = images[i:i + step]
+            n_tok = 3 * self.cfg["tokenizer"]["plane_size"] ** 2   # a batch entry's rows / V^T columns must start 16-byte aligned
+            if len(group) == 1 or n_tok % 8 or any(tuple(g.shape) != tuple(group[0].shape) for g in group):
+                for im in group:
+                    _, outb = self.encode_image(im)
+                    codes.append(self.scene_code(outb)[None])
+            else:   # the reference's batched pass (system.py:82-115)
+                _, outb = self.encode_images(group)
+                codes.append(self.scene_code(outb, len(group)))
+        return torch.cat(codes, 0) if len(codes) > 1 else codes[0]
 
     __call__ = forward
 

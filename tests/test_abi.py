@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from sculptmate_amd import _lib
 
-    assert _lib.lib.sculpt_version() == 1
+    assert _lib.lib.sculpt_version() == 2
     assert isinstance(_lib.last_error(), str)
     assert _lib.lib.sculpt_device_count() >= 0
 

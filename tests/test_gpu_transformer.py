@@ -267,6 +267,45 @@ def test_attention_vs_fp32_reference(cuda, Tq, Tk, heads):
     assert rel < 6e-3 and mx < 0.06, (rel, mx)
 
 
+@pytest.mark.parametrize("Tq,Tk,heads,B,prescaled", [(3072, 3072, 16, 3, True), (3072, 1025, 16, 4, True), (1025, 1025, 12, 2, True),
+                                                       (1025, 1025, 12, 5, False), (200, 77, 2, 3, True), (64, 130, 1, 7, False)])
+def test_batched_attention_equals_per_entry_launches(cuda, Tq, Tk, heads, B, prescaled):
+    """sculpt_attention_bf16_batched: B independent attentions in one launch (entries stacked row-wise, V^T side by side at a
+    column stride that is a multiple of 8 but not of 64) == B single launches on the same operands, bit for bit where the
+    launcher picks the same workgroup shape, and always within the kernel's own error against fp32."""
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(Tq + Tk + B)
+    D = heads * 64
+    Tqs, Tks = ((Tq + 7) // 8) * 8, ((Tk + 7) // 8) * 8           # row stride between entries (image_tokens' stacking)
+    ldv = (((B - 1) * Tks + ((Tk + 63) // 64) * 64 + 63) // 64) * 64
+    q = torch.randn(B * Tqs, D, generator=g).to(BF).to(cuda)
+    k = torch.randn(B * Tks, D, generator=g).to(BF).to(cuda)
+    v = torch.randn(B * Tks, D, generator=g).to(BF).to(cuda)
+    vt = torch.zeros(D, ldv, dtype=BF, device=cuda)
+    vt[:, :B * Tks] = v.t()
+    scale = None if prescaled else 0.125
+    o = torch.zeros(B * Tqs, D, dtype=BF, device=cuda)
+    ops.attention(q, k, vt, o, Tq, Tk, heads, scale, batch=B, q_bs=Tqs * D, k_bs=Tks * D, vt_bs=Tks, o_bs=Tqs * D)
+    same = True
+    for b in range(B):
+        ob = torch.zeros(Tq, D, dtype=BF, device=cuda)
+        ops.attention(q[b * Tqs:], k[b * Tks:], vt[:, b * Tks:], ob, Tq, Tk, heads, scale)
+        got = o[b * Tqs:b * Tqs + Tq]
+        same = same and torch.equal(got, ob)
+        qh = q[b * Tqs:b * Tqs + Tq].float().view(Tq, heads, 64).transpose(0, 1)
+        kh = k[b * Tks:b * Tks + Tk].float().view(Tk, heads, 64).transpose(0, 1)
+        vh = v[b * Tks:b * Tks + Tk].float().view(Tk, heads, 64).transpose(0, 1)
+        sc = qh @ kh.transpose(1, 2)
+        p = torch.softmax(sc * math.log(2.0), -1) if prescaled else torch.softmax(sc * 0.125, -1)
+        ref = (p @ vh).transpose(0, 1).reshape(Tq, D)
+        rel, mx = _rel(got, ref)
+        assert rel < 6e-3 and mx < 0.08, (b, rel, mx)
+        assert _rel(got, ob)[0] < 2e-3
+        assert (o[b * Tqs + Tq:(b + 1) * Tqs] == 0).all()        # pad rows between entries are not written
+    print("batched == per-entry launches bit for bit:", same)
+
+
 def test_attention_forced_rescale_branch(cuda):
     """One key spikes late in the sequence so the running max jumps in a late tile (online softmax)."""
     from sculptmate_amd import ops
@@ -425,13 +464,19 @@ def test_end_to_end_run_returns_meshes(cuda):
 
 
 def test_batch_of_images_equals_one_at_a_time(cuda):
-    """BASELINE config 3 per GPU: TSR.forward / TSR.run on a LIST of images (the reference batches them, system.py:94-125)
-    gives, image by image, exactly what single-image calls give -- scene codes bit for bit, meshes bit for bit."""
+    """BASELINE config 3 per GPU: TSR.forward / TSR.run on a LIST of images.  forward() runs the list as ONE batched pass like
+    the reference (system.py:82-115: every Linear over the stacked token rows, attention over batch x heads); run() goes
+    image by image.  Both give, image by image, what single-image calls give: the batched scene codes bit for bit on this
+    small model (the same tile kernels run), the meshes of run() bit for bit."""
     m, sd = _small_model(cuda, seed=43)
     S = SMALL_CFG["cond_image_size"]
     imgs = [synth.composite_rgb(synth.image_rgba(seed=60 + i, size=S)) for i in range(3)]
     codes = m(imgs, device=cuda)
-    assert codes.shape[0] == 3
+    assert codes.shape == (3, 3, 40, 16, 16)
+    m.max_batch = 1
+    serial = m(imgs, device=cuda)
+    m.max_batch = 8
+    assert serial.shape == codes.shape
     from sculptmate_amd import ops
 
     thr = float(ops.density_grid(codes[0].contiguous(), m.decoder, 32).median())
@@ -439,11 +484,46 @@ def test_batch_of_images_equals_one_at_a_time(cuda):
     assert len(batch) == 3
     for i, im in enumerate(imgs):
         one = m([im], device=cuda)
-        assert torch.equal(one[0], codes[i])
+        assert torch.equal(one[0], serial[i])
+        assert torch.equal(one[0], codes[i]), _rel(codes[i], one[0])
         single = m.run([im], mc_resolution=32, threshold=thr)[0]
         assert np.array_equal(single.vertices.view(np.uint32), batch[i].vertices.view(np.uint32))
         assert np.array_equal(single.faces, batch[i].faces)
     assert not np.array_equal(batch[0].vertices[:50], batch[1].vertices[:50])  # different images, different meshes
+    # a batch larger than max_batch is cut into passes; a ragged last pass and a pass of one
+    m.max_batch = 2
+    assert torch.equal(m(imgs, device=cuda), codes)
+    m.max_batch = 8
+
+
+def test_full_size_batched_forward_equals_single_image_passes(cuda):
+    """The full-size model: TSR.forward on B = 3 images in one batched pass (M = 3 x 3072 / 3 x 1032 stacked token rows; the
+    256-row tile kernel takes over FF1 / QKV / K-V-all at this size, attention runs over 3 x 16 heads per launch) against the
+    single-image passes.  Every kernel accumulates a given output in the same order whatever the tile, so the scene codes are
+    expected bit-identical; the asserted bound is the bf16 one (the transformer's own error vs the fp32 oracle is 7.6e-3)."""
+    from sculptmate_amd.tsr import TSR
+
+    sd = synth.tsr_state(seed=0)
+    m = TSR(pos_embed_mode="scale_factor")
+    m.load_state_dict(sd)
+    m.to(cuda)
+    imgs = [torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=100 + i))).to(cuda) for i in range(3)]
+    with torch.no_grad():
+        codes = m(imgs, device=cuda).clone()
+        singles = [m([im], device=cuda)[0].clone() for im in imgs]
+        again = m(imgs, device=cuda)
+    assert codes.shape == (3, 3, 40, 64, 64) and torch.isfinite(codes).all()
+    assert torch.equal(again, codes)                       # deterministic, buffers reused
+    rels = [_rel(codes[i], singles[i]) for i in range(3)]
+    print("batched vs single-image scene codes (rel L2, max abs):", rels, "bit-identical:", [torch.equal(codes[i], singles[i]) for i in range(3)])
+    # Measured 2.7e-3: the image tokens are bit-identical; in the backbone the N = 1024 launches take the 128-row weight tile at
+    # 3 x 3072 rows and the 64-row tile at 3072, whose LayerNorm slice statistics are merged in a different order -- 1e-7 in
+    # fp32, which flips a bf16 rounding now and then; sixteen blocks turn that into 8e-4 of the residual stream.  The bound is
+    # the transformer's own distance from the fp32 oracle (7.6e-3, test_full_size_tsr_forward_vs_oracle: both passes sit
+    # equally close to the oracle).
+    for r, mx in rels:
+        assert r < 8e-3, rels
+    assert _rel(codes[0], codes[1])[0] > 1e-2              # different images
 
 
 def test_tokenizer_lookahead_gives_the_serial_meshes(cuda):
@@ -635,6 +715,12 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     assert r32 < 3e-2, r32
     ctx, ctx32 = m.image_tokens(torch.from_numpy(img).to(cuda))
     assert _rel(ctx32, col["ctx"])[0] < 2e-2
+    # the batched pass (TSR.forward on a list, system.py:82-115) against the SAME fp32 oracle: the same bound, and as close to
+    # the oracle as the one-image pass is (the two differ from each other by bf16 rounding flips, 2.7e-3: below)
+    codes_b = m([img, synth.composite_rgb(synth.image_rgba(seed=101)), synth.composite_rgb(synth.image_rgba(seed=102))], device=cuda)
+    r32_b, _ = _rel(codes_b[0], ref32)
+    print("full-size scene code vs fp32 oracle: one-image pass rel %.3e, image 0 of a batched pass of three rel %.3e" % (r32, r32_b))
+    assert r32_b < 3e-2 and r32_b < 1.25 * r32 + 1e-3, (r32_b, r32)
     # the tokenizer look-ahead at full size (real launch shapes and timings): several rounds of TSR.run on six images must
     # reproduce the one-image-at-a-time meshes bit for bit (a race between the two streams would show as a different mesh)
     six = [synth.composite_rgb(synth.image_rgba(seed=100 + i)) for i in range(6)]
