@@ -240,6 +240,27 @@ int sculpt_row_slice_stats(const float *x, int ldx, int rows, int cols, float *s
 int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
                     float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K,
                     float alpha, int epilogue, sculpt_stream_t stream);
+/* The same GEMM with a choice of arithmetic and a batch dimension (grid z):
+ *   arithmetic SCULPT_F32_EXACT  = v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain (sculpt_gemm_f32);
+ *              SCULPT_F32_BF16L3 = fp32 arithmetic on the bf16 matrix pipe: A and W are split EXACTLY into three bf16 limbs each
+ *                                  while staged (x = x1 + x2 + x3, 24 significant bits, fp32 exponent range), the six limb products
+ *                                  of order >= 2^-16 are exact in fp32 and accumulate in fp32 (csrc/gemm_l3.hip); K % 32 == 0.
+ *                                  What TSR(precision="bf16l3") runs its Linears and per-head attention products on: the
+ *                                  reference's fp32 Linears (TripoSR/tsr/models/transformer/attention.py:569-653,
+ *                                  basic_transformer_block.py:291-315) to fp32 rounding.
+ *   batch > 1: entry z reads A + z*a_bs, W + z*w_bs and writes out / out_t (+ reads residual) + z*o_bs (element strides,
+ *              multiples of 4): the heads of one attention as ONE launch. */
+#define SCULPT_F32_EXACT 0
+#define SCULPT_F32_BF16L3 1
+int sculpt_gemm_f32_ex(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
+                       float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K, float alpha,
+                       int epilogue, int arithmetic, int batch, int64_t a_bs, int64_t w_bs, int64_t o_bs, sculpt_stream_t stream);
+/* Fused attention of the fast parity mode: O = softmax(Q K^T * scale) V per head (head dim 64), fp32 in and out, both products
+ * with three-limb bf16 operands and fp32 accumulation (SCULPT_F32_BF16L3 arithmetic), the softmax in fp32 registers
+ * (csrc/attention_l3.hip; attention.py:629-631 in the reference's own fp32).  Q [Tq][ldq], K [Tk][ldk] with head h at columns
+ * 64 h ..; Vt [heads*64][ldvt] = V transposed, ldvt >= round_up(Tk, 64), columns >= Tk finite; O [Tq][ldo]. */
+int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, int Tq,
+                            int Tk, int heads, float scale, sculpt_stream_t stream);
 /* in-place softmax over the first `cols` columns of each row; columns [cols, pad_cols) are set to 0 */
 int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, sculpt_stream_t stream);
 

@@ -97,6 +97,8 @@ SIGNATURES = {
     "sculpt_add_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "sculpt_fuse_sigmoid": (_i, [_vp, _i, _i64, _vp, _f, _vp, _vp]),
     "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sculpt_attention_f32_l3": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_gemm_f32_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sculpt_attention_bf16_prescaled": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
@@ -171,6 +173,7 @@ QUERY_CHANNEL_LAST = 2
 DENSITY_BF16X3 = 1
 DENSITY_FP16X3 = 2
 DENSITY_BF16L3 = 4
+F32_EXACT, F32_BF16L3 = 0, 1
 
 
 def last_error():

@@ -10,43 +10,22 @@
 // 128 x 128 x 16 tiles, 4 waves (2x2), each wave 2x2 MFMA tiles of 32x32; operands staged k-major in LDS
 // (register-staged, double buffered) so that a lane's MFMA operand is one conflict-free ds_read_b32.
 // Weight tile = A operand -> a lane owns 4 consecutive output columns (float4 epilogue).
-#include "common.h"
+#include "gemm_f32.h"
 
 namespace sculpt {
 
-static constexpr int FBM = 128, FBW = 128, FBK = 16, FLD = 132;  // LDS row stride (floats), padded
-
-struct GemmF32Args {
-    const float *A; int lda;
-    const float *W; int ldw;
-    const float *bias;
-    const float *residual; int ldr;
-    float *out; int ldo;
-    float *out_t; int ldt;
-    int M, N, K;
-    int n_split;
-    int w_rows;   // valid rows of W (rows beyond are clamped; lets N be padded to a multiple of 4)
-    float alpha;  // scale applied to the accumulator before bias (attention scores)
-};
-
-__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+static constexpr int FBK = 16, FLD = 132;  // LDS row stride (floats), padded
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g_in) {
+    const GemmF32Args g = f32_batch_entry(g_in);
     __shared__ float Ws[2][FBK][FLD];
     __shared__ float As[2][FBK][FLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? FBW / 2 : FBW;
     const int n0 = blockIdx.x * NOUT, m0 = blockIdx.y * FBM;
-    // GEGLU: tile rows in groups of 32 alternate value / gate so a lane holds matching pairs
-    auto wrow = [&](int j) -> int {
-        if (EPI == SCULPT_EPI_GEGLU) {
-            const int sub = j >> 5, within = j & 31;
-            return ((sub & 1) ? g.N : 0) + n0 + (sub >> 1) * 32 + within;
-        }
-        return min(n0 + j, g.w_rows - 1);
-    };
+    auto wrow = [&](int j) -> int { return f32_tile_wrow<EPI>(g, n0, j); };
     // staging: a tile is 128 rows x 16 k = 512 float4; thread t handles rows t/4 and t/4 + 64, k-quad t%4
     const int sr = tid >> 2, kq = tid & 3;
     const float *wp0 = g.W + (long)wrow(sr) * g.ldw + 4 * kq;
@@ -102,52 +81,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
 #undef GLOAD
 #undef SWRITE
 
-    // acc[i][j][r]: column m = m0 + wc*64 + j*32 + l31; tile row = wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*lh
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wc * 64 + j * 32 + l31;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {  // register quad: rows 8*q4 + 4*lh + {0..3}
-            if (EPI == SCULPT_EPI_GEGLU) {
-                // wave rows [wr*64, +32) = value group, [+32, +64) = gate group of output columns n0 + wr*32 ..
-                const int n = n0 + wr * 32 + 8 * q4 + 4 * lh;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[0][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f);
-                    const float gt = acc[1][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[g.N + n + r] : 0.f);
-                    o[r] = v * gelu_erf_exact(gt);
-                }
-                *reinterpret_cast<float4 *>(g.out + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int n = n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
-                    if (n >= g.N) continue;  // N is a multiple of 4: a quad is entirely in or out
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f);
-                        if (EPI == SCULPT_EPI_GELU) v = gelu_erf_exact(v);
-                        if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
-                        o[r] = v;
-                    }
-                    if (g.residual) {
-                        const float4 rs = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n);
-                        o[0] += rs.x; o[1] += rs.y; o[2] += rs.z; o[3] += rs.w;
-                    }
-                    const bool tpart = n >= g.n_split;
-                    if (!tpart && g.out) *reinterpret_cast<float4 *>(g.out + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (g.out_t && (tpart || g.n_split >= g.N)) {
-                        const int nt0 = tpart ? n - g.n_split : n;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) g.out_t[(long)(nt0 + r) * g.ldt + m] = o[r];
-                    }
-                }
-            }
-        }
-    }
+    f32_tile_epilogue<EPI>(g, acc, n0, m0, wr, wc, l31, lh);
 }
 
 // in-place row softmax of x [rows][ld] over the first `cols` columns; columns [cols, pad_cols) are zeroed
@@ -179,32 +113,46 @@ using namespace sculpt;
 
 extern "C" {
 
-int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
-                    float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K, float alpha,
-                    int epilogue, sculpt_stream_t stream) {
+int sculpt_gemm_f32_ex(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
+                       float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K, float alpha,
+                       int epilogue, int arithmetic, int batch, int64_t a_bs, int64_t w_bs, int64_t o_bs, sculpt_stream_t stream) {
     SC_REQUIRE(A && W && (out || out_t), "gemm_f32: null argument");
-    SC_REQUIRE(M >= 1 && N >= 4 && K >= FBK && K % FBK == 0, "gemm_f32: bad shape M=%d N=%d K=%d (K %% 16 == 0)", M, N, K);
+    SC_REQUIRE(arithmetic == SCULPT_F32_EXACT || arithmetic == SCULPT_F32_BF16L3, "gemm_f32: arithmetic must be 0 (exact fp32 MFMA) or 1 (three-limb bf16)");
+    const int kq = arithmetic == SCULPT_F32_BF16L3 ? 32 : FBK;
+    SC_REQUIRE(M >= 1 && N >= 4 && K >= kq && K % kq == 0, "gemm_f32: bad shape M=%d N=%d K=%d (K %% %d == 0)", M, N, K, kq);
     SC_REQUIRE(N % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && (!residual || ldr % 4 == 0),
                "gemm_f32: N and the row strides must be multiples of 4");
+    SC_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || (a_bs % 4 == 0 && w_bs % 4 == 0 && o_bs % 4 == 0)),
+               "gemm_f32: bad batch %d / batch strides (multiples of 4 elements)", batch);
     if (n_split <= 0 || n_split > N) n_split = N;
     SC_REQUIRE(n_split % 4 == 0 && (n_split == N || out_t), "gemm_f32: bad n_split");
     if (w_rows <= 0 || w_rows > N) w_rows = N;
-    GemmF32Args g{A, lda, W, ldw, bias, residual, ldr, out, ldo, out_t, ldt, M, N, K, n_split, w_rows, alpha};
+    GemmF32Args g{A, lda, W, ldw, bias, residual, ldr, out, ldo, out_t, ldt, M, N, K, n_split, w_rows, alpha,
+                  batch > 1 ? (long)a_bs : 0, batch > 1 ? (long)w_bs : 0, batch > 1 ? (long)o_bs : 0};
     hipStream_t st = as_stream(stream);
     const int mt = cdiv(M, FBM);
-    if (epilogue == SCULPT_EPI_GEGLU) {
-        SC_REQUIRE(N % 64 == 0 && out && !residual && !out_t, "gemm_f32(GEGLU): N %% 64 == 0, plain output only");
-        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_GEGLU>, dim3(N / 64, mt), dim3(256), 0, st, g);
+    if (epilogue == SCULPT_EPI_GEGLU) SC_REQUIRE(N % 64 == 0 && out && !residual && !out_t, "gemm_f32(GEGLU): N %% 64 == 0, plain output only");
+    else SC_REQUIRE(epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_GELU || epilogue == SCULPT_EPI_RELU, "gemm_f32: unknown epilogue %d", epilogue);
+    if (arithmetic == SCULPT_F32_BF16L3) {
+        gemm_l3_launch(g, epilogue, batch, st);
+    } else if (epilogue == SCULPT_EPI_GEGLU) {
+        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_GEGLU>, dim3(N / 64, mt, batch), dim3(256), 0, st, g);
     } else if (epilogue == SCULPT_EPI_GELU) {
-        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_GELU>, dim3(cdiv(N, FBW), mt), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_GELU>, dim3(cdiv(N, FBW), mt, batch), dim3(256), 0, st, g);
     } else if (epilogue == SCULPT_EPI_RELU) {
-        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_RELU>, dim3(cdiv(N, FBW), mt), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_RELU>, dim3(cdiv(N, FBW), mt, batch), dim3(256), 0, st, g);
     } else {
-        SC_REQUIRE(epilogue == SCULPT_EPI_NONE, "gemm_f32: unknown epilogue %d", epilogue);
-        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_NONE>, dim3(cdiv(N, FBW), mt), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gemm_f32_kernel<SCULPT_EPI_NONE>, dim3(cdiv(N, FBW), mt, batch), dim3(256), 0, st, g);
     }
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
+                    float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K, float alpha,
+                    int epilogue, sculpt_stream_t stream) {
+    return sculpt_gemm_f32_ex(A, lda, W, ldw, bias, residual, ldr, out, ldo, out_t, ldt, n_split, w_rows, M, N, K, alpha, epilogue,
+                              SCULPT_F32_EXACT, 1, 0, 0, 0, stream);
 }
 
 int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, sculpt_stream_t stream) {

@@ -1,8 +1,10 @@
 """Precision dispatch and buffer pool shared by the host-side model mirrors (TSR, SF3D).
 
-bf16: bf16 storage / fp32 accumulate on the MFMA kernels (what bench.py times).
-fp32: every GEMM / attention / norm on the exact-fp32 parity kernels (the reference's own precision).
-A subclass provides self.precision ("bf16" | "fp32"), self.device and self._buf = {}.
+bf16:   bf16 storage / fp32 accumulate on the MFMA kernels (what bench.py times).
+fp32:   every GEMM / attention / norm on the exact-fp32 parity kernels (the reference's own precision).
+bf16l3: fp32 storage and fp32 norms / softmax like "fp32", but every matrix product (Linears, QK^T, PV) on the bf16 matrix pipe
+        through the exact three-limb split of both operands, fp32 accumulate (csrc/gemm_l3.hip): fp32-equivalent, ~6x faster.
+A subclass provides self.precision ("bf16" | "fp32" | "bf16l3"), self.device and self._buf = {}.
 """
 import torch
 
@@ -51,20 +53,29 @@ class KernelEngine:
                             epilogue=epilogue, n_split=n_split)
         out = out_f32 if out_f32 is not None else out_bf16
         return ops.gemm_f32(A, W, bias=bias, residual=residual, out=out, out_t=out_t, M=M, epilogue=epilogue,
-                            n_split=n_split)
+                            n_split=n_split, l3=self.l3)
+
+    @property
+    def l3(self):
+        """fp32 storage with the matrix products on the three-limb bf16 pipe."""
+        return self.precision == "bf16l3"
 
     def _attn(self, Q, K, Vt, O, Tq, Tk, heads, scale, batch=1, q_bs=0, k_bs=0, vt_bs=0, o_bs=0):
         """batch > 1: `batch` independent attentions, entry b at Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (a column offset), O + b*o_bs
-        (elements): one launch in bf16 mode, a loop over the entries in the fp32 parity mode."""
+        (elements): one launch in bf16 mode, a loop over the entries in the fp32 parity modes (there one attention is three
+        launches over all heads: scores = alpha Q K^T into an fp32 [heads][Tq][Tk] scratch, row softmax, P V)."""
         if self.precision == "bf16":
             return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
-        scores = self._b("attn_scores", (Tq, ((Tk + 15) // 16) * 16), torch.float32)
+        # bf16l3: one fused launch, no score matrix; SCULPT_L3_ATTN_FUSED=0 keeps the three-launch composition (A/B)
+        import os
+        fused = self.l3 and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0"
+        scores = None if fused else self._b("attn_scores", (heads, Tq, ((Tk + 31) // 32) * 32), torch.float32)
         if batch == 1:
-            return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores)
+            return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=self.l3)
         assert q_bs % Q.stride(0) == 0 and k_bs % K.stride(0) == 0 and o_bs % O.stride(0) == 0 and vt_bs < Vt.stride(0)
         for b in range(batch):
             ops.attention_f32(Q[b * q_bs // Q.stride(0):], K[b * k_bs // K.stride(0):], Vt[:, b * vt_bs:], O[b * o_bs // O.stride(0):],
-                              Tq, Tk, heads, scale, scores)
+                              Tq, Tk, heads, scale, scores, l3=self.l3)
 
     def _ln(self, x, gamma, beta, eps, y):
         if self.precision == "bf16":

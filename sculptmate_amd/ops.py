@@ -562,33 +562,53 @@ def marching_tets(grid: TetGrid, pos, sdf, vert_mul=1.0, vert_add=0.0):
 # fp32 parity mode primitives
 # ----------------------------------------------------------------------------------------------
 def gemm_f32(A, W, bias=None, residual=None, out=None, out_t=None, M=None, N=None, epilogue=0, n_split=0, w_rows=0,
-             alpha=1.0):
-    """out[m][n] = epi(alpha * A[m][:] . W[n][:] + bias[n]) (+ residual); fp32 throughout (sculpt_gemm_f32)."""
+             alpha=1.0, l3=False, batch=1, a_bs=0, w_bs=0, o_bs=0):
+    """out[m][n] = epi(alpha * A[m][:] . W[n][:] + bias[n]) (+ residual); fp32 in and out (sculpt_gemm_f32_ex).
+    l3=False: the exact-fp32 matrix instruction.  l3=True: fp32 arithmetic on the bf16 matrix pipe through the exact
+    three-limb split of both operands (K % 32 == 0).  batch > 1: grid z, entry z at A + z*a_bs, W + z*w_bs, out + z*o_bs."""
     K = A.shape[1]
     if N is None:
         N = W.shape[0] // 2 if epilogue == _lib.EPI_GEGLU else W.shape[0]
     M = A.shape[0] if M is None else M
-    check(lib.sculpt_gemm_f32(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
-                              residual.stride(0) if residual is not None else 0, _ptr(out),
-                              out.stride(0) if out is not None else 0, _ptr(out_t),
-                              out_t.stride(0) if out_t is not None else 0, int(n_split), int(w_rows), M, N, K,
-                              float(alpha), epilogue, _stream()))
+    check(lib.sculpt_gemm_f32_ex(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
+                                 residual.stride(0) if residual is not None else 0, _ptr(out),
+                                 out.stride(0) if out is not None else 0, _ptr(out_t),
+                                 out_t.stride(0) if out_t is not None else 0, int(n_split), int(w_rows), M, N, K,
+                                 float(alpha), epilogue, _lib.F32_BF16L3 if l3 else _lib.F32_EXACT, int(batch), int(a_bs), int(w_bs),
+                                 int(o_bs), _stream()))
 
 
 def softmax_rows_f32(x, rows, cols, pad_cols):
     check(lib.sculpt_softmax_rows_f32(_ptr(x), x.stride(0), rows, cols, pad_cols, _stream()))
 
 
-def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores):
+def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False):
     """softmax(Q K^T scale) V per head in fp32: two GEMMs and a row softmax per head.
-    Q [Tq][*], K [Tk][*] with head h at columns 64h..; Vt [heads*64][>= round_up(Tk,16)] (zero padded);
-    scores: scratch fp32 [Tq][>= round_up(Tk,16)]."""
-    Tkp = ((Tk + 15) // 16) * 16
+    Q [Tq][*], K [Tk][*] with head h at columns 64h..; Vt [heads*64][>= round_up(Tk,32)] (zero padded).
+    scores: fp32 scratch.  [Tq][>= round_up(Tk,32)]: the heads run one after the other (three launches each);
+    [heads][Tq][>= round_up(Tk,32)]: all heads at once, three launches per attention (grid z = head).
+    l3: the two products on the three-limb bf16 matrix pipe (gemm_f32 l3=True) instead of the exact-fp32 instruction;
+    with scores=None (l3 only) the whole attention is ONE fused launch (sculpt_attention_f32_l3): what TSR(precision="bf16l3") runs."""
+    Tkp = ((Tk + 31) // 32) * 32 if l3 else ((Tk + 15) // 16) * 16
+    N4 = ((Tk + 3) // 4) * 4
+    if scores is None:   # the fused kernel of the three-limb mode: no score matrix in HBM
+        assert l3, "the exact-fp32 attention is a composition: it needs the scores scratch"
+        check(lib.sculpt_attention_f32_l3(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O), O.stride(0),
+                                          Tq, Tk, heads, float(scale), _stream()))
+        return
+    if scores.dim() == 3:
+        assert scores.shape[0] >= heads and scores.shape[1] == Tq and scores.is_contiguous()
+        ld = scores.shape[2]
+        flat = scores.view(-1, ld)
+        gemm_f32(Q[:, :64], K[:, :64], out=flat, M=Tq, N=N4, w_rows=Tk, alpha=scale, l3=l3, batch=heads, a_bs=64, w_bs=64, o_bs=Tq * ld)
+        softmax_rows_f32(flat, heads * Tq, Tk, Tkp)
+        gemm_f32(flat[:, :Tkp], Vt[:64, :Tkp], out=O[:, :64], M=Tq, N=64, l3=l3, batch=heads, a_bs=Tq * ld, w_bs=64 * Vt.stride(0), o_bs=64)
+        return
     for h in range(heads):
         q, k = Q[:, 64 * h:64 * h + 64], K[:, 64 * h:64 * h + 64]
-        gemm_f32(q, k, out=scores, M=Tq, N=((Tk + 3) // 4) * 4, w_rows=Tk, alpha=scale)
+        gemm_f32(q, k, out=scores, M=Tq, N=N4, w_rows=Tk, alpha=scale, l3=l3)
         softmax_rows_f32(scores, Tq, Tk, Tkp)
-        gemm_f32(scores[:, :Tkp], Vt[64 * h:64 * h + 64, :Tkp], out=O[:, 64 * h:64 * h + 64], M=Tq, N=64)
+        gemm_f32(scores[:, :Tkp], Vt[64 * h:64 * h + 64, :Tkp], out=O[:, 64 * h:64 * h + 64], M=Tq, N=64, l3=l3)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -196,8 +196,10 @@ def _f32(x, dev):
 
 class TSR(KernelEngine):
     def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16", decoder_precision="bf16l3"):
-        """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times) or
-        "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference).
+        """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times),
+        "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference), or
+        "bf16l3" (the fast parity mode: fp32 storage, norms and softmax as in "fp32", every matrix product on the bf16 matrix pipe
+        with both operands split exactly into three bf16 limbs and fp32 accumulation -- fp32-equivalent, csrc/gemm_l3.hip).
         decoder_precision: how the 64x64 hidden layers of the dense density query (extract_mesh's 256^3 grid) are evaluated.
           "bf16l3" (default): fp32-equivalent -- both operands split EXACTLY into three bf16 limbs (24 significant bits, fp32
                    exponent range), six exact products per weight on the bf16 matrix pipe, fp32 accumulation; no range
@@ -205,8 +207,8 @@ class TSR(KernelEngine):
           "fp32":  the exact-fp32 MFMA kernel (a k-ordered fmaf chain, 1.5x slower): the parity mode.
           "fp16x3" / "bf16x3": two-limb experiments with 22 / 16-bit operands (fp16x3 needs |activation| < 65504 and falls
                    back to fp32 when the volume comes out non-finite); kept for A/B only, never the default."""
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp32", "bf16l3"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'bf16l3'")
         if decoder_precision not in ("fp32", "bf16l3", "bf16x3", "fp16x3"):
             raise ValueError("decoder_precision must be 'bf16l3', 'fp32', 'fp16x3' or 'bf16x3'")
         self.decoder_precision = decoder_precision
@@ -487,7 +489,7 @@ class TSR(KernelEngine):
             outb = self._b("bb_outb", (M, C), BF16)
             ops.gemm(st["hb"], w["pout_w"], bias=w["pout_b"], residual=res, out_f32=out, out_bf16=outb)  # hb = bf16(h)
         else:
-            ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=res, out=out)
+            ops.gemm_f32(h, w["pout_w"], bias=w["pout_b"], residual=res, out=out, l3=self.l3)
             outb = out
         return out, outb
 

@@ -760,6 +760,24 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     v, f = mesh.vertices.cpu().numpy(), mesh.faces.cpu().numpy()
     info = assert_mesh_close(v, f, rv, rf, tol=1e-4 * 1.74)  # unconditional: same topology or not
     print("image -> mesh at %d^3: %d vertices, %d faces, %s" % (R, len(v), len(f), info))
+    # the FAST parity mode (precision="bf16l3": fp32 storage, every matrix product with three-limb bf16 operands and fp32
+    # accumulation, fused three-limb attention): the same two assertions as the exact-fp32 mode -- scene code within fp32 rounding
+    # of the oracle, image -> mesh within the north-star tolerance with the oracle's topology -- at ~1/6 of its time
+    del m32
+    torch.cuda.empty_cache()
+    ml3 = TSR(pos_embed_mode="scale_factor", precision="bf16l3")
+    ml3.load_state_dict(sd)
+    ml3.to(cuda)
+    cl3 = ml3([img], device=cuda)
+    rell3, _ = _rel(cl3[0], ref32)
+    print("full-size scene code, bf16l3 mode: rel %.3e (exact-fp32 mode %.3e)" % (rell3, rel32))
+    assert rell3 < 1e-4 and rell3 < 2.0 * rel32 + 1e-6, (rell3, rel32)
+    densl3 = ops.density_grid(cl3[0].contiguous(), ml3.decoder, R)
+    assert float(np.abs(np.log(densl3.cpu().numpy()) - np.log(dref)).max()) < 2e-4
+    meshl3 = ml3.extract_meshes(cl3, resolution=R, threshold=thr)[0]
+    infol3 = assert_mesh_close(meshl3.vertices.cpu().numpy(), meshl3.faces.cpu().numpy(), rv, rf, tol=1e-4 * 1.74)
+    print("image -> mesh at %d^3 in bf16l3 mode: %s" % (R, infol3))
+    m32 = ml3   # the bf16-mode comparison below only needs a decoder
     # The DEFAULT mode (bf16 transformer, what bench.py times) against the same fp32 CPU mesh: the scene code is 0.8 % away
     # (bf16 weights and activations through 28 layers), so the iso-surface moves; how far is stated here and in bench.py's
     # `parity.bf16_mesh_vs_fp32_cpu` as two-sided nearest-vertex distances over the 1.74 extent.  Measured on MI355X
@@ -797,6 +815,144 @@ def test_gemm_f32_and_softmax(cuda):
     xs = x.clone().to(cuda)
     ops.softmax_rows_f32(xs, 37, 100, 112)
     assert _rel(xs[:, :100], torch.softmax(x[:, :100], -1))[1] < 1e-6 and (xs[:, 100:] == 0).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 64), (1025, 768, 768), (3072, 1028, 64), (3072, 1024, 4096), (77, 64, 3072), (1, 4, 32)])
+def test_gemm_three_limb_bf16_is_fp32_equivalent(cuda, M, N, K):
+    """sculpt_gemm_f32_ex(SCULPT_F32_BF16L3): both fp32 operands split exactly into three bf16 limbs, six exact products, fp32
+    accumulate.  Against an fp64 product of the SAME fp32 operands it must be as close as the exact-fp32 matrix instruction is
+    (both errors are fp32 accumulation error; the dropped limb products are < 2^-23 relative) -- on plain data, on data with a
+    huge dynamic range inside a row (limbs of very different exponents), and with operands that are exact bf16 values."""
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    for case in ("normal", "range", "bf16"):
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) / math.sqrt(K)
+        if case == "range":
+            A = A * torch.exp2(torch.randint(-20, 20, (M, K), generator=g).float())
+            W = W * torch.exp2(torch.randint(-12, 12, (N, K), generator=g).float())
+        if case == "bf16":
+            A, W = A.to(BF).float(), W.to(BF).float()
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = A.double() @ W.double().t() * 0.5 + b.double() + r.double()
+        mag = (A.double().abs() @ W.double().abs().t() * 0.5 + b.abs().double() + r.abs().double())   # sum |a||w|: the error scale
+        out3 = torch.empty(M, N, device=cuda)
+        out1 = torch.empty(M, N, device=cuda)
+        ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), residual=r.to(cuda), out=out3, alpha=0.5, l3=True)
+        ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), residual=r.to(cuda), out=out1, alpha=0.5) if K % 16 == 0 else None
+        e3 = float(((out3.cpu().double() - ref).abs() / mag).max())
+        e1 = float(((out1.cpu().double() - ref).abs() / mag).max()) if K % 16 == 0 else 1e-6
+        # relative to sum |a||w|: fp32 accumulation of K terms; measured 1e-7 .. 5e-7 for BOTH kernels (the wide-range rows,
+        # where single products dominate a sum, sit at the top: 4.9e-7 here, 5.4e-7 for the exact instruction)
+        assert e3 < 5e-6, (case, e3, e1)                       # (1.3e-6 / 1.4e-6 at K = 768 on the wide-range rows)
+        assert e3 < 2.0 * e1 + 2.5 * 2.0 ** -23, (case, e3, e1)
+        if case == "bf16":   # one limb each: the single product W1 x1 is exact, only the accumulation order differs from fp32
+            assert _rel(out3, ref.float())[0] < 2e-7
+
+
+def test_gemm_three_limb_epilogues_batch_and_split(cuda):
+    """The l3 kernel shares gemm_f32's epilogue: GEGLU / GELU, the Q|K / V^T column split, w_rows clamping, and grid-z batches
+    (the heads of an attention as one launch) against torch on the host."""
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(130, 128, generator=g); W = torch.randn(256, 128, generator=g) / 11; b = torch.randn(256, generator=g)
+    pre = (A.double() @ W.double().t() + b.double())
+    o = torch.empty(130, 128, device=cuda)
+    ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), out=o, epilogue=_lib.EPI_GEGLU, l3=True)
+    assert _rel(o, (pre[:, :128] * torch.nn.functional.gelu(pre[:, 128:])).float())[1] < 2e-5
+    o2 = torch.empty(130, 256, device=cuda)
+    ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), out=o2, epilogue=_lib.EPI_GELU, l3=True)
+    assert _rel(o2, torch.nn.functional.gelu(pre).float())[1] < 2e-5
+    # column split: first 128 columns token-major, the rest transposed
+    o3 = torch.empty(130, 128, device=cuda); ot = torch.zeros(128, 192, device=cuda)
+    ops.gemm_f32(A.to(cuda), W.to(cuda), bias=b.to(cuda), out=o3, out_t=ot, n_split=128, l3=True)
+    assert _rel(o3, pre[:, :128].float())[0] < 3e-7 and _rel(ot[:, :130].t(), pre[:, 128:].float())[0] < 3e-7 and (ot[:, 130:] == 0).all()
+    # heads of an attention as one launch: scores[h] = 0.125 Q_h K_h^T (w_rows clamp on a ragged key count), then P V per head
+    heads, Tq, Tk = 3, 70, 45
+    D = heads * 64
+    Q = torch.randn(Tq, D, generator=g); K = torch.randn(Tk, D, generator=g); V = torch.randn(Tk, D, generator=g)
+    Vt = torch.zeros(D, 64); Vt[:, :Tk] = V.t()
+    O = torch.empty(Tq, D, device=cuda)
+    scores = torch.empty(heads, Tq, 64, device=cuda)
+    ops.attention_f32(Q.to(cuda), K.to(cuda), Vt.to(cuda), O, Tq, Tk, heads, 0.125, scores, l3=True)
+    qh = Q.double().view(Tq, heads, 64).transpose(0, 1); kh = K.double().view(Tk, heads, 64).transpose(0, 1)
+    vh = V.double().view(Tk, heads, 64).transpose(0, 1)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) * 0.125, -1) @ vh).transpose(0, 1).reshape(Tq, D)
+    assert _rel(O, ref.float())[0] < 1e-6
+    O1 = torch.empty(Tq, D, device=cuda)
+    ops.attention_f32(Q.to(cuda), K.to(cuda), Vt.to(cuda), O1, Tq, Tk, heads, 0.125, torch.empty(Tq, 64, device=cuda), l3=True)
+    assert torch.equal(O1, O)      # head by head == all heads in one launch
+    O2 = torch.empty(Tq, D, device=cuda)
+    ops.attention_f32(Q.to(cuda), K.to(cuda), Vt.to(cuda), O2, Tq, Tk, heads, 0.125, torch.empty(heads, Tq, 48, device=cuda))
+    assert _rel(O2, ref.float())[0] < 1e-6   # the exact-fp32 instruction through the same batched launches
+
+
+@pytest.mark.parametrize("Tq,Tk,heads", [(3072, 3072, 16), (3072, 1025, 16), (1025, 1025, 12), (200, 77, 2), (37, 5, 1), (130, 640, 3)])
+def test_fused_three_limb_attention_vs_fp64(cuda, Tq, Tk, heads):
+    """sculpt_attention_f32_l3 (one launch: three-limb QK^T, fp32 online softmax in registers, three-limb PV) against an fp64
+    softmax of the same fp32 operands -- the bound of an fp32 evaluation (1e-6 of the norm), three orders below the bf16 kernel;
+    one key is spiked so that the running maximum jumps late in the sequence, and one query row sees only tiny scores."""
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(Tq * 3 + Tk)
+    D = heads * 64
+    Q = torch.randn(Tq, D, generator=g); K = torch.randn(Tk, D, generator=g); V = torch.randn(Tk, D, generator=g)
+    K[Tk - 1, :64] = 6.0 * Q[min(3, Tq - 1), :64]            # a late maximum jump for one query of head 0
+    Q[min(5, Tq - 1)] *= 1e-3
+    ldv = ((Tk + 63) // 64) * 64
+    Vt = torch.zeros(D, ldv); Vt[:, :Tk] = V.t()
+    Vt[:, Tk:] = 7.0                                            # padding columns: finite, multiplied by exact zeros
+    O = torch.empty(Tq, D, device=cuda)
+    ops.attention_f32(Q.to(cuda), K.to(cuda), Vt.to(cuda), O, Tq, Tk, heads, 0.125, None, l3=True)
+    qh = Q.double().view(Tq, heads, 64).transpose(0, 1); kh = K.double().view(Tk, heads, 64).transpose(0, 1)
+    vh = V.double().view(Tk, heads, 64).transpose(0, 1)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) * 0.125, -1) @ vh).transpose(0, 1).reshape(Tq, D)
+    rel, mx = _rel(O, ref.float())
+    assert torch.isfinite(O).all() and rel < 1e-6 and mx < 2e-5, (rel, mx)
+    # the composition (scores in HBM) on the same limb arithmetic agrees to fp32 rounding
+    O2 = torch.empty(Tq, D, device=cuda)
+    ops.attention_f32(Q.to(cuda), K.to(cuda), Vt.to(cuda), O2, Tq, Tk, heads, 0.125,
+                      torch.empty(heads, Tq, ((Tk + 31) // 32) * 32, device=cuda), l3=True)
+    assert _rel(O2, ref.float())[0] < 1e-6 and _rel(O, O2)[0] < 1e-6
+
+
+def test_bf16l3_parity_mode_small_and_mesh(cuda):
+    """TSR(precision='bf16l3'): fp32 storage, every matrix product on the bf16 matrix pipe through the exact three-limb split --
+    the same bounds as the exact-fp32 mode: scene code within fp32 rounding of the oracle, mesh within the north-star 1e-4."""
+    from oracle import capi
+    from sculptmate_amd.tsr import TSR
+
+    sd = synth.tsr_state(31, SMALL_CFG)
+    m = TSR(SMALL_CFG, pos_embed_mode="size", precision="bf16l3")
+    m.load_state_dict(sd)
+    m.to(cuda)
+    img = synth.composite_rgb(synth.image_rgba(seed=32, size=SMALL_CFG["cond_image_size"]))
+    codes = m([img], device=cuda)
+    ref = tsr_ref.tsr_forward(sd, img, SMALL_CFG, pos_mode="size")
+    rel, mx = _rel(codes[0], ref)
+    assert rel < 2e-5, rel
+    m32 = TSR(SMALL_CFG, pos_embed_mode="size", precision="fp32")
+    m32.load_state_dict(sd)
+    m32.to(cuda)
+    rel32, _ = _rel(m32([img], device=cuda)[0], ref)
+    print("small model scene code vs fp32 oracle: bf16l3 %.3e, exact fp32 %.3e" % (rel, rel32))
+    assert rel < 2.0 * rel32 + 2e-7
+    R = 40
+    Ws, bs = synth.decoder_lists(sd)
+    dens_ref = capi.density_grid(ref.numpy(), Ws, bs, R)
+    thr = float(np.median(dens_ref))
+    mesh = m.run([img], mc_resolution=R, threshold=thr)[0]
+    rv, rf = capi.reference_isosurface(-(dens_ref - np.float32(thr)), R)
+    rv = rv * np.float32(0.87 - (-0.87)) + np.float32(-0.87)
+    from _meshcmp import assert_mesh_close
+
+    assert_mesh_close(mesh.vertices, mesh.faces, rv, rf, tol=1e-4 * 1.74)
+    # a batch in this mode runs the entries' attentions one after the other (engine._attn) on the same stacked Linears
+    two = m([img, synth.composite_rgb(synth.image_rgba(seed=33, size=SMALL_CFG["cond_image_size"]))], device=cuda)
+    assert _rel(two[0], ref)[0] < 2e-5
 
 
 def test_fp32_parity_mode_small_and_mesh(cuda):
