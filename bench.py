@@ -84,10 +84,27 @@ def one_step(model, img_dev, events=None):
 
 
 def boundary_rate(model, imgs_host, steps):
-    """The same work through the host boundary: TSR.run_async(host fp32 HWC image) -> PendingMesh -> host arrays.
-    Steady state: the pinned device->host copy of mesh i runs on a copy stream under the kernels of image i+1."""
-    # warm-up: the pinned-buffer pool and the upload ring fill during the first few images (a pinned allocation of a 54 MB mesh
-    # is a ~1 ms driver call; three meshes are in flight at most)
+    """The same work through the host boundary, by the entry north_star names: TSR.run(list of host fp32 HWC images) -> list of
+    Mesh with host (NumPy, pinned) arrays.  Inside, per image: H2D of the 3 MB image + ImagePreprocessor + tokenizer on a second
+    stream one image ahead (TSR.tokens_async), backbone / density grid / marching cubes on the current stream, the mesh (the
+    reference's `.cpu().numpy()`, system.py:200) device -> pinned host on a copy stream under the next image's kernels.
+    `meshes_per_s` = images / wall time of run() calls on lists of up to 20 images; `run_async_loop` = the hand-rolled loop of
+    TSR.run_async without the look-ahead (round 3's figure); `latency_ms_single_image` = one image alone, nothing to overlap."""
+    chunk = max(1, min(steps, 20))
+    lists = [[imgs_host[(c * chunk + i) % len(imgs_host)] for i in range(chunk)] for c in range(max(1, steps // chunk))]
+    nbytes = 0
+    for _ in range(2):   # warm-up: the pinned-buffer pool (a pinned allocation of a 54 MB mesh is a ~1 ms driver call), streams, slots
+        model.run(lists[0], MC_RES, THRESHOLD)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_run = 0
+    for lst in lists:
+        meshes = model.run(lst, MC_RES, THRESHOLD)
+        n_run += len(meshes)
+        nbytes = meshes[-1].vertices.nbytes + meshes[-1].faces.nbytes
+        del meshes
+    dt_run = time.perf_counter() - t0
+    # the hand-rolled loop: one run_async per image, mesh i collected while image i + 1 runs, no tokenizer look-ahead
     prev = model.run_async(imgs_host[0], MC_RES, THRESHOLD)
     for i in range(1, 5):
         cur = model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD)
@@ -96,37 +113,12 @@ def boundary_rate(model, imgs_host, steps):
     prev.result()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nbytes = 0
     for i in range(steps):
         cur = model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD)
-        m = prev.result()
-        nbytes = m.vertices.nbytes + m.faces.nbytes
+        prev.result()
         prev = cur
-    m = prev.result()
+    prev.result()
     dt = time.perf_counter() - t0
-    # the batch form of the same boundary (TSR.run / run_sharded): the image tokenizer of image i + 1 queued on a second stream
-    # beside the backbone / density grid / marching cubes of image i (TSR.tokens_async), same meshes bit for bit
-    nxt = model.tokens_async(imgs_host[0])
-    prev = None
-    for i in range(4):   # warm-up: streams, token slots
-        cur_tok, nxt = nxt, model.tokens_async(imgs_host[(i + 1) % len(imgs_host)])
-        cur = model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD, tokens=cur_tok)
-        if prev is not None:
-            prev.result()
-        prev = cur
-    prev.result()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    prev = None
-    for i in range(steps):   # the tokens of image `steps` (the look-ahead of the last iteration) are extra work inside the region
-        cur_tok, nxt = nxt, model.tokens_async(imgs_host[(i + 5) % len(imgs_host)])
-        cur = model.run_async(imgs_host[(i + 4) % len(imgs_host)], MC_RES, THRESHOLD, tokens=cur_tok)
-        if prev is not None:
-            prev.result()
-        prev = cur
-    prev.result()
-    torch.cuda.synchronize()
-    dt_look = time.perf_counter() - t1
     # latency of ONE image with nothing to overlap: host image in -> host mesh out
     lat = []
     for i in range(3):
@@ -134,11 +126,11 @@ def boundary_rate(model, imgs_host, steps):
         t1 = time.perf_counter()
         model.run_async(imgs_host[i % len(imgs_host)], MC_RES, THRESHOLD).result()
         lat.append((time.perf_counter() - t1) * 1e3)
-    return {"entry": "TSR.run_async(host fp32 HWC 512x512 image) -> host (pinned) vertices + int64 faces",
-            "meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "latency_ms_single_image": float(np.median(lat)),
-            "tokenizer_lookahead": {"entry": "TSR.tokens_async(image i + 1) beside TSR.run_async(image i, tokens=...) -- what TSR.run / "
-                                             "run_sharded do with several images; same meshes",
-                                    "meshes_per_s": steps / dt_look, "ms_per_step": dt_look / steps * 1e3},
+    return {"entry": "TSR.run([host fp32 HWC 512x512 images]) -> host (pinned) vertices + int64 faces per image; lists of %d" % chunk,
+            "meshes_per_s": n_run / dt_run, "ms_per_step": dt_run / n_run * 1e3, "images_timed": n_run,
+            "run_async_loop": {"entry": "TSR.run_async(image) per image, mesh i collected under image i + 1, no tokenizer look-ahead",
+                               "meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3},
+            "latency_ms_single_image": float(np.median(lat)),
             "h2d_bytes_per_image": int(imgs_host[0].nbytes), "d2h_bytes_per_mesh": int(nbytes)}
 
 

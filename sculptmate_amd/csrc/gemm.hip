@@ -832,6 +832,13 @@ static const uint16_t *zero_page() {
     return pages[dev];
 }
 
+namespace sculpt {
+const float *zero_floats_page(long *count) {
+    if (count) *count = ZERO_FLOATS;
+    return reinterpret_cast<const float *>(zero_page());
+}
+}  // namespace sculpt
+
 extern "C" int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, int H, int W, int C_pad, int dilation,
                                    const uint16_t *Wt, const float *bias, float *out_f32, uint16_t *out_bf16, int ldo,
                                    int n_store, int N, int epilogue, sculpt_stream_t stream) {

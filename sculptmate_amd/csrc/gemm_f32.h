@@ -19,6 +19,7 @@ struct GemmF32Args {
     int n_split;
     int w_rows;   // valid rows of W (rows beyond are clamped; lets N be padded to a multiple of 4)
     float alpha;  // scale applied to the accumulator before bias (attention scores)
+    // (bias is never null inside the kernels: the launcher substitutes the zero page)
     // blockIdx.z = batch entry (the heads of an attention as ONE launch): element strides of A, W, out / out_t, residual
     long a_bs, w_bs, o_bs;
 };
@@ -48,11 +49,13 @@ __device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f3
             if (EPI == SCULPT_EPI_GEGLU) {
                 // wave rows [wr*64, +32) = value group, [+32, +64) = gate group of output columns n0 + wr*32 ..
                 const int n = n0 + wr * 32 + 8 * q4 + 4 * lh;
+                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n), bg = *reinterpret_cast<const float4 *>(g.bias + g.N + n);
+                const float bvs[4] = {bv.x, bv.y, bv.z, bv.w}, bgs[4] = {bg.x, bg.y, bg.z, bg.w};
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = acc[0][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f);
-                    const float gt = acc[1][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[g.N + n + r] : 0.f);
+                    const float v = acc[0][j][4 * q4 + r] * g.alpha + bvs[r];
+                    const float gt = acc[1][j][4 * q4 + r] * g.alpha + bgs[r];
                     o[r] = v * gelu_erf_exact(gt);
                 }
                 *reinterpret_cast<float4 *>(g.out + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
@@ -61,10 +64,12 @@ __device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f3
                 for (int i = 0; i < 2; ++i) {
                     const int n = n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
                     if (n >= g.N) continue;  // N is a multiple of 4: a quad is entirely in or out
+                    const float4 b4 = *reinterpret_cast<const float4 *>(g.bias + n);
+                    const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
                     float o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc[i][j][4 * q4 + r] * g.alpha + (g.bias ? g.bias[n + r] : 0.f);
+                        float v = acc[i][j][4 * q4 + r] * g.alpha + bs[r];
                         if (EPI == SCULPT_EPI_GELU) v = gelu_erf_exact(v);
                         if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
                         o[r] = v;
@@ -96,6 +101,10 @@ __device__ __forceinline__ GemmF32Args f32_batch_entry(GemmF32Args g) {
     if (g.residual) g.residual += z * g.o_bs;
     return g;
 }
+
+// gemm.hip: a per-device page of zeros (`*count` floats) that stands in for a missing bias vector, so that the epilogue's bias
+// loads are unconditional float4 loads (a per-element `bias ? bias[n] : 0` makes hipcc branch around every load and wait for it)
+const float *zero_floats_page(long *count);
 
 // gemm_l3.hip
 int gemm_l3_launch(const GemmF32Args &g, int epilogue, int batch, hipStream_t st);

@@ -127,6 +127,12 @@ int sculpt_gemm_f32_ex(const float *A, int lda, const float *W, int ldw, const f
     if (n_split <= 0 || n_split > N) n_split = N;
     SC_REQUIRE(n_split % 4 == 0 && (n_split == N || out_t), "gemm_f32: bad n_split");
     if (w_rows <= 0 || w_rows > N) w_rows = N;
+    if (!bias) {   // unconditional float4 bias loads in the epilogue: a zero page stands in for a missing vector
+        long zn = 0;
+        bias = zero_floats_page(&zn);
+        SC_REQUIRE(bias && (epilogue == SCULPT_EPI_GEGLU ? 2L * N : (long)N) + 4 <= zn, "gemm_f32: N=%d too large without a bias", N);
+    }
+    SC_REQUIRE(((uintptr_t)bias & 15) == 0, "gemm_f32: bias must be 16-byte aligned");
     GemmF32Args g{A, lda, W, ldw, bias, residual, ldr, out, ldo, out_t, ldt, M, N, K, n_split, w_rows, alpha,
                   batch > 1 ? (long)a_bs : 0, batch > 1 ? (long)w_bs : 0, batch > 1 ? (long)o_bs : 0};
     hipStream_t st = as_stream(stream);

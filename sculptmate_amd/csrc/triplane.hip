@@ -1019,7 +1019,14 @@ __global__ __launch_bounds__(NT) void density_grid_l3k_kernel(
     int iy = (int)(t_begin % R);
     int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
     const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;               // [l][part][T][s][lane]
+#ifdef SCULPT_L3_W3_LDS_EXPERIMENT
+    // TIMING EXPERIMENT ONLY (wrong values): every third-limb fragment read from LDS (the W1 | W2 image) instead of L2 -- an upper
+    // bound on what keeping W3 on chip could return (only three of the eight layers' W3 would really fit beside W1 | W2);
+    // tools/micro/density_shape_experiment.sh, profiles/round4/density_levers.txt
+    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(smem) + lane;
+#else
     const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;  // [l][T][s][lane], global (L2)
+#endif
 
     for (long t = t_begin; t < t_end; ++t, ++iy) {
         if (iy == R) {

@@ -7,6 +7,10 @@ from sculptmate_amd import ops
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 M, N = 3072, 1024
 res_mode = len(sys.argv) > 1 and sys.argv[1] == "residual"
+if len(sys.argv) > 1 and sys.argv[1] in ("g256", "g256full"):
+    # the 256 x 256 tile kernel: a 48-tile launch (every workgroup has a CU to itself) or FF1's shape with every CU on it
+    os.environ["SCULPT_GEMM_256"], os.environ["SCULPT_GEMM_192"] = "2", "0"
+    M, N = (768, 4096) if sys.argv[1] == "g256" else (3072, 8192)
 g = torch.Generator().manual_seed(0)
 for K in (64, 128, 256, 512, 1024, 2048, 4096):
     A = torch.randn(M, K, generator=g).to(BF).to(dev); W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev)

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/ksweep; rm -rf $OUT; mkdir -p $OUT; cd $R
-for mode in plain residual; do
+for mode in plain residual g256 g256full; do
 rocprofv3 --kernel-trace --output-format csv -d $OUT/$mode -- python3 tools/gemm_ksweep.py $mode > $OUT/$mode.log 2>&1
 python3 - <<PY
 import csv, glob
