@@ -37,12 +37,13 @@ __device__ __forceinline__ int f32_tile_wrow(const GemmF32Args &g, int n0, int j
 }
 
 // acc[i][j][r]: column m = m0 + wc*64 + j*32 + l31; tile row = wr*64 + i*32 + (r&3) + 8*(r>>2) + 4*lh
-template <int EPI>
-__device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f32x16 (&acc)[2][2], int n0, int m0, int wr, int wc,
+// (JT = 32-row activation sub-tiles per wave: 2 for the 128-row tile, 1 for gemm_l3's 64-row tile)
+template <int EPI, int JT = 2>
+__device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f32x16 (&acc)[2][JT], int n0, int m0, int wr, int wc,
                                                   int l31, int lh) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wc * 64 + j * 32 + l31;
+    for (int j = 0; j < JT; ++j) {
+        const int m = m0 + wc * (32 * JT) + j * 32 + l31;
         if (m >= g.M) continue;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {  // register quad: rows 8*q4 + 4*lh + {0..3}

@@ -58,15 +58,20 @@ __device__ __forceinline__ void l3_split4(const float4 &x, uint2 &p1, uint2 &p2,
 // PIPE = true (default): the split of K-step kt + 1 is issued in the shadows of the MFMAs of K-step kt by the SAME wave (a wave's
 // own vector instructions behind its own MFMA are free up to ~6 per MFMA, tools/micro/mfma_fill.hip) -- the limbs wait in 48
 // registers for the barrier, then only the 24 ds_write_b64 and the next global loads sit between the two barriers.
-template <int EPI, bool PIPE>
+// BM = 128 activation rows per tile, or 64 (plain loop only): launches that would leave CUs without a tile at 128 rows -- the
+// N = 1024 projections of the backbone (192 tiles of 128 x 128 on 256 CUs), everything in the 1025-token image tokenizer -- get
+// twice the tiles, a wave then owns 64 weight rows x 32 activation rows.
+template <int EPI, bool PIPE, int BM = 128>
 __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
+    static_assert(BM == 128 || (BM == 64 && !PIPE), "64-row tiles run the plain K loop");
+    constexpr int JT = BM / 64, AI = BM / 32;   // 32-row activation sub-tiles per wave; float4 per thread and K-step of the activation tile
     const GemmF32Args g = f32_batch_entry(g_in);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * L3_OP];   // [W limbs | A limbs]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * L3_OP];   // [W limbs | A limbs] (the A planes keep 128-row strides)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? FBW / 2 : FBW;
-    const int n0 = blockIdx.x * NOUT, m0 = blockIdx.y * FBM;
+    const int n0 = blockIdx.x * NOUT, m0 = blockIdx.y * BM;
 
     // staging: a tile is 128 rows x 32 k = 1024 float4; thread t takes k-quad t % 8 of rows t / 8 + 32 i (a row's 128 bytes are
     // one cache line read by 8 neighbouring lanes)
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         wp[i] = g.W + (long)f32_tile_wrow<EPI>(g, n0, sr + 32 * i) * g.ldw + 4 * kq;
-        ap[i] = g.A + (long)min(m0 + sr + 32 * i, g.M - 1) * g.lda + 4 * kq;
+        ap[i] = g.A + (long)min(m0 + sr + 32 * (i < AI ? i : 0), g.M - 1) * g.lda + 4 * kq;
     }
     // LDS byte offset of this thread's 8-byte piece of row sr in a limb plane (chunk = kq / 2, half = kq % 2)
     const int wofs = (kq >> 1) * L3_CS + sr * 16 + (kq & 1) * 8;
@@ -83,31 +88,31 @@ __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
     uint2 pw[4][3], pa[4][3];   // PIPE: the limbs of the next K-step, waiting for the barrier
     const int nk = g.K / L3_BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][JT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    // fragment read offsets: k-step s reads chunk 2 s + lh; rows wr * 64 + i * 32 + l31 (W) / wc * 64 + j * 32 + l31 (A)
+    // fragment read offsets: k-step s reads chunk 2 s + lh; rows wr * 64 + i * 32 + l31 (W) / wc * 32 JT + j * 32 + l31 (A)
     const int wfo = lh * L3_CS + (wr * 64 + l31) * 16;
-    const int afo = L3_OP + lh * L3_CS + (wc * 64 + l31) * 16;
+    const int afo = L3_OP + lh * L3_CS + (wc * (32 * JT) + l31) * 16;
 
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             rw[i] = *reinterpret_cast<const float4 *>(wp[i] + kt * L3_BK);
-            ra[i] = *reinterpret_cast<const float4 *>(ap[i] + kt * L3_BK);
+            if (i < AI) ra[i] = *reinterpret_cast<const float4 *>(ap[i] + kt * L3_BK);
         }
     };
     auto split_all = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             l3_split4(rw[i], pw[i][0], pw[i][1], pw[i][2]);
-            l3_split4(ra[i], pa[i][0], pa[i][1], pa[i][2]);
+            if (i < AI) l3_split4(ra[i], pa[i][0], pa[i][1], pa[i][2]);
         }
     };
     auto write_all = [&]() {
@@ -117,23 +122,23 @@ __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 *reinterpret_cast<uint2 *>(d + l * L3_LT) = pw[i][l];
-                *reinterpret_cast<uint2 *>(d + L3_OP + l * L3_LT) = pa[i][l];
+                if (i < AI) *reinterpret_cast<uint2 *>(d + L3_OP + l * L3_LT) = pa[i][l];
             }
         }
     };
     auto mfma_kstep = [&](int s) {
-        lbf16x8 wf[2][3], af[2][3];
+        lbf16x8 wf[2][3], af[JT][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 wf[i][l] = *reinterpret_cast<const lbf16x8 *>(smem + wfo + l * L3_LT + 2 * s * L3_CS + i * (32 * 16));
-                af[i][l] = *reinterpret_cast<const lbf16x8 *>(smem + afo + l * L3_LT + 2 * s * L3_CS + i * (32 * 16));
+                if (i < JT) af[i < JT ? i : 0][l] = *reinterpret_cast<const lbf16x8 *>(smem + afo + l * L3_LT + 2 * s * L3_CS + i * (32 * 16));
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < JT; ++j) {
                 f32x16 c = acc[i][j];   // smallest terms first
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][2], af[j][0], c, 0, 0, 0);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
     };
 
     gload(0);
-    if (PIPE) {
+    if constexpr (PIPE) {
         split_all();
         write_all();
         __syncthreads();
@@ -236,22 +241,29 @@ __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
             mfma_kstep(1);
         }
     }
-    f32_tile_epilogue<EPI>(g, acc, n0, m0, wr, wc, l31, lh);
+    f32_tile_epilogue<EPI, JT>(g, acc, n0, m0, wr, wc, l31, lh);
 }
 
 int gemm_l3_launch(const GemmF32Args &g, int epilogue, int batch, hipStream_t st) {
-    const int mt = cdiv(g.M, FBM);
     const char *e = getenv("SCULPT_L3_PIPE");   // 0: the plain (phase-separated) K loop, for A/B; read per call
     const bool pipe = !(e && atoi(e) == 0);
-#define L3_GO(E, GX)                                                                                                      \
+    const char *e64 = getenv("SCULPT_L3_BM64");  // 0 / 1: never / always the 64-row tile (A/B); default: by CU fill
+    const int gx = epilogue == SCULPT_EPI_GEGLU ? g.N / 64 : cdiv(g.N, FBW);
+    const long tiles128 = (long)gx * cdiv(g.M, 128) * batch;
+    // fewer than 3 tiles per CU at 128 rows (tools/time_l3_gemm.py: fused Q|K|V 149 -> 133 us, to_out 65 -> 56, FF2 213 -> 190, the
+    // image tokenizer's f2 151 -> 99; FF1 with 6 tiles per CU: 286 -> 313, stays)
+    const bool bm64 = e64 ? atoi(e64) != 0 : tiles128 < 3L * num_cus();
+    const int mt = cdiv(g.M, bm64 ? 64 : 128);
+#define L3_GO(E)                                                                                                          \
     do {                                                                                                                  \
-        if (pipe) hipLaunchKernelGGL((gemm_l3_kernel<E, true>), dim3(GX, mt, batch), dim3(256), 0, st, g);                \
-        else hipLaunchKernelGGL((gemm_l3_kernel<E, false>), dim3(GX, mt, batch), dim3(256), 0, st, g);                    \
+        if (bm64) hipLaunchKernelGGL((gemm_l3_kernel<E, false, 64>), dim3(gx, mt, batch), dim3(256), 0, st, g);           \
+        else if (pipe) hipLaunchKernelGGL((gemm_l3_kernel<E, true, 128>), dim3(gx, mt, batch), dim3(256), 0, st, g);      \
+        else hipLaunchKernelGGL((gemm_l3_kernel<E, false, 128>), dim3(gx, mt, batch), dim3(256), 0, st, g);               \
     } while (0)
-    if (epilogue == SCULPT_EPI_GEGLU) L3_GO(SCULPT_EPI_GEGLU, g.N / 64);
-    else if (epilogue == SCULPT_EPI_GELU) L3_GO(SCULPT_EPI_GELU, cdiv(g.N, FBW));
-    else if (epilogue == SCULPT_EPI_RELU) L3_GO(SCULPT_EPI_RELU, cdiv(g.N, FBW));
-    else L3_GO(SCULPT_EPI_NONE, cdiv(g.N, FBW));
+    if (epilogue == SCULPT_EPI_GEGLU) L3_GO(SCULPT_EPI_GEGLU);
+    else if (epilogue == SCULPT_EPI_GELU) L3_GO(SCULPT_EPI_GELU);
+    else if (epilogue == SCULPT_EPI_RELU) L3_GO(SCULPT_EPI_RELU);
+    else L3_GO(SCULPT_EPI_NONE);
 #undef L3_GO
     return 0;
 }
