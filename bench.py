@@ -104,6 +104,18 @@ def boundary_rate(model, imgs_host, steps):
         nbytes = meshes[-1].vertices.nbytes + meshes[-1].faces.nbytes
         del meshes
     dt_run = time.perf_counter() - t0
+    # the same entry with batched transformer passes (TSR.run(images, batch=4)): meshes differ from the one-image pass by bf16 rounding
+    batched4 = None
+    try:
+        model.run(lists[0], MC_RES, THRESHOLD, batch=4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = 0
+        for lst in lists:
+            nb += len(model.run(lst, MC_RES, THRESHOLD, batch=4))
+        batched4 = {"entry": "TSR.run(images, batch=4): four images per transformer pass", "meshes_per_s": nb / (time.perf_counter() - t0)}
+    except Exception as e:
+        batched4 = {"error": "%s: %s" % (type(e).__name__, e)}
     # the hand-rolled loop: one run_async per image, mesh i collected while image i + 1 runs, no tokenizer look-ahead
     prev = model.run_async(imgs_host[0], MC_RES, THRESHOLD)
     for i in range(1, 5):
@@ -128,6 +140,7 @@ def boundary_rate(model, imgs_host, steps):
         lat.append((time.perf_counter() - t1) * 1e3)
     return {"entry": "TSR.run([host fp32 HWC 512x512 images]) -> host (pinned) vertices + int64 faces per image; lists of %d" % chunk,
             "meshes_per_s": n_run / dt_run, "ms_per_step": dt_run / n_run * 1e3, "images_timed": n_run,
+            "batched4": batched4,
             "run_async_loop": {"entry": "TSR.run_async(image) per image, mesh i collected under image i + 1, no tokenizer look-ahead",
                                "meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3},
             "latency_ms_single_image": float(np.median(lat)),

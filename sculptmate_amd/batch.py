@@ -63,7 +63,7 @@ class MeshWriter:
 
 
 def run_sharded(model, images, mc_resolution=256, threshold=25.0, enable_texture=False, out_dir=None, names=None, fmt="ply",
-                keep=True, writers=4):
+                keep=True, writers=4, batch=1):
     """images: the WHOLE batch, identical on every rank (a list of host arrays / PIL images, or callables returning one, so
     that a rank only loads the files it owns).  Returns (local, summary):
       local   {index: Mesh} of the images this rank owns (empty dict with keep=False: meshes are only written);
@@ -71,6 +71,8 @@ def run_sharded(model, images, mc_resolution=256, threshold=25.0, enable_texture
     Each image is processed by exactly one rank; meshes are bit-identical to a single-process TSR.run of the same image.
     out_dir: every mesh is also written there (fmt "ply" binary, "npz" raw arrays, "obj" text) by `writers` threads off the
     submit loop (0: synchronously, inside the loop).
+    batch > 1: this rank's images go through the transformer `batch` per pass (TSR.run_batched: the reference's batched forward,
+    3.9 instead of 5.3 ms per image at 4); the meshes then differ from single-image calls by the bf16 transformer's rounding.
     A rank that fails still takes part in the one exchange, with an error marker in place of its counts: every rank then
     raises, none is left waiting in a collective the failed rank never enters."""
     import torch.distributed as dist
@@ -109,10 +111,26 @@ def run_sharded(model, images, mc_resolution=256, threshold=25.0, enable_texture
         # current one (TSR.tokens_async), and mesh i - 1 is collected while image i runs
         lookahead = hasattr(model, "tokens_async") and len(mine) > 1
         prev, im_next, tok_next = None, None, None
-        if lookahead:
+        if batch > 1 and hasattr(model, "run_batched") and len(mine) > 1:
+            # batched passes: queue a pass, collect the previous pass's meshes while it runs
+            prev_group = None
+            for k in range(0, len(mine), batch):
+                idx = mine[k:k + batch]
+                cur_group = (idx, model.run_batched([load(i) for i in idx], batch, mc_resolution, threshold, enable_texture))
+                if prev_group is not None:
+                    for i, pnd in zip(*prev_group):
+                        finish(i, pnd)
+                prev_group = cur_group
+            if prev_group is not None:
+                for i, pnd in zip(*prev_group):
+                    finish(i, pnd)
+            mine_loop = []
+        else:
+            mine_loop = mine
+        if lookahead and mine_loop:
             im_next = load(mine[0])
             tok_next = model.tokens_async(im_next)
-        for k, i in enumerate(mine):
+        for k, i in enumerate(mine_loop):
             if lookahead:
                 im, tok = im_next, tok_next
                 if k + 1 < len(mine):
@@ -200,6 +218,8 @@ def main(argv=None):
     ap.add_argument("--format", choices=("ply", "npz", "obj"), default="ply",
                     help="binary PLY (default), raw .npz arrays, or OBJ text (~200x slower to write than PLY)")
     ap.add_argument("--writers", type=int, default=4, help="mesh-writer threads beside the submit loop (0: write inside the loop)")
+    ap.add_argument("--batch", type=int, default=1, help="images per transformer pass on each rank (1: image by image, meshes "
+                                                         "bit-identical to single-image calls; 4: ~15 %% more meshes per second)")
     ap.add_argument("--texture", action="store_true", help="vertex colours (TSR.extract_mesh's enable_texture)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL)")
     args = ap.parse_args(argv)
@@ -245,7 +265,7 @@ def main(argv=None):
             synth.calibrate_tsr_density_bias(model, sd_syn, torch.from_numpy(images[0]()).to(device), threshold=args.threshold)
         try:
             _, summary = run_sharded(model, images, args.resolution, args.threshold, args.texture, args.out, names, args.format,
-                                     keep=False, writers=args.writers)
+                                     keep=False, writers=args.writers, batch=args.batch)
         except BaseException:
             # no collective on the failure path (run_sharded has already told the other ranks through its one exchange): print,
             # and leave without the process-group teardown that would wait for them

@@ -530,9 +530,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 // BM = 256 or 192 activation rows per tile (TJ = 4 or 3 sub-tiles of 16 per wave; with 192 the second activation half B1 is one
 // sub-tile and phases 1 / 2 have 8 MFMAs): 3072 rows are 12 tiles of 256 or 16 of 192 -- 512 instead of 384 FF1 tiles, i.e.
 // two FULL rounds of 256 CUs instead of one and a half.
-template <int EPI, int BM>
+// RES (round 4, 192-row tiles only): the residual form -- out_f32 = acc + bias + residual (in place), its bf16 copy and the 64-column
+// slice statistics of the fp32 result, i.e. what the 128-row kernel does for the N = 1024 projections that write the residual
+// stream.  Dispatched where 192 x 256 tiles give every CU a tile: a 4-image batch (M = 12288, N = 1024 -> 256 tiles), where the
+// 128 x 128 tiles (768 of them, 3 per CU) move 1.75x the bytes through L2 -> LDS.
+template <int EPI, int BM, bool RES = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     static_assert(BM == 256 || BM == 192, "activation rows per tile");
+    static_assert(!RES || (BM == 192 && EPI == SCULPT_EPI_NONE), "the residual form: 192-row tiles, no activation");
     constexpr int BW = 256, NW = 8, NWC = 4, TI = 8, TJ = BM / 64, WROWS = BM / 4;  // WROWS: activation rows per wave (64 / 48)
     constexpr int JB1 = TJ - 2, AU = BM / 64;  // sub-tiles in B1; DMA units of the activation tile (one per 8 rows per wave)
     constexpr int NU = 4 + AU;                 // DMA units per K-tile: 8 or 7
@@ -767,6 +772,68 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                 }
             }
         }
+    } else if (RES) {
+        // every residual tile of this lane before the first store (vmcnt counts stores: a load behind a store waits for it too);
+        // the 64 fragment registers of the K loop are free now
+        float4 rs[TI][TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = min(m0 + wc * WROWS + j * 16 + fr, g.M - 1);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) rs[i][j] = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n0 + wr * 128 + i * 16 + fq * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int n = n0 + wr * 128 + i * 16 + fq * 4;
+            const float4 b4 = *reinterpret_cast<const float4 *>(biasp + n), c4 = *reinterpret_cast<const float4 *>(csp + n);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = ln_rstd[j] * (acc[i][j][r] - ln_mean[j] * f4(c4, r)) + f4(b4, r) + f4(rs[i][j], r);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int m = m0 + wc * WROWS + j * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int n = n0 + wr * 128 + i * 16 + fq * 4;
+                const f32x4 o = acc[i][j];
+                *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
+                if (g.out_bf16) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
+                }
+            }
+        }
+        // (mean, M2) of the two 64-column slices this wave owns (sub-tiles 0-3 and 4-7): two passes over registers, the four lanes
+        // that share a row (fq) combine by shuffles -- gemm_bf16_kernel's WCOLS == LN_SLOT case
+        if (g.stats_out) {
+            float2 *so = reinterpret_cast<float2 *>(g.stats_out);
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int i = 4 * sl; i < 4 * sl + 4; ++i) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                    sm += __shfl_xor(sm, 16, 64);
+                    sm += __shfl_xor(sm, 32, 64);
+                    const float mean = sm * (1.0f / LN_SLOT);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int i = 4 * sl; i < 4 * sl + 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean; m2 = fmaf(d, d, m2); }
+                    m2 += __shfl_xor(m2, 16, 64);
+                    m2 += __shfl_xor(m2, 32, 64);
+                    const int m = m0 + wc * WROWS + j * 16 + fr;
+                    if (fq == 0 && m < g.M) so[(long)((n0 + wr * 128 + sl * 64) / LN_SLOT) * g.stats_ld + m] = make_float2(mean, m2);
+                }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -954,6 +1021,23 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
         const char *e192 = getenv("SCULPT_GEMM_192");
         const int f192 = e192 ? atoi(e192) : -1;
         const bool pays192 = M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus());
+        // the residual form on 192 x 256 tiles (round 4): every CU gets a tile where the 128-row tiles need three -- the N = 1024
+        // projections of a batched pass (to_out of both attentions, FF2): M = 12288 -> 4 x 64 = 256 tiles
+        {
+            const char *eres = getenv("SCULPT_GEMM_RES256");   // 0 / 1: never / whenever legal (A/B, tests); read per call
+            const int fres = eres ? atoi(eres) : -1;
+            const bool legal = p256 && residual && out_f32 && epilogue == SCULPT_EPI_NONE && n_store == N && n_split == N && !out_bf16_t &&
+                               N % 256 == 0 && K >= 2 * BK && (long)N * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L;
+            const long t192 = (long)(N / 256) * cdiv(M, 192);
+            const bool pays_res = M % 192 == 0 && t192 * 4 >= 3L * num_cus() && t192 * 2 <= 5L * num_cus();
+            if (legal && (fres >= 0 ? fres != 0 : pays_res)) {
+                const dim3 grid(N / 256, cdiv(M, 192));
+                g.gm = group_rows(256, 192, 1, (long)grid.x * grid.y, grid.y);
+                hipLaunchKernelGGL((gemm256_kernel<SCULPT_EPI_NONE, 192, true>), grid, dim3(512), 0, st, g);
+                SC_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         const bool fits = p256 && !residual && !g.stats_out && n_store == N && N % nout == 0 && K >= 2 * BK &&
                           (epilogue == SCULPT_EPI_GEGLU || epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_GELU) &&
                           n_split % 16 == 0 && (long)w_rows * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L &&

@@ -762,6 +762,10 @@ class TSR(KernelEngine):
         with torch.no_grad():
             codes = self.forward([image], self.device) if tokens is None else self.forward_tokens(tokens)
             m = self.extract_meshes(codes, enable_texture, mc_resolution, threshold)[0]
+        return self._mesh_to_host_async(m)
+
+    def _mesh_to_host_async(self, m) -> PendingMesh:
+        """Device mesh -> PendingMesh: vertices / faces / colours copied into pinned host buffers on the copy stream."""
         main = torch.cuda.current_stream(self.device)
         copy = getattr(self, "_copy_stream", None)
         if copy is None:
@@ -787,10 +791,33 @@ class TSR(KernelEngine):
             done.record(copy)
         return PendingMesh(host, done, tuple(leases))
 
-    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False) -> List[Mesh]:
+    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False, batch: int = 1) -> List[Mesh]:
         """Headless entry point: images -> list of Mesh with host (NumPy) arrays.  With several images the device -> host
-        copy of mesh i overlaps the kernels of image i + 1 (run_async)."""
-        return [p.result() for p in self.run_pipelined(_as_image_list(images), mc_resolution, threshold, enable_texture)]
+        copy of mesh i overlaps the kernels of image i + 1 (run_async).
+        batch = 1 (default): image by image with the tokenizer look-ahead -- the meshes are bit-identical to single-image calls.
+        batch > 1: the transformer runs `batch` images per pass like the reference's batched forward (system.py:82-115; 3.9
+        instead of 5.3 ms per image at 4), the meshes are extracted and copied out one by one under the next pass; the scene
+        codes then differ from the single-image pass by bf16 rounding, i.e. so do the meshes."""
+        images = _as_image_list(images)
+        if batch <= 1 or len(images) < 2:
+            return [p.result() for p in self.run_pipelined(images, mc_resolution, threshold, enable_texture)]
+        return [p.result() for p in self.run_batched(images, batch, mc_resolution, threshold, enable_texture)]
+
+    def run_batched(self, images, batch: int = 4, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
+        """images (host or device) -> list of PendingMesh through batched forward passes of `batch` images each."""
+        images = list(images)
+        pending = []
+        keep = self.max_batch
+        try:
+            self.max_batch = max(1, int(batch))
+            for i in range(0, len(images), self.max_batch):
+                with torch.no_grad():
+                    codes = self.forward(images[i:i + self.max_batch], self.device)
+                    for m in self.extract_meshes(codes, enable_texture, mc_resolution, threshold):
+                        pending.append(self._mesh_to_host_async(m))
+        finally:
+            self.max_batch = keep
+        return pending
 
     def run_pipelined(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
         """images (host or device) -> list of PendingMesh, with the tokenizer of image i + 1 queued beside the backbone /

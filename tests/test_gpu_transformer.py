@@ -224,6 +224,38 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_128_row_tiles(cuda, monkeyp
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (bm192, rep)
 
 
+@pytest.mark.parametrize("M,K", [(12288, 1024), (3072, 4096), (960, 128)])
+def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
+    """gemm256_kernel<NONE, 192, RES>: h += A W^T + b in place, bf16(h) and the 64-column slice statistics -- against the 128-row
+    kernel on the same operands: h and bf16(h) bit for bit (same k order), the statistics to fp32 summation order."""
+    from sculptmate_amd import ops
+
+    N = 1024
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(BF).to(cuda)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda)
+    h0 = (torch.randn(M, N, generator=g) + 2.0 * torch.randn(M, 1, generator=g)).to(cuda)
+
+    def run(flag):
+        monkeypatch.setenv("SCULPT_GEMM_RES256", flag)
+        h = h0.clone()
+        hb = torch.empty(M, N, dtype=BF, device=cuda)
+        st = torch.zeros(N // 64, M, 2, device=cuda)
+        for _ in range(2):     # twice: in place, so the second launch reads what the first wrote
+            ops.gemm(A, W, bias=b, residual=h, out_f32=h, out_bf16=hb, stats_out=st)
+        return h, hb, st
+
+    h1, hb1, st1 = run("0")
+    h2, hb2, st2 = run("1")
+    assert torch.equal(h1, h2) and torch.equal(hb1, hb2)
+    assert _rel(st2, st1)[0] < 1e-6
+    ref = h0.double().cpu() + 2 * (A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
+    assert _rel(h2, ref.float())[0] < 1e-5
+    sl = h2.cpu().view(M, N // 64, 64)
+    assert (st2[..., 0].cpu().t() - sl.mean(-1)).abs().max() < 2e-5
+
+
 def test_gemm_gelu_and_geglu_epilogues(cuda):
     from sculptmate_amd import _lib, ops
 
@@ -494,6 +526,11 @@ def test_batch_of_images_equals_one_at_a_time(cuda):
     m.max_batch = 2
     assert torch.equal(m(imgs, device=cuda), codes)
     m.max_batch = 8
+    # TSR.run(images, batch=2): batched transformer passes behind the headless entry point (on this small model the batched
+    # scene codes are bit-identical, so the meshes are too); max_batch is restored afterwards
+    for got, want in zip(m.run(imgs, mc_resolution=32, threshold=thr, batch=2), batch):
+        assert np.array_equal(got.vertices.view(np.uint32), want.vertices.view(np.uint32)) and np.array_equal(got.faces, want.faces)
+    assert m.max_batch == 8
 
 
 def test_full_size_batched_forward_equals_single_image_passes(cuda):

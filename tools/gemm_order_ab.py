@@ -15,8 +15,12 @@ VARIANTS = [("128/band", "0", "0", "0"), ("128/grouped", "0", "0", None), ("256/
             ("192/band", "2", "1", "0"), ("192/grouped", "2", "1", None)]
 
 
+RES_VARIANTS = [("128/band", "0", "0", "0"), ("128/grouped", "0", "0", None), ("192-row residual form", "1", "1", None)]
+
+
 def setenv(v):
     os.environ["SCULPT_GEMM_256"], os.environ["SCULPT_GEMM_192"] = v[1], v[2]
+    os.environ["SCULPT_GEMM_RES256"] = "1" if v[0].startswith("192-row residual") else "0"
     if v[3] is None:
         os.environ.pop("SCULPT_GEMM_GM", None)
     else:
@@ -45,7 +49,7 @@ def case(name, M, K, N, epi, split=0, residual=False, ln=True):
         kw.update(out_bf16=o)
     f = lambda: ops.gemm(A, W, bias=bias, epilogue=epi, **kw)
     res, outs = {}, {}
-    variants = [v for v in VARIANTS if not (residual and v[1] == "2")]   # the 256-row kernels take no residual
+    variants = RES_VARIANTS if residual else VARIANTS
     for rnd in range(3 if "quick" in sys.argv else 5):
         for v in variants:
             setenv(v)
@@ -66,7 +70,7 @@ def case(name, M, K, N, epi, split=0, residual=False, ln=True):
           ("" if residual else " | identical: %s" % same), flush=True)
 
 
-for B in (1, 4):
+for B in (1, 4, 8):
     T = 3072 * B
     case("FF1 + GEGLU  B=%d" % B, T, 1024, 4096, _lib.EPI_GEGLU)
     case("fused Q|K|V^T B=%d" % B, T, 1024, 3072, _lib.EPI_NONE, split=2048)
@@ -74,3 +78,4 @@ for B in (1, 4):
     case("to_out (res)  B=%d" % B, T, 1024, 1024, _lib.EPI_NONE, residual=True, ln=False)
     case("FF2 (res)     B=%d" % B, T, 4096, 1024, _lib.EPI_NONE, residual=True, ln=False)
     case("K/V all layers B=%d" % B, 1025 if B == 1 else 1032 * B, 768, 32768, _lib.EPI_NONE, split=16384, ln=False)
+os.environ.pop("SCULPT_GEMM_RES256", None)
