@@ -39,7 +39,7 @@ res = {
     "algorithmic_bytes_per_launch": int(R ** 3 * 4 + 3 * R * R * 64 * 4),
     "note": "L2-miss traffic: the (iy, iz) table FC (16.8 MB) is streamed by every one of the 8 XCDs, FA/FB bands once, the 128 KiB "
             "W1|W2 blob once per workgroup (33 MB) and the 64 KiB of third limbs through L2; served largely by the 256 MB Infinity Cache",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-optional-modes --no-extras`, tools/profile_bench.sh, round 3",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-optional-modes --no-extras`, tools/profile_bench.sh, round 4",
 }
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res))
