@@ -99,3 +99,15 @@ def test_host_mesh_entry_points_refuse_bad_arguments():
     assert lib.sculpt_mesh_read(out, v2.ctypes.data, f2.ctypes.data) == 0
     lib.sculpt_mesh_free(out)
     assert np.array_equal(v2, v) and np.array_equal(f2, f)
+
+
+def test_graft_entry_build_passes_on_the_built_tree():
+    """The driver's `build()` check: compiles (a no-op on a fresh tree), builds the C oracle and verifies the ABI version the
+    header declares -- a hard-coded version here once outlived an ABI bump."""
+    import importlib
+    import sys
+
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.build()
