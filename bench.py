@@ -210,7 +210,9 @@ def batched_rates(model, imgs, steps):
         dt = time.perf_counter() - t0
         fwd = float(np.median([a.elapsed_time(b) for a, b in ev]))
         res["B%d" % B] = {"ms_per_image": dt / (n * B) * 1e3, "meshes_per_s": n * B / dt, "transformer_ms_per_image": fwd / B,
-                          "forward_ms": fwd, "passes_timed": n}
+                          "forward_ms": fwd, "passes_timed": n,
+                          # 2.96 TFLOP per image over the forward time: the transformer's fraction of the bf16 peak
+                          "transformer_tflops": 2.96 * B / (fwd * 1e-3), "transformer_frac": 2.96 * B / (fwd * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
     torch.cuda.empty_cache()
     return res
 

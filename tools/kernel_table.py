@@ -18,8 +18,9 @@ def flops(name):
 
 
 # the transformer runs once more than the dense grid (bench.py's calibration pass): images for its kernels = FF1 launches / 16
-ff1 = [r for r in rows if "gemm_bf16_kernel<2," in r["Name"]]
-n_tr = int(ff1[0]["Calls"]) // 16 if ff1 else n_img
+# (FF1 + GEGLU = EPI 2: on the 128-row tiles until round 3, on the 192 x 256 tiles of gemm256_kernel since round 4)
+ff1 = [r for r in rows if "gemm_bf16_kernel<2," in r["Name"] or "gemm256_kernel<2," in r["Name"]]
+n_tr = sum(int(r["Calls"]) for r in ff1) // 16 if ff1 else n_img
 
 
 def images(name):
