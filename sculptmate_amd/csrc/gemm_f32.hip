@@ -107,6 +107,40 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ x
     for (int c = cols + lane; c < pad_cols; c += 64) p[c] = 0.f;
 }
 
+// The same with the row held in registers (cols <= 64 * NPL): one read and one write of the score matrix instead of three reads
+// and two writes -- the exact-fp32 mode's attention is bound by exactly that traffic (600 MB of scores per backbone self-attention).
+template <int NPL>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float *__restrict__ x, int ld, int rows, int cols, int pad_cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float *p = x + (long)row * ld;
+    float v[NPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < cols ? p[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        v[i] = expf(v[i] - mx);   // exp(-inf) = 0 for the columns past `cols`
+        s += v[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < pad_cols) p[c] = c < cols ? v[i] * inv : 0.f;
+    }
+}
+
 }  // namespace sculpt
 
 using namespace sculpt;
@@ -163,7 +197,9 @@ int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const floa
 
 int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, sculpt_stream_t stream) {
     SC_REQUIRE(x && rows >= 1 && cols >= 1 && pad_cols >= cols && pad_cols <= ld, "softmax_rows: bad argument");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, ld, rows, cols, pad_cols);
+    if (pad_cols <= 64 * 17) hipLaunchKernelGGL(softmax_rows_reg_kernel<17>, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, ld, rows, cols, pad_cols);
+    else if (pad_cols <= 64 * 48) hipLaunchKernelGGL(softmax_rows_reg_kernel<48>, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, ld, rows, cols, pad_cols);
+    else hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, ld, rows, cols, pad_cols);
     SC_LAUNCH_CHECK();
     return 0;
 }

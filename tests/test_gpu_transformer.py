@@ -956,6 +956,33 @@ def test_fused_three_limb_attention_vs_fp64(cuda, Tq, Tk, heads):
     assert _rel(O2, ref.float())[0] < 1e-6 and _rel(O, O2)[0] < 1e-6
 
 
+def test_three_limb_kernels_repeated_launches_are_bit_identical(cuda):
+    """Race screen for the single-buffer LDS pipelines of gemm_l3.hip / attention_l3.hip (limbs written between two barriers while
+    the previous K-step's fragments were just read): a dozen launches each of the pipelined GEMM, the 64-row GEMM and both attention
+    forms on full-size shapes must reproduce the first launch bit for bit, with other kernels running in between."""
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(3072, 1024, generator=g).to(cuda); W = (torch.randn(1024, 1024, generator=g) / 32).to(cuda)
+    Wb = (torch.randn(3072, 1024, generator=g) / 32).to(cuda)
+    Q = torch.randn(3072, 1024, generator=g).to(cuda); K = torch.randn(1025, 1024, generator=g).to(cuda)
+    Vt = torch.zeros(1024, 1088, device=cuda); Vt[:, :1025] = torch.randn(1024, 1025, generator=g).to(cuda)
+    noise = torch.randn(4096, 4096, device=cuda)
+
+    def variants():
+        o1 = torch.empty(3072, 1024, device=cuda); ops.gemm_f32(A, W, out=o1, l3=True)          # 64-row tiles (192 tiles of 128)
+        o2 = torch.empty(3072, 3072, device=cuda); ops.gemm_f32(A, Wb, out=o2, l3=True)
+        o3 = torch.empty(3072, 1024, device=cuda); ops.attention_f32(Q, K, Vt, o3, 3072, 1025, 16, 0.125, None, l3=True)
+        o4 = torch.empty(1025, 1024, device=cuda); ops.attention_f32(K, K, Vt, o4, 1025, 1025, 16, 0.125, None, l3=True)   # plain 4-wave form
+        return o1, o2, o3, o4
+
+    first = variants()
+    for it in range(12):
+        noise.mul_(1.0001)           # something else on the GPU between the launches
+        for a, b in zip(first, variants()):
+            assert torch.equal(a, b), it
+
+
 def test_bf16l3_parity_mode_small_and_mesh(cuda):
     """TSR(precision='bf16l3'): fp32 storage, every matrix product on the bf16 matrix pipe through the exact three-limb split --
     the same bounds as the exact-fp32 mode: scene code within fp32 rounding of the oracle, mesh within the north-star 1e-4."""
