@@ -89,6 +89,15 @@ struct GemmArgs {
     // resident at any time form a gm x R/gm block of the tile grid and stream gm row tiles + R/gm weight tiles through its L2
     // per round, not one row tile + every weight tile (FF1 of a 4-image batch: 6 MB instead of 17 MB per XCD and round).
     int gm;
+    // rows m < m_store are written (= M in every product launch).  SCULPT_GEMM_DBG_NOSTORE=1 sets 0: the same loads, K loop and
+    // epilogue arithmetic with no output stores at all -- what the stores of an epilogue cost (timing only, tools/gemm_store_cost.py)
+    int m_store;
+    // gemm256_kernel: 1 = the epilogue stages its bf16 tile in the (now free) LDS ring and writes it out in whole rows -- 16 bytes
+    // per lane, 256 / 512 contiguous bytes per tile row -- instead of 8 bytes per lane in 32-byte row segments straight from the
+    // MFMA accumulator layout (four partial writes per 128-byte line: the stores were 22-32 % of these launches,
+    // tools/gemm_store_cost.py); the transposed (V^T) part of a column-split launch is staged transposed and written the same way
+    // instead of as 2-byte scalars.  Set by the launcher when every tile is entirely token-major or entirely transposed.
+    int stage;
 };
 
 // (n tile, m tile) of workgroup-linear index `lin` in a grid of gx weight tiles x gy activation-row tiles
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
-        if (m >= g.M) continue;
+        if (m >= g.m_store) continue;
         if (EPI == SCULPT_EPI_GEGLU) {
 #pragma unroll
             for (int ip = 0; ip < TI / 2; ++ip) {
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
-                if (fq == 0 && m < g.M) so[(long)((n0 + wr * WCOLS) / LN_SLOT) * g.stats_ld + m] = make_float2(pm[j], pq[j]);
+                if (fq == 0 && m < g.m_store) so[(long)((n0 + wr * WCOLS) / LN_SLOT) * g.stats_ld + m] = make_float2(pm[j], pq[j]);
             }
         } else {
             static_assert(WCOLS == LN_SLOT || 2 * WCOLS == LN_SLOT, "statistics slice = one or two waves' columns");
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
                     const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
                     const float2 o = xch[wc * (16 * TJ) + j * 16 + fr];
                     const float d = pm[j] - o.x;
-                    if (m < g.M) so[(long)(n0 / LN_SLOT) * g.stats_ld + m] = make_float2(0.5f * (pm[j] + o.x), pq[j] + o.y + (0.5f * WCOLS) * d * d);
+                    if (m < g.m_store) so[(long)(n0 / LN_SLOT) * g.stats_ld + m] = make_float2(0.5f * (pm[j] + o.x), pq[j] + o.y + (0.5f * WCOLS) * d * d);
                 }
             }
         }
@@ -742,6 +751,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #undef G256_FENCE
 
     // ---- epilogue (as in gemm_bf16_kernel): acc[i][j][r] = out[m = m0 + wc*64 + j*16 + fr][tile row = wr*128 + i*16 + fq*4 + r]
+    // staged stores (GemmArgs::stage): the K loop's last LDS reads are behind its mid-tile barrier, so the ring is free here
+    constexpr int RSB = NOUT * 2 + 16;   // staged row: NOUT bf16 + 16 bytes (rows 4 banks apart: 2-way at worst on the 8-byte writes)
+    constexpr int TSB = BM * 2 + 16;     // transposed staging: a row = the BM activation rows of one weight row
+    static_assert(BM * RSB <= XCH + 2 * BM * 8 && 256 * TSB <= XCH + 2 * BM * 8, "the staged tile fits the LDS of the ring");
+    const bool staged = !RES && g.stage != 0;
+    const bool tileT = staged && EPI != SCULPT_EPI_GEGLU && g.out_t && n0 >= g.n_split;   // workgroup-uniform
     const float *biasp = g.bias ? g.bias : g.zeros;
     const float *csp = g.ln_stats ? g.ln_colsum : g.zeros;
     auto f4 = [](const float4 &v, int r) -> float { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
@@ -761,7 +776,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                     const float gt = ln_rstd[j] * (acc[2 * ip + 1][j][r] - ln_mean[j] * f4(cg, r)) + f4(bg, r);
                     o[r] = v * gelu_erf(gt);
                 }
-                if (m < g.M) {
+                if (staged) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + ((wr * (TI / 2) + ip) * 16 + fq * 4) * 2) = pk;
+                } else if (m < g.m_store) {
                     if (g.out_bf16) {
                         uint2 pk;
                         pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
@@ -795,7 +815,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int m = m0 + wc * WROWS + j * 16 + fr;
-            if (m >= g.M) continue;
+            if (m >= g.m_store) continue;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int n = n0 + wr * 128 + i * 16 + fq * 4;
@@ -831,7 +851,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                     m2 += __shfl_xor(m2, 16, 64);
                     m2 += __shfl_xor(m2, 32, 64);
                     const int m = m0 + wc * WROWS + j * 16 + fr;
-                    if (fq == 0 && m < g.M) so[(long)((n0 + wr * 128 + sl * 64) / LN_SLOT) * g.stats_ld + m] = make_float2(mean, m2);
+                    if (fq == 0 && m < g.m_store) so[(long)((n0 + wr * 128 + sl * 64) / LN_SLOT) * g.stats_ld + m] = make_float2(mean, m2);
                 }
         }
     } else {
@@ -850,7 +870,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                     if (EPI == SCULPT_EPI_GELU) v = gelu_erf(v);
                     o[r] = v;
                 }
-                if (m >= g.M) continue;
+                if (staged) {
+                    if (tileT) {   // [tile row n][activation row m], 2 bytes each
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            *reinterpret_cast<uint16_t *>(smem + (wr * 128 + i * 16 + fq * 4 + r) * TSB + (wc * WROWS + j * 16 + fr) * 2) = f32_to_bf16(o[r]);
+                    } else {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + (wr * 128 + i * 16 + fq * 4) * 2) = pk;
+                    }
+                    continue;
+                }
+                if (m >= g.m_store) continue;
                 if (!tpart) {
                     if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
                     if (g.out_bf16) {
@@ -865,6 +898,30 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g.out_t[(long)(nt0 + r) * g.ldt + m] = f32_to_bf16(o[r]);
                 }
+            }
+        }
+    }
+    if (!RES && staged) {
+        // the staged tile -> HBM in whole rows: 16 bytes per lane, a row's 256 / 512 (transposed: 384 / 512) bytes contiguous
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tileT) {
+            constexpr int CPR = BM / 8;   // 16-byte pieces per tile row (24 / 32); tile rows = 256 weight rows
+            uint16_t *ob = g.out_t + (long)(n0 - g.n_split) * g.ldt + m0;
+#pragma unroll
+            for (int c0 = 0; c0 < 256 * CPR; c0 += 512) {
+                const int c = c0 + tid, nl = c / CPR, mc = c - nl * CPR;
+                if (c < 256 * CPR && m0 + mc * 8 < g.m_store)   // (M is a multiple of 8 on this path: a piece is whole or absent)
+                    *reinterpret_cast<uint4 *>(ob + (long)nl * g.ldt + mc * 8) = *reinterpret_cast<const uint4 *>(smem + nl * TSB + mc * 16);
+            }
+        } else {
+            constexpr int CPR = NOUT / 8;   // 16-byte pieces per tile row (16 / 32)
+            uint16_t *ob = g.out_bf16 + (long)m0 * g.ldo + n0;
+#pragma unroll
+            for (int c0 = 0; c0 < BM * CPR; c0 += 512) {
+                const int c = c0 + tid, row = c / CPR, cc = c - row * CPR;
+                if (c < BM * CPR && m0 + row < g.m_store)
+                    *reinterpret_cast<uint4 *>(ob + (long)row * g.ldo + cc * 8) = *reinterpret_cast<const uint4 *>(smem + row * RSB + cc * 16);
             }
         }
     }
@@ -923,6 +980,7 @@ extern "C" int sculpt_conv3x3_bf16(const uint16_t *in, int ld_in, int n_images, 
     GemmArgs g{in, ld_in, Wt, K, bias, nullptr, 0, out_f32, out_bf16, ldo, nullptr, 0, (int)M, N, K, N, (long)N > M ? 1 : 0,
                n_store, H, W, C_pad / 64, dilation, zp, nullptr, 0, nullptr, 0.f, nullptr, 0, reinterpret_cast<const float *>(zp)};
     SC_REQUIRE((long)N <= ZERO_FLOATS, "conv3x3_bf16: N=%d too large", N);
+    g.m_store = (int)M;
     const int mt = cdiv(M, BM_DEFAULT);
     hipStream_t st = as_stream(stream);
     const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
@@ -968,6 +1026,10 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
                w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
     SC_REQUIRE(w_rows <= ZERO_FLOATS, "gemm_bf16: N=%d too large", N);
+    {
+        const char *ens = getenv("SCULPT_GEMM_DBG_NOSTORE");   // timing experiments only (read per call)
+        g.m_store = (ens && atoi(ens) != 0) ? 0 : M;
+    }
     g.zeros = reinterpret_cast<const float *>(zero_page());
     SC_REQUIRE(g.zeros, "gemm_bf16: could not allocate the zero page");
     SC_REQUIRE((!bias || ((uintptr_t)bias & 15) == 0) && (!ln || !ln->colsum || ((uintptr_t)ln->colsum & 15) == 0),
@@ -1046,6 +1108,14 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             const bool bm192 = f192 >= 0 ? f192 != 0 : pays192;
             const dim3 grid(N / nout, bm192 ? cdiv(M, 192) : cdiv(M, 256));
             g.gm = group_rows(256, bm192 ? 192 : 256, 1, (long)grid.x * grid.y, grid.y);
+            {
+                // staged stores: bf16 outputs only, every tile entirely token-major or entirely transposed, 16-byte aligned rows
+                const char *est = getenv("SCULPT_GEMM_STAGE");   // 0: direct stores from the accumulator layout (A/B); read per call
+                const bool split = out_bf16_t && n_split < N;
+                g.stage = !(est && atoi(est) == 0) && !out_f32 && (out_bf16 || split) && (!out_bf16_t || split) &&
+                          (!split || (n_split % nout == 0 && M % 8 == 0 && ldt % 8 == 0 && ((uintptr_t)out_bf16_t & 15) == 0)) &&
+                          (!out_bf16 || (ldo % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0));
+            }
 #define SCULPT_G256(E)                                                                                     \
     do {                                                                                                   \
         if (bm192) hipLaunchKernelGGL((gemm256_kernel<E, 192>), grid, dim3(512), 0, st, g);                \

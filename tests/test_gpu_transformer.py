@@ -256,6 +256,44 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
     assert (st2[..., 0].cpu().t() - sl.mean(-1)).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N,epi,split,bm192", [(3072, 1024, 4096, 2, 0, 1), (3072, 1024, 3072, 0, 2048, 1), (12288, 1024, 1024, 0, 0, 1),
+                                                     (3000, 256, 512, 0, 0, 1), (3000, 256, 512, 1, 0, 0), (2048, 128, 1024, 0, 512, 0),
+                                                     (1032, 768, 2304, 0, 1536, 0), (520, 128, 256, 2, 0, 1)])
+def test_gemm256_staged_stores_equal_direct_stores(cuda, monkeypatch, M, K, N, epi, split, bm192):
+    """gemm256_kernel's epilogue through LDS (whole rows, 16 bytes per lane; the V^T part staged transposed) against its direct
+    stores from the accumulator layout: the same bits, ragged last row tiles, a column-sliced output buffer, several launches
+    (the staging reuses the K loop's LDS ring), and nothing written outside the outputs."""
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M + K + N + epi)
+    rows = 2 * N if epi == 2 else N
+    A = torch.randn(M, K, generator=g).to(BF).to(cuda)
+    W = (torch.randn(rows, K, generator=g) / math.sqrt(K)).to(BF).to(cuda)
+    b = torch.randn(rows, generator=g).to(cuda)
+    stats = torch.zeros(K // 64, M, 2, device=cuda); stats[..., 1] = 64.0 + torch.rand(K // 64, M, device=cuda)
+    cs = W.float().sum(1).contiguous()
+    Mp = ((M + 63) // 64) * 64
+    monkeypatch.setenv("SCULPT_GEMM_256", "2")
+    monkeypatch.setenv("SCULPT_GEMM_192", str(bm192))
+
+    def run(stage):
+        monkeypatch.setenv("SCULPT_GEMM_STAGE", stage)
+        ncol = split if split else N
+        buf = torch.full((M + 3, ncol + 8), 7.0, dtype=BF, device=cuda)     # the output is a column slice of a wider buffer
+        o = buf[:M, :ncol]
+        ot = torch.full((N - split, Mp), 5.0, dtype=BF, device=cuda) if split else None
+        for _ in range(3):
+            ops.gemm(A, W, bias=b, out_bf16=o, out_t=ot, n_split=split, epilogue=epi, ln_stats=stats, ln_colsum=cs, ln_eps=1e-5)
+        return buf.clone(), None if ot is None else ot.clone()
+
+    d, dt = run("0")
+    s_, st = run("1")
+    assert torch.equal(d, s_)
+    assert (s_[M:] == 7.0).all() and (s_[:, (split if split else N):] == 7.0).all()
+    if split:
+        assert torch.equal(dt, st) and (st[:, M:] == 5.0).all()
+
+
 def test_gemm_gelu_and_geglu_epilogues(cuda):
     from sculptmate_amd import _lib, ops
 
