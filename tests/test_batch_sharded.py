@@ -264,3 +264,46 @@ def test_batch_cli_writer_keeps_up_with_the_gpu(tmp_path):
         import shutil
 
         shutil.rmtree(out, ignore_errors=True)
+
+
+def test_run_sharded_batched_passes_with_a_stand_in_model(tmp_path):
+    """run_sharded(batch=3): this rank's images go through model.run_batched in groups, the previous group is collected while the
+    next is queued, every image is written exactly once and the summary is complete (single process, stand-in model)."""
+    from sculptmate_amd import batch, meshio
+    from sculptmate_amd.tsr.system import Mesh
+
+    calls = []
+
+    class Pending:
+        def __init__(self, m):
+            self.m = m
+
+        def result(self):
+            calls.append(("result", int(self.m.vertices[0, 0])))
+            return self.m
+
+    class Model:
+        device = "cpu"
+
+        def run_batched(self, images, batch_, res, thr, tex):
+            calls.append(("pass", [int(im[0, 0, 0]) for im in images]))
+            out = []
+            for im in images:
+                k = int(im[0, 0, 0])
+                out.append(Pending(Mesh(np.full((3 + k, 3), k, np.float32), np.zeros((k + 1, 3), np.int64), None)))
+            return out
+
+        def run_async(self, *a, **k):
+            raise AssertionError("batched mode must not fall back to run_async")
+
+    images = [np.full((2, 2, 3), i, np.float32) for i in range(8)]
+    local, summary = batch.run_sharded(Model(), images, 32, 1.0, out_dir=str(tmp_path), fmt="npz", batch=3)
+    assert sorted(local) == list(range(8))
+    assert summary == [(i, 0, 3 + i, i + 1) for i in range(8)]
+    passes = [c[1] for c in calls if c[0] == "pass"]
+    assert passes == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    # the first group's meshes are collected only after the second pass was queued
+    assert calls.index(("pass", [3, 4, 5])) < calls.index(("result", 0))
+    assert sorted(os.listdir(tmp_path)) == ["mesh_%05d.npz" % i for i in range(8)]
+    z = np.load(tmp_path / "mesh_00005.npz")
+    assert z["vertices"].shape == (8, 3) and z["faces"].shape == (6, 3)
