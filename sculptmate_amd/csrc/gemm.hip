@@ -1112,9 +1112,10 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                 // staged stores: bf16 outputs only, every tile entirely token-major or entirely transposed, 16-byte aligned rows
                 const char *est = getenv("SCULPT_GEMM_STAGE");   // 0: direct stores from the accumulator layout (A/B); read per call
                 const bool split = out_bf16_t && n_split < N;
-                g.stage = !(est && atoi(est) == 0) && !out_f32 && (out_bf16 || split) && (!out_bf16_t || split) &&
+                // (out_bf16 must exist: the token-major tiles of a split launch are written through it unconditionally)
+                g.stage = !(est && atoi(est) == 0) && !out_f32 && out_bf16 && (!out_bf16_t || split) &&
                           (!split || (n_split % nout == 0 && M % 8 == 0 && ldt % 8 == 0 && ((uintptr_t)out_bf16_t & 15) == 0)) &&
-                          (!out_bf16 || (ldo % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0));
+                          ldo % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0;
             }
 #define SCULPT_G256(E)                                                                                     \
     do {                                                                                                   \
