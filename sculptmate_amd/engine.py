@@ -6,6 +6,8 @@ bf16l3: fp32 storage and fp32 norms / softmax like "fp32", but every matrix prod
         through the exact three-limb split of both operands, fp32 accumulate (csrc/gemm_l3.hip): fp32-equivalent, ~6x faster.
 A subclass provides self.precision ("bf16" | "fp32" | "bf16l3"), self.device and self._buf = {}.
 """
+import os
+
 import torch
 
 from . import ops
@@ -67,7 +69,6 @@ class KernelEngine:
         if self.precision == "bf16":
             return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
         # bf16l3: one fused launch, no score matrix; SCULPT_L3_ATTN_FUSED=0 keeps the three-launch composition (A/B)
-        import os
         fused = self.l3 and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0"
         scores = None if fused else self._b("attn_scores", (heads, Tq, ((Tk + 31) // 32) * 32), torch.float32)
         if batch == 1:
