@@ -38,6 +38,12 @@ FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling (A
 # (layer 0 is hoisted into the separable plane tables, the last layer is a VALU dot: neither is on the matrix pipe)
 EXECUTED_FLOP_PER_POINT = {"bf16l3": 8 * 48 * 32768 / 32, "fp32": 8 * 64 * 4096 / 32, "bf16x3": 8 * 24 * 32768 / 32,
                            "fp16x3": 8 * 24 * 32768 / 32}
+# the two-pass ("filtered") grid, TSR's default since round 5 (csrc/density_filter.hip): pass A = one 16-bit product per hidden layer at
+# EVERY point (8 MFMAs per layer and 32 points), pass C = the six-product arithmetic at the re-evaluated points only
+COARSE_FLOP_PER_POINT = 8 * 8 * 32768 / 32
+FILTER_KERNEL_NAME = ("density_coarse_kernel<f16> (every lattice point: fused triplane-sum + NeRF-MLP, one fp16 product per hidden layer "
+                      "on v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 SiLU) + filter_cells / filter_points (bit arithmetic) + "
+                      "density_list_l3k_kernel (six exact bf16-limb products at the corners of every possibly active cell)")
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak
 KERNEL_NAME = {"bf16l3": "density_grid_l3k_kernel (fused triplane-sum + NeRF-MLP; hidden layers as six exact bf16-limb products on "
@@ -147,6 +153,90 @@ def boundary_rate(model, imgs_host, steps):
             "h2d_bytes_per_image": int(imgs_host[0].nbytes), "d2h_bytes_per_mesh": int(nbytes)}
 
 
+def filtered_active(model):
+    """True when extract_meshes evaluates the grid in two passes (TSR.decoder_filter, calibrated and usable)."""
+    return bool(model.decoder_filter and model.decoder_precision == "bf16l3" and model.filter_info["usable"]
+                and model.filter_info["margin"] is not None)
+
+
+def filter_identity_check(model, img_dev, rounds=5):
+    """OUTSIDE the timed region, before it: the two-pass grid of the bench image against the full three-limb evaluation -- lattice
+    points whose side of the level differs (must be 0), marching-cubes output equal bit for bit (vertices, faces, order), the
+    fraction of points re-evaluated, and the three passes timed one by one (HIP events, median).  `value` uses the filter only
+    when this check passes; otherwise the model is switched to the full evaluation and the line says so."""
+    from sculptmate_amd import ops
+
+    _, outb = model.encode_image(img_dev)
+    planes = model.scene_code(outb)
+    cfg = model.renderer.cfg
+    kw = dict(radius=cfg.radius, density_bias=cfg.density_bias, out_add=-THRESHOLD)
+    info = model.calibrate_decoder_filter(planes)
+    res = {"usable": bool(info["usable"]), "coarse_operands": info["coarse"], "margin_log_density": info["margin"],
+           "probe_max_err_log_density": info.get("probe_max_err"),
+           "margin_rule": "%g x the largest |log d~ - log d| on a %d^3 probe of the scene code; a call whose re-evaluated points show "
+                          "more than %.2f x margin is redone in full" % (model.FILTER_SAFETY, model.FILTER_PROBE, model.FILTER_GUARD)}
+    if not info["usable"]:
+        return res
+    R = MC_RES
+    full = ops.density_grid(planes, model.decoder, R, precision="bf16l3", **kw).clone()
+    vol, st = ops.density_grid_filtered(planes, model.decoder, R, info["margin"], coarse=info["coarse"], **kw)
+    stt = ops.filter_stats(st)
+    mism = int(((vol > 0) != (full > 0)).sum())
+    mca = ops.marching_cubes(full.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0, vert_mul=2 * cfg.radius, vert_add=-cfg.radius)
+    mcb = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0, vert_mul=2 * cfg.radius, vert_add=-cfg.radius)
+    same = (mca[0].shape == mcb[0].shape and mca[1].shape == mcb[1].shape
+            and bool(torch.equal(mca[0].view(torch.int32), mcb[0].view(torch.int32))) and bool(torch.equal(mca[1], mcb[1])))
+    times = {"A": [], "B": [], "C": [], "ABC": [], "full": []}
+    for rnd in range(rounds + 1):
+        evs = {}
+        for k, p in enumerate(("A", "B", "C")):
+            evs[p] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ops.density_grid_filtered(planes, model.decoder, R, info["margin"], coarse=info["coarse"], out=vol, passes=p,
+                                      tables=(k == 0), events=evs[p], **kw)
+        evs["ABC"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ops.density_grid_filtered(planes, model.decoder, R, info["margin"], coarse=info["coarse"], out=vol, events=evs["ABC"], **kw)
+        evs["full"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ops.density_grid(planes, model.decoder, R, precision="bf16l3", out=full, events=evs["full"], **kw)
+        torch.cuda.synchronize()
+        if rnd:
+            for k, (a, b) in evs.items():
+                times[k].append(a.elapsed_time(b))
+    med = {k: float(np.median(v)) for k, v in times.items()}
+    res.update({"pass_a_ms": med["A"], "pass_b_ms": med["B"], "pass_c_ms": med["C"], "all_passes_ms": med["ABC"],
+                "full_evaluation_ms": med["full"],
+                "refined_fraction": stt["n_refined"] / stt["n_points"], "marked_fraction": stt["n_marked"] / stt["n_points"],
+                "possibly_active_cells": stt["n_cells"], "nonfinite_coarse_values": stt["n_nonfinite"],
+                "guard_max_err_log_density": stt["max_err"], "guard_over_margin": stt["max_err"] / info["margin"],
+                "sign_mismatches_vs_full": mism, "mesh_identical": bool(same),
+                "mesh": {"vertices": int(mcb[0].shape[0]), "faces": int(mcb[1].shape[0])},
+                "checked_on": "256^3 volume of bench image 0, before the timed region"})
+    del full, vol
+    return res
+
+
+def full_density_sibling(model, imgs, steps):
+    """The same step with TSR(decoder_filter=False): every lattice point through the six-product kernel (round 4's headline path)."""
+    keep = model.decoder_filter
+    try:
+        model.decoder_filter = False
+        one_step(model, imgs[0])
+        torch.cuda.synchronize()
+        n = max(3, min(steps, 10))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        t0 = time.perf_counter()
+        for i in range(n):
+            one_step(model, imgs[i % len(imgs)], events=ev[i])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    finally:
+        model.decoder_filter = keep
+    ex = EXECUTED_FLOP_PER_POINT["bf16l3"] * MC_RES ** 3
+    return {"kernel": KERNEL_NAME["bf16l3"], "launch_ms": ms, "bound": "mfma", "executed_flop_per_launch": ex,
+            "achieved": ex / (ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ex / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "meshes_per_s": n / dt, "ms_per_step": dt / n * 1e3}
+
+
 def stage_split(model, img_dev, n=5):
     """ms per stage (HIP events on torch's stream, median of n untimed extra steps): SURVEY 8d's stage split."""
     from sculptmate_amd import ops
@@ -162,8 +252,13 @@ def stage_split(model, img_dev, n=5):
         e[2].record()
         planes = model.scene_code(outb)
         e[3].record()
-        vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
-                               out_add=-THRESHOLD, precision=DECODER_PRECISION)
+        if filtered_active(model):
+            vol, _ = ops.density_grid_filtered(planes, model.decoder, MC_RES, model.filter_info["margin"], radius=r,
+                                               density_bias=model.renderer.cfg.density_bias, out_add=-THRESHOLD,
+                                               coarse=model.filter_info["coarse"])
+        else:
+            vol = ops.density_grid(planes, model.decoder, MC_RES, radius=r, density_bias=model.renderer.cfg.density_bias,
+                                   out_add=-THRESHOLD, precision=DECODER_PRECISION)
         e[4].record()
         ops.marching_cubes(vol.view(MC_RES, MC_RES, MC_RES), 0.0, reference_order=True, vert_div=MC_RES - 1.0,
                            vert_mul=r - (-r), vert_add=-r)
@@ -562,6 +657,8 @@ def main():
     ap.add_argument("--decoder-precision", choices=("bf16l3", "fp32", "fp16x3", "bf16x3"), default="bf16l3",
                     help="bf16l3 (default = TSR's default: fp32-equivalent three-limb bf16 split), fp32 (exact-fp32 MFMA kernel), "
                          "or a two-limb experiment mode")
+    ap.add_argument("--no-decoder-filter", action="store_true",
+                    help="every lattice point through the six-product kernel (TSR(decoder_filter=False), round 4's path) as the headline")
     args = ap.parse_args()
     global DECODER_PRECISION
     DECODER_PRECISION = args.decoder_precision
@@ -597,8 +694,19 @@ def main():
     model.decoder_precision = DECODER_PRECISION
     imgs_np = [synth.composite_rgb(synth.image_rgba(seed=100 + rank * 8 + i)) for i in range(4)]
     imgs = [torch.from_numpy(a).to(device).contiguous() for a in imgs_np]
+    filt = None
     with torch.no_grad():
         calibrate(model, sd, imgs[0])
+        if args.no_decoder_filter:
+            model.decoder_filter = False
+        if model.decoder_filter and DECODER_PRECISION == "bf16l3":
+            # the two-pass grid may carry `value` only if it reproduces the full evaluation on the bench's own field
+            filt = filter_identity_check(model, imgs[0])
+            if not (filt.get("usable") and filt.get("sign_mismatches_vs_full") == 0 and filt.get("mesh_identical")):
+                model.decoder_filter = False
+                filt["used_for_value"] = False
+            else:
+                filt["used_for_value"] = True
         for i in range(args.warmup):
             one_step(model, imgs[i % len(imgs)])
         torch.cuda.synchronize()
@@ -621,7 +729,13 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0:
         mode = DECODER_PRECISION
-        executed = EXECUTED_FLOP_PER_POINT[mode] * MC_RES ** 3
+        use_filter = filtered_active(model)
+        if use_filter:
+            # executed MFMA FLOPs of BOTH passes: one product per layer at every point + six at the re-evaluated ones (of the last step)
+            n_ref = int((model.filter_info["last"] or {}).get("n_refined", 0))
+            executed = COARSE_FLOP_PER_POINT * MC_RES ** 3 + EXECUTED_FLOP_PER_POINT["bf16l3"] * n_ref
+        else:
+            executed = EXECUTED_FLOP_PER_POINT[mode] * MC_RES ** 3
         achieved = executed / (kern_ms * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if mode == "fp32" else PEAK_BF16_MFMA_TFLOPS
         traffic, traffic_src = None, None
@@ -629,7 +743,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("mode", "fp32") == mode:
+                if j.get("mode", "fp32") == (mode + "+filter" if use_filter else mode):
                     traffic, traffic_src = j.get("hbm_bytes_per_launch"), "profiles/pmc_density_grid.json (%s)" % j.get("source", "rocprofv3 --pmc passes")
             except Exception:
                 traffic = None
@@ -644,19 +758,21 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE[mode],
+            "dtype": DTYPE[mode] + (" [two-pass grid: an fp16 one-product pass decides the SIGN away from the surface, every corner of every "
+                                    "active marching-cubes cell carries the three-limb value: mesh bit-identical to the full evaluation, "
+                                    "checked in-bench under density.filtered]" if filtered_active(model) else ""),
             "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
             "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
                        "entry_points_timed": "TSR.forward([image resident in HBM]) + TSR.extract_meshes(codes, resolution=256): mesh "
                                              "left in HBM; the host-boundary rate is the extra key 'boundary'",
                        "mc_resolution": MC_RES, "threshold": THRESHOLD, "images_per_gpu_per_step": 1,
-                       "decoder_precision": mode,
+                       "decoder_precision": mode, "decoder_filter": use_filter,
                        # test plumbing made visible (tests/test_gpu_bench_ranks.py): ranks sharing one device are NOT a multi-GPU figure
                        "shared_gpu": share_gpu, "collective_backend": backend if dist is not None else None,
                        "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
             # achieved / frac: the FLOPs the kernel's MFMA instructions execute (cross-check: SQ_INSTS_VALU_MFMA_MOPS_* x 512 in
             # profiles/round3/pmc_summary.txt) over the live HIP-event launch time, against the dense peak of that pipe
-            "roofline": {"kernel": KERNEL_NAME[mode],
+            "roofline": {"kernel": FILTER_KERNEL_NAME if use_filter else KERNEL_NAME[mode],
                          "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          # the same two numbers under names that say what they count: FLOPs the MFMA instructions
@@ -665,7 +781,9 @@ def main():
                          "meaning": "achieved / frac = executed MFMA FLOPs over the launch time (matrix-pipe utilisation; since "
                                     "round 3); useful fp32-equivalent work = algorithmic_tflops / algorithmic_frac",
                          "mfma_executed_tflops": achieved, "mfma_util": achieved / peak,
-                         "launch_ms": kern_ms, "executed_flop_per_launch": executed,
+                         "launch_ms": kern_ms, "launch_ms_covers": ("all launches of sculpt_density_grid_filtered (pass A + bit passes + "
+                                                                    "pass C), HIP events on their stream" if use_filter else "the one launch"),
+                         "executed_flop_per_launch": executed,
                          "algorithmic_flop_per_launch": FLOP_PER_POINT * MC_RES ** 3,
                          "algorithmic_tflops": FLOP_PER_POINT * MC_RES ** 3 / (kern_ms * 1e-3) / 1e12,
                          # SURVEY 8(d)'s 82.4 kFLOP/point (includes the layer-0 work the separable tables remove) over the SAME
@@ -681,6 +799,11 @@ def main():
             out["transformer_roofline"] = {"bound": "mfma", "achieved": 2.96 / (out["transformer_ms"] * 1e-3), "peak": PEAK_BF16_MFMA_TFLOPS,
                                            "unit": "TFLOP/s", "frac": 2.96 / (out["transformer_ms"] * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
             single = args.gpus == 1 and DECODER_PRECISION == "bf16l3"
+            if filt is not None:
+                out["density"] = {"filtered": filt,
+                                  "guard": {k: model.filter_info[k] for k in ("filtered", "fallbacks", "calibrations")}}
+                if use_filter and single and not args.no_siblings:
+                    out["density"]["full"] = full_density_sibling(model, imgs, args.steps)
             if single and not args.no_siblings:
                 out["fp32_exact"] = fp32_exact_sibling(model, imgs, args.steps)
                 out["parity"] = {"kernel_vs_fp32_kernel": kernel_parity(model, imgs[0])}

@@ -82,6 +82,9 @@ SIGNATURES = {
     "sculpt_grid_decode": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "sculpt_density_grid": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sculpt_density_grid_ex": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _u, _vp]),
+    "sculpt_density_filter_workspace_bytes": (_sz, [_i, _i]),
+    "sculpt_density_grid_filtered": (_i, [_vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _u, _vp]),
+    "sculpt_density_filter_stats": (_i, [_vp, _vp, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
@@ -173,6 +176,9 @@ QUERY_CHANNEL_LAST = 2
 DENSITY_BF16X3 = 1
 DENSITY_FP16X3 = 2
 DENSITY_BF16L3 = 4
+FILTER_COARSE_FP16 = 8
+FILTER_MARK_ALL = 16
+FILTER_PASS_A, FILTER_PASS_B, FILTER_PASS_C = 32, 64, 128
 F32_EXACT, F32_BF16L3 = 0, 1
 
 

@@ -1,0 +1,474 @@
+// Two-pass ("filtered") dense density grid for gfx950 (MI355X): sculpt_density_grid_filtered.
+//
+// Replaces, like csrc/triplane.hip (reference file:line):
+//   dense query over MarchingCubeHelper.grid_vertices     TripoSR/tsr/system.py:171-184
+//   TriplaneNeRFRenderer.query_triplane + NeRFMLP.forward  TripoSR/tsr/models/nerf_renderer.py:41-91, network_utils.py:116-124
+// for the one consumer the dense grid has, MarchingCubeHelper.forward (TripoSR/tsr/models/isosurface.py:41-54): marching cubes
+// reads the MAGNITUDE of the volume only at the corners of active cells (vertex interpolation, Lewiner's face / interior tests)
+// and the SIGN everywhere else.  The fp32-equivalent three-limb evaluation (six bf16 products per hidden layer, triplane.hip) is
+// therefore needed at a few per cent of the lattice points; everywhere else a sign that is certainly right is enough.
+//
+//   pass A  density_coarse_kernel    every lattice point with ONE 16-bit product per hidden layer (fp16 or bf16 operands, fp32
+//                                    accumulate: 8 instead of 48 MFMAs per layer and 32 points, no limb split).  Writes the coarse
+//                                    value exp(d~ + bias) + out_add, and per 32 points along z one word of SIGN bits (value > 0)
+//                                    and one word of MARK bits: |d~ + bias - log(level)| < margin, or not finite.
+//   pass B  filter_*_kernel          bit arithmetic on those 2 x R^3/8 bytes: a cell is POSSIBLY ACTIVE when the coarse signs of
+//                                    its 8 corners differ or a corner is marked; a point is REFINED when it is a corner of a possibly
+//                                    active cell (which includes every marked point), and goes into a packed point list.
+//   pass C  density_list_l3k_kernel  the exact three-limb arithmetic of density_grid_l3k_kernel (the same device function, so the
+//                                    same bits: a point's value depends on its own MFMA column only) on the listed points,
+//                                    scattered over the coarse values.
+//
+// If no coarse error |d~ - d| reaches the margin, every truly active cell is possibly active (a corner whose coarse sign is wrong
+// lies within the margin, hence is marked), so all corners of every active cell and the sign of every lattice point equal the
+// full evaluation's, and the mesh is bit-identical to it.  The margin is calibrated by the caller (8 x the largest coarse error
+// measured with SCULPT_FILTER_MARK_ALL on a probe lattice of the same scene code) and guarded at run time: pass C knows both
+// values at every refined point near the level and records the largest |d~ - d| it sees (FilterHeader::max_err).
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "triplane_mlp.h"
+
+namespace sculpt {
+
+struct FilterHeader {        // first 64 bytes of the filter workspace; zeroed by every call
+    int32_t n_refined;       // points re-evaluated exactly (pass C)
+    uint32_t max_err_bits;   // bits of max |log coarse - log exact| over the refined points within 2 margins of the level
+    int32_t n_marked;        // points within the margin of the level in pass A, non-finite ones included
+    int32_t n_nonfinite;     // non-finite coarse values (all marked, all re-evaluated)
+    int32_t n_cells;         // possibly active cells
+    int32_t n_points;        // nx * R * R
+    int32_t pad[10];
+};
+static_assert(sizeof(FilterHeader) == 64, "header is 16 words");
+
+struct FilterView {
+    FilterHeader *hd;
+    uint32_t *sign, *mark, *cell;        // [nx*R rows][nw words]
+    uint32_t *list;                      // [nx*R*R] packed (ix << 20 | iy << 10 | iz)
+};
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t filter_layout(int R, int nx, void *base, FilterView *v) {
+    const size_t rows = (size_t)nx * R, nw = (R + 31) / 32, words = rows * nw;
+    char *p = reinterpret_cast<char *>(base);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char *q = p ? p + o : nullptr; o += align256(bytes); return q; };
+    char *hd = take(sizeof(FilterHeader));
+    char *sign = take(words * 4), *mark = take(words * 4), *cell = take(words * 4);
+    char *list = take(rows * (size_t)R * 4);
+    if (v) {
+        v->hd = reinterpret_cast<FilterHeader *>(hd);
+        v->sign = reinterpret_cast<uint32_t *>(sign); v->mark = reinterpret_cast<uint32_t *>(mark);
+        v->cell = reinterpret_cast<uint32_t *>(cell);
+        v->list = reinterpret_cast<uint32_t *>(list);
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass A: one 16-bit product per hidden layer
+// ---------------------------------------------------------------------------------------------
+struct CState {
+    float x[8], t[8];
+    unsigned h[4];
+};
+
+template <typename V8> __device__ __forceinline__ unsigned cvt_pk16(float a, float b);
+template <> __device__ __forceinline__ unsigned cvt_pk16<tbf16x8>(float a, float b) { return cvt_pk_bf16(a, b); }
+template <> __device__ __forceinline__ unsigned cvt_pk16<tf16x8>(float a, float b) {
+    const tf32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, tf16x2));  // v_cvt_pk_f16_f32 (RNE; overflow -> inf)
+}
+
+// chunk C (0..6) of the SiLU + conversion of the 8 values in s.x (activations carried scaled by log2 e, silu_f); stage-major
+// so that neighbours are independent
+template <int C, typename V8>
+__device__ __forceinline__ void cchunk(CState &s) {
+    if constexpr (C == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.t[i] = __builtin_amdgcn_exp2f(-s.x[i]);
+    } else if constexpr (C == 1) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) s.t[i] = __builtin_amdgcn_exp2f(-s.x[i]);
+    } else if constexpr (C == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.t[i] = 1.0f + s.t[i];
+    } else if constexpr (C == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.t[i] = __builtin_amdgcn_rcpf(s.t[i]);
+    } else if constexpr (C == 4) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) s.t[i] = __builtin_amdgcn_rcpf(s.t[i]);
+    } else if constexpr (C == 5) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.x[i] = s.x[i] * s.t[i];
+    } else if constexpr (C == 6) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.h[q] = cvt_pk16<V8>(s.x[2 * q], s.x[2 * q + 1]);
+    }
+}
+
+template <typename V8>
+__device__ __forceinline__ V8 cstate_operand(const CState &s) {
+    const u32x4 w = {s.h[0], s.h[1], s.h[2], s.h[3]};
+    return __builtin_bit_cast(V8, w);
+}
+
+// LDS image of pass A: [leading parts of the hidden weights: NH * 2048 floats][bacc][wlast][blast]
+__host__ __device__ __forceinline__ int coarse_lds_floats(int NH) { return NH * 2048 + (NH + 1) * 64 + 256 + 4; }
+
+template <typename V8>
+__global__ __launch_bounds__(1024) void density_coarse_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float level_log, float margin,
+    int mark_all, float *__restrict__ out, uint32_t *__restrict__ signbits, uint32_t *__restrict__ markbits,
+    FilterHeader *__restrict__ hdr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;  // >= 1
+    {
+        // the leading 16-bit part of every hidden weight: the first half of each layer's [part][T][s4][lane][8] image
+        const float *src = blob + (__is_same(V8, tf16x8) ? hd.off_x3h : hd.off_x3);
+        for (int i = threadIdx.x; i < NH * 512; i += blockDim.x) {
+            const int l = i >> 9, r = i & 511;
+            reinterpret_cast<f32x4 *>(smem)[i] = reinterpret_cast<const f32x4 *>(src + (long)l * 4096)[r];
+        }
+        float *bacc = smem + NH * 2048;
+        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
+        float *wl = bacc + (NH + 1) * 64;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
+        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
+        __syncthreads();
+    }
+    LdsView L;
+    L.hid = smem;
+    L.bacc = smem + NH * 2048;
+    L.wlast = L.bacc + (NH + 1) * 64;
+    L.blast = L.wlast + 256;
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int nzb = (R + 31) / 32;
+    const long ntiles = (long)nx * nzb * R;
+    const long nw_total = (long)gridDim.x * nwave;
+    // tile order of density_grid_l3k_kernel: a wave walks iy at fixed (ix, z block); the workgroups of one XCD take one band of ix
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    int iy = (int)(t_begin % R);
+    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
+    const V8 *A = reinterpret_cast<const V8 *>(smem) + lane;  // [l][T][s4][lane]
+    int n_marked = 0, n_nonfinite = 0;
+    bool fresh = true;
+    f32x16 fb0, fb1;  // the FB row of this lane's point: constant while the wave walks iy
+
+    for (long t = t_begin; t < t_end; ++t, ++iy) {
+        if (iy == R) {
+            iy = 0;
+            if (++zb == nzb) { zb = 0; ++ixl; }
+            fresh = true;
+        }
+        const int iz = zb * 32 + p;
+        const int izc = min(iz, R - 1);
+        if (fresh) {
+            load_row32(FB + ((long)ixl * R + izc) * 64 + h * 32, fb0, fb1);
+            fresh = false;
+        }
+        f32x16 x0, x1, y0, y1;
+        load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
+        load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
+        x0 += fb0; x1 += fb1;
+        x0 += y0; x1 += y1;
+        for (int l = 0; l < NH; ++l) {
+            const V8 *Al = A + (long)l * 512;
+            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
+            V8 a0 = Al[0], a1 = Al[256];
+            V8 b;
+            {   // k-step 0's SiLU has no MFMA of this tile to run behind
+                CState s;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s.x[i] = x0[i];
+                cchunk<0, V8>(s); cchunk<1, V8>(s); cchunk<2, V8>(s); cchunk<3, V8>(s); cchunk<4, V8>(s); cchunk<5, V8>(s);
+                cchunk<6, V8>(s);
+                b = cstate_operand<V8>(s);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                CState s;
+                V8 a0n = a0, a1n = a1;
+                if (g < 3) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s.x[i] = (g + 1 < 2 ? x0 : x1)[8 * ((g + 1) & 1) + i];
+                }
+                acc0 = mfma16(a0, b, acc0);
+                if (g < 3) {
+                    cchunk<0, V8>(s); cchunk<1, V8>(s); cchunk<2, V8>(s);
+                    a0n = Al[(g + 1) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc1 = mfma16(a1, b, acc1);
+                if (g < 3) {
+                    cchunk<3, V8>(s); cchunk<4, V8>(s); cchunk<5, V8>(s); cchunk<6, V8>(s);
+                    a1n = Al[256 + (g + 1) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (g < 3) b = cstate_operand<V8>(s);
+                a0 = a0n; a1 = a1n;
+            }
+            x0 = acc0;
+            x1 = acc1;
+        }
+        x0 = silu16_scalar(x0);
+        x1 = silu16_scalar(x1);
+        const float d = last_dot(L, 0, h, x0, x1) + density_bias;
+        const float v = d - level_log;                       // log-domain distance from the level
+        const bool live = iz < R;
+        const bool finite = fabsf(v) < INFINITY;             // false for NaN and +-inf
+        const bool marked = live && (mark_all || !(fabsf(v) >= margin));  // a NaN is marked
+        const float c = exp_f(d) + out_add;
+        const uint32_t sb = (uint32_t)__ballot(live && c > 0.0f), mb = (uint32_t)__ballot(marked);
+        n_marked += __popc(mb);
+        n_nonfinite += __popc((uint32_t)__ballot(live && !finite));
+        const long row = (long)ixl * R + iy;
+        if (lane == 0) {
+            signbits[row * nzb + zb] = sb;
+            markbits[row * nzb + zb] = mb;
+        }
+        if (h == 0 && live) out[row * R + iz] = c;
+    }
+    if (lane == 0) {
+        if (n_marked) atomicAdd(&hdr->n_marked, n_marked);
+        if (n_nonfinite) atomicAdd(&hdr->n_nonfinite, n_nonfinite);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass B: possibly active cells, refined points, packed list (bit arithmetic on the sign / mark words)
+// ---------------------------------------------------------------------------------------------
+// cell (x, y, z) has corners (x..x+1, y..y+1, z..z+1); one thread per word of 32 cells along z
+__global__ __launch_bounds__(1024) void filter_cells_kernel(const uint32_t *__restrict__ sign, const uint32_t *__restrict__ mark,
+                                                            int R, int nx, uint32_t *__restrict__ cell, FilterHeader *__restrict__ hdr) {
+    __shared__ int wsum[16];
+    const int nw = (R + 31) / 32;
+    const long words = (long)nx * R * nw;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = 0;
+    if (i < words) {
+        const int w = (int)(i % nw);
+        const long row = i / nw;
+        const int y = (int)(row % R), x = (int)(row / R);
+        if (x + 1 < nx && y + 1 < R) {
+            const long r00 = row * nw, r01 = (row + 1) * nw, r10 = (row + R) * nw, r11 = (row + R + 1) * nw;
+            const bool hi = w + 1 < nw;
+            auto w64 = [&](const uint32_t *a, long r) { return (uint64_t)a[r + w] | (hi ? (uint64_t)a[r + w + 1] << 32 : 0); };
+            const uint64_t s00 = w64(sign, r00), s01 = w64(sign, r01), s10 = w64(sign, r10), s11 = w64(sign, r11);
+            const uint64_t A = s00 & s01 & s10 & s11, O = s00 | s01 | s10 | s11;
+            const uint64_t M = w64(mark, r00) | w64(mark, r01) | w64(mark, r10) | w64(mark, r11);
+            const uint64_t same = (A & (A >> 1)) | (~O & ~(O >> 1));   // bit z: the 8 corners (z, z + 1) agree
+            const uint64_t poss = ~same | M | (M >> 1);
+            // cells exist for z <= R - 2
+            const int zmax = R - 2 - 32 * w;                            // last valid bit of this word
+            const uint32_t valid = zmax >= 31 ? 0xffffffffu : (zmax < 0 ? 0u : ((2u << zmax) - 1u));
+            c = (uint32_t)poss & valid;
+        }
+        cell[i] = c;
+    }
+    // possibly active cells, for the statistics: one atomic per workgroup
+    int tot = __popc(c);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += wsum[k];
+        if (t) atomicAdd(&hdr->n_cells, t);
+        if (blockIdx.x == 0) hdr->n_points = nx * R * R;
+    }
+}
+
+// point (x, y, z) is a corner of the cells (x-1..x, y-1..y, z-1..z); one thread per word of 32 points along z.  A workgroup
+// reserves one contiguous range of the list for its points (one atomic): the list is ordered inside a workgroup's 1024 words and
+// unordered between workgroups -- the order of the list is irrelevant to the values pass C writes.
+__global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__restrict__ cell, int R, int nx,
+                                                             uint32_t *__restrict__ list, FilterHeader *__restrict__ hdr) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int nw = (R + 31) / 32;
+    const long words = (long)nx * R * nw;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t r = 0, entry = 0;
+    if (i < words) {
+        const int w = (int)(i % nw);
+        const long row = i / nw;
+        const int y = (int)(row % R), x = (int)(row / R);
+        uint32_t c = 0, prev = 0;
+#pragma unroll
+        for (int dx = -1; dx <= 0; ++dx)
+#pragma unroll
+            for (int dy = -1; dy <= 0; ++dy)
+                if (x + dx >= 0 && y + dy >= 0) {
+                    const long q = (row + (long)dx * R + dy) * nw + w;
+                    c |= cell[q];
+                    if (w) prev |= cell[q - 1];
+                }
+        r = c | (c << 1) | (prev >> 31);
+        const int zrem = R - 32 * w;  // points exist for z < R
+        if (zrem < 32) r &= (1u << zrem) - 1u;
+        entry = ((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)(32 * w);
+    }
+    const int n = __popc(r);
+    int incl = n;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { const int v = wsum[k]; wsum[k] = t; t += v; }
+        base_s = t ? atomicAdd(&hdr->n_refined, t) : 0;
+    }
+    __syncthreads();
+    int o = base_s + wsum[wv] + incl - n;
+    while (r) {
+        const int z = __ffs(r) - 1;
+        r &= r - 1;
+        list[o++] = entry + (uint32_t)z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass C: the exact three-limb arithmetic at the listed points (tiles of 32 list entries)
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void density_list_l3k_kernel(
+    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
+    const float *__restrict__ FC, int R, float density_bias, float out_add, float level_log, float guard_band,
+    const uint32_t *__restrict__ list, FilterHeader *__restrict__ hdr, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
+    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
+    const int NH = hd.NH;
+    const int n = hdr->n_refined;
+    if (n <= 0) return;
+    l3_load_lds(smem, blob, hd);
+    const LdsView L = lds_view(smem, NH);
+    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const long ntiles = ((long)n + 31) / 32;
+    const long nw_total = (long)gridDim.x * nwave;
+    const long wid = (long)blockIdx.x * nwave + wave;
+    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;
+    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;
+    float worst = 0.f;
+    for (long t = t_begin; t < t_end; ++t) {
+        const long j = t * 32 + p;
+        const bool valid = j < n;
+        const uint32_t e = list[valid ? j : n - 1];
+        const int ixl = (int)(e >> 20), iy = (int)((e >> 10) & 1023u), iz = (int)(e & 1023u);
+        f32x16 x0, x1;
+        l3_table_sum(FA, FB, FC, R, ixl, iy, iz, h, x0, x1);
+        l3k_hidden(L, NH, A, A3, h, x0, x1);
+        const float d = last_dot(L, 0, h, x0, x1);
+        if (h == 0 && valid) {
+            const long idx = ((long)ixl * R + iy) * R + iz;
+            const float dl = d + density_bias;
+            if (fabsf(dl - level_log) < guard_band) {
+                // the coarse value was exp(d~ + bias) + out_add: near the level the subtraction below is exact to an ulp of the level
+                const float err = fabsf(__logf(out[idx] - out_add) - dl);
+                if (err < INFINITY) worst = fmaxf(worst, err);
+            }
+            out[idx] = exp_f(dl) + out_add;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o, 64));
+    if (lane == 0 && worst > 0.f) atomicMax(&hdr->max_err_bits, __float_as_uint(worst));
+}
+
+}  // namespace sculpt
+
+using namespace sculpt;
+
+extern "C" {
+
+size_t sculpt_density_filter_workspace_bytes(int R, int nx) {
+    if (R < 2 || nx < 1) return 0;
+    return filter_layout(R, nx, nullptr, nullptr);
+}
+
+int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end, float density_bias,
+                                 float out_add, float margin, const void *workspace, void *filter_workspace, float *out,
+                                 unsigned flags, sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    SC_REQUIRE(mlp_packed && workspace && filter_workspace && out, "density_grid_filtered: null argument");
+    SC_REQUIRE(R >= 2 && R <= 1024 && x_begin >= 0 && x_end <= R && x_begin < x_end,
+               "density_grid_filtered: bad range [%d,%d) of %d (R <= 1024)", x_begin, x_end, R);
+    SC_REQUIRE(n_hidden_64 >= 1, "density_grid_filtered: needs at least one 64x64 hidden layer (got %d)", n_hidden_64);
+    SC_REQUIRE(flags & SCULPT_DENSITY_BF16L3, "density_grid_filtered: the exact pass is the three-limb kernel (pass SCULPT_DENSITY_BF16L3)");
+    const unsigned pass_bits = SCULPT_FILTER_PASS_A | SCULPT_FILTER_PASS_B | SCULPT_FILTER_PASS_C;
+    SC_REQUIRE((flags & ~(SCULPT_DENSITY_BF16L3 | SCULPT_FILTER_COARSE_FP16 | SCULPT_FILTER_MARK_ALL | pass_bits)) == 0,
+               "density_grid_filtered: unknown flags %u", flags);
+    const unsigned passes = (flags & pass_bits) ? (flags & pass_bits) : pass_bits;
+    const bool mark_all = flags & SCULPT_FILTER_MARK_ALL;
+    SC_REQUIRE(mark_all || (out_add < 0.f && margin > 0.f && margin < INFINITY),
+               "density_grid_filtered: needs a positive level (out_add = -level < 0, got %g) and a finite margin > 0 (got %g)",
+               (double)out_add, (double)margin);
+    const size_t lds_c = (size_t)coarse_lds_floats(n_hidden_64) * sizeof(float);
+    const size_t lds_x = (size_t)lds_floats_for(n_hidden_64) * sizeof(float);
+    SC_REQUIRE(lds_x <= 160 * 1024, "density_grid_filtered: %d hidden layers do not fit LDS", n_hidden_64);
+    const int nx = x_end - x_begin;
+    const float *FA = reinterpret_cast<const float *>(workspace);
+    const float *FB = FA + (size_t)nx * R * 64;
+    const float *FC = FB + (size_t)nx * R * 64;
+    FilterView v;
+    filter_layout(R, nx, filter_workspace, &v);
+    const float level_log = out_add < 0.f ? logf(-out_add) : 0.f;
+    const float *blob = reinterpret_cast<const float *>(mlp_packed);
+    const long ntiles = (long)nx * ((R + 31) / 32) * R;
+    if (passes & SCULPT_FILTER_PASS_A) {
+        SC_HIP(hipMemsetAsync(v.hd, 0, sizeof(FilterHeader), st));
+        auto kern = (flags & SCULPT_FILTER_COARSE_FP16) ? density_coarse_kernel<tf16x8> : density_coarse_kernel<tbf16x8>;
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_c, st, blob, FA, FB, FC, R, nx, density_bias, out_add, level_log,
+                           margin, mark_all ? 1 : 0, out, v.sign, v.mark, v.hd);
+        SC_LAUNCH_CHECK();
+    }
+    if (passes & SCULPT_FILTER_PASS_B) {
+        const long rows = (long)nx * R, words = rows * ((R + 31) / 32);
+        hipLaunchKernelGGL(filter_cells_kernel, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.sign, v.mark, R, nx, v.cell, v.hd);
+        hipLaunchKernelGGL(filter_points_kernel, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.cell, R, nx, v.list, v.hd);
+        SC_LAUNCH_CHECK();
+    }
+    if (passes & SCULPT_FILTER_PASS_C) {
+        auto kern = density_list_l3k_kernel<1024>;
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+        const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_x, st, blob, FA, FB, FC, R, density_bias, out_add, level_log,
+                           mark_all ? INFINITY : 2.0f * margin, v.list, v.hd, out);
+        SC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats8, sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    SC_REQUIRE(filter_workspace && stats8, "density_filter_stats: null argument");
+    SC_HIP(hipMemcpyAsync(stats8, filter_workspace, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SC_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

@@ -171,6 +171,54 @@ def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begi
     return out
 
 
+def density_grid_filtered(planes, mlp, resolution, margin, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None,
+                          out_add=0.0, events=None, coarse="fp16", mark_all=False, stats_host=None, passes="ABC", tables=True):
+    """density_grid(precision="bf16l3") for marching cubes in two passes (sculpt_density_grid_filtered): every lattice point with
+    one 16-bit product per hidden layer (`coarse`: "fp16" or "bf16"), then the exact three-limb arithmetic at the corners of every
+    cell whose coarse corner signs differ or that has a corner within `margin` (natural-log units of density_act) of the level
+    -out_add.  Returns (volume, stats): the volume holds the bits of the full evaluation at those corners and a value of the
+    right sign elsewhere as long as no coarse error reaches the margin; stats = device int32[8] view of the call's statistics
+    (include/sculpt_hip.h), valid once the stream has passed the call -- stats_host (a pinned int32[8] tensor) receives an
+    asynchronous copy.  mark_all=True re-evaluates every point and stats[1] is the largest coarse error (calibration).
+    passes / tables: timing aids -- run only the named passes ("A", "B", "C" one after the other on the same workspace give what
+    "ABC" gives), skip the plane tables when an earlier call with the same arguments has left them in the workspace."""
+    if coarse not in ("fp16", "bf16"):
+        raise SculptError("density_grid_filtered: coarse must be 'fp16' or 'bf16'")
+    planes = _req(planes, torch.float32, "planes")
+    R = int(resolution)
+    x_end = R if x_end is None else int(x_end)
+    nx = x_end - x_begin
+    _, C, H, W = planes.shape
+    axis = _axis_table(R, radius, planes.device)
+    ws = _workspace(("dg", planes.device), lib.sculpt_density_grid_workspace_bytes(R, nx), planes.device)
+    fws = _workspace(("dgf", planes.device), lib.sculpt_density_filter_workspace_bytes(R, nx), planes.device)
+    if out is None:
+        out = torch.empty(nx * R * R, dtype=torch.float32, device=planes.device)
+    if tables:
+        check(lib.sculpt_plane_features(_ptr(planes), C, H, W, _ptr(mlp.blob), _ptr(axis), R, int(x_begin), x_end,
+                                        float(radius), _ptr(ws), _stream()))
+    flags = _lib.DENSITY_BF16L3 | (_lib.FILTER_COARSE_FP16 if coarse == "fp16" else 0) | (_lib.FILTER_MARK_ALL if mark_all else 0)
+    if passes != "ABC":
+        flags |= sum({"A": _lib.FILTER_PASS_A, "B": _lib.FILTER_PASS_B, "C": _lib.FILTER_PASS_C}[c] for c in passes)
+    if events is not None:
+        events[0].record()
+    check(lib.sculpt_density_grid_filtered(_ptr(mlp.blob), mlp.n_hidden, R, int(x_begin), x_end, float(density_bias),
+                                           float(out_add), float(margin), _ptr(ws), _ptr(fws), _ptr(out), flags, _stream()))
+    if events is not None:
+        events[1].record()
+    stats = fws[:32].view(torch.int32)
+    if stats_host is not None:
+        stats_host.copy_(stats, non_blocking=True)
+    return out, stats
+
+
+def filter_stats(stats):
+    """int32[8] statistics of density_grid_filtered (host or device tensor; a device tensor is read back here) -> dict."""
+    s = stats.cpu().numpy() if isinstance(stats, torch.Tensor) else np.asarray(stats)
+    return {"n_refined": int(s[0]), "max_err": float(s[1:2].view(np.float32)[0]), "n_marked": int(s[2]),
+            "n_nonfinite": int(s[3]), "n_cells": int(s[4]), "n_points": int(s[5])}
+
+
 _axis_cache = {}
 
 

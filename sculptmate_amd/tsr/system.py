@@ -195,7 +195,7 @@ def _f32(x, dev):
 
 
 class TSR(KernelEngine):
-    def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16", decoder_precision="bf16l3"):
+    def __init__(self, cfg=None, pos_embed_mode="scale_factor", precision="bf16", decoder_precision="bf16l3", decoder_filter=True):
         """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times),
         "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference), or
         "bf16l3" (the fast parity mode: fp32 storage, norms and softmax as in "fp32", every matrix product on the bf16 matrix pipe
@@ -206,12 +206,22 @@ class TSR(KernelEngine):
                    limit and no fallback; measured error against the CPU oracle = the fp32 kernel's own.
           "fp32":  the exact-fp32 MFMA kernel (a k-ordered fmaf chain, 1.5x slower): the parity mode.
           "fp16x3" / "bf16x3": two-limb experiments with 22 / 16-bit operands (fp16x3 needs |activation| < 65504 and falls
-                   back to fp32 when the volume comes out non-finite); kept for A/B only, never the default."""
+                   back to fp32 when the volume comes out non-finite); kept for A/B only, never the default.
+        decoder_filter (default True; applies to decoder_precision "bf16l3"): extract_mesh evaluates the dense grid in two passes
+          (csrc/density_filter.hip) -- every lattice point with one 16-bit product per hidden layer, then the three-limb arithmetic at
+          all corners of every cell that can be active -- which gives the mesh of the full evaluation bit for bit as long as no coarse
+          error reaches the calibrated margin (8 x the largest error measured on a 64^3 probe of the first scene code); every call is
+          guarded by the largest coarse error seen at the re-evaluated points and redone in full when that exceeds a third of the
+          margin (filter_info counts both).  False: every lattice point with the three-limb arithmetic."""
         if precision not in ("bf16", "fp32", "bf16l3"):
             raise ValueError("precision must be 'bf16', 'fp32' or 'bf16l3'")
         if decoder_precision not in ("fp32", "bf16l3", "bf16x3", "fp16x3"):
             raise ValueError("decoder_precision must be 'bf16l3', 'fp32', 'fp16x3' or 'bf16x3'")
         self.decoder_precision = decoder_precision
+        self.decoder_filter = bool(decoder_filter)
+        # state of the two-pass density grid: margin (None = not calibrated yet), coarse operand type, counters
+        self.filter_info = {"margin": None, "coarse": "fp16", "usable": True, "calibrations": 0, "filtered": 0, "fallbacks": 0,
+                            "last": None}
         self.cfg = cfg or DEFAULT_CFG
         self.pos_embed_mode = pos_embed_mode
         self.precision = precision
@@ -696,27 +706,95 @@ class TSR(KernelEngine):
         r = self.renderer.cfg.radius
         R = resolution
         out = []
+        mc = lambda v: ops.marching_cubes(v.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,  # noqa: E731
+                                          vert_mul=r - (-r), vert_add=-r)
         for scene_code in scene_codes:
             planes = scene_code.contiguous()
+            dkw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, out_add=-threshold)
             # density_act - threshold == -(-(density_act - threshold))  (system.py:184, isosurface.py:45)
-            vol = ops.density_grid(planes, self.decoder, R, radius=r, density_bias=self.renderer.cfg.density_bias,
-                                   out_add=-threshold, precision=self.decoder_precision, events=density_events)
+            if self._filter_applies(planes, R, threshold):
+                v_pos, t_pos_idx = self._extract_filtered(planes, R, mc, dkw, density_events)
+                color = None
+                if enable_texture:
+                    color = self.renderer.query_triplane(self.decoder, v_pos, planes)["color"]
+                out.append(Mesh(v_pos, t_pos_idx, color))
+                continue
+            vol = ops.density_grid(planes, self.decoder, R, precision=self.decoder_precision, events=density_events, **dkw)
             try:
-                v_pos, t_pos_idx = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
-                                                      vert_mul=r - (-r), vert_add=-r)
+                v_pos, t_pos_idx = mc(vol)
             except _lib.SculptError as e:
                 if e.code != _lib.ERR_MC_NAN or self.decoder_precision != "fp16x3":
                     raise  # fp32 and the bf16 limb modes have the fp32 range: a NaN there is a NaN of the model
                 # the fp16 split left its range (|hidden activation| >= 65504): redo this grid in exact fp32
-                vol = ops.density_grid(planes, self.decoder, R, radius=r, density_bias=self.renderer.cfg.density_bias,
-                                       out_add=-threshold, out=vol)
-                v_pos, t_pos_idx = ops.marching_cubes(vol.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
-                                                      vert_mul=r - (-r), vert_add=-r)
+                vol = ops.density_grid(planes, self.decoder, R, out=vol, **dkw)
+                v_pos, t_pos_idx = mc(vol)
             color = None
             if enable_texture:
                 color = self.renderer.query_triplane(self.decoder, v_pos, planes)["color"]
             out.append(Mesh(v_pos, t_pos_idx, color))
         return out
+
+    # -- the two-pass ("filtered") density grid: calibration, guard, fallback (csrc/density_filter.hip)
+    FILTER_SAFETY = 8.0        # margin = FILTER_SAFETY x the largest coarse error of the calibration probe
+    FILTER_GUARD = 1.0 / 3.0   # a call whose re-evaluated points show a coarse error above FILTER_GUARD x margin is redone in full
+    FILTER_PROBE = 64          # lattice of the calibration probe
+    FILTER_MAX_MARGIN = 2.0    # a model whose coarse pass is this far off (log units of density) gains nothing: filter off
+
+    def _filter_applies(self, planes, R, threshold):
+        return (self.decoder_filter and self.decoder_precision == "bf16l3" and self.filter_info["usable"] and threshold > 0
+                and self.decoder.n_hidden >= 1 and 32 <= R <= 1024)
+
+    def calibrate_decoder_filter(self, planes):
+        """Margin of the two-pass density grid for this model, measured on `planes` (one scene code [3, C, H, W]): every point of a
+        64^3 lattice through both the one-product pass and the three-limb arithmetic (SCULPT_FILTER_MARK_ALL); margin =
+        FILTER_SAFETY x the largest |log d~ - log d|.  IEEE-half operands when the probe stays finite, bf16 otherwise; a model
+        for which neither gives a usable margin runs unfiltered."""
+        info, r = self.filter_info, self.renderer.cfg.radius
+        info["calibrations"] += 1
+        for coarse in ("fp16", "bf16"):
+            _, st = ops.density_grid_filtered(planes, self.decoder, self.FILTER_PROBE, 0.0, radius=r,
+                                              density_bias=self.renderer.cfg.density_bias, out_add=0.0, coarse=coarse, mark_all=True)
+            s = ops.filter_stats(st)
+            if s["n_nonfinite"] == 0 and np.isfinite(s["max_err"]):
+                margin = max(self.FILTER_SAFETY * s["max_err"], 1e-3)
+                if margin <= self.FILTER_MAX_MARGIN:
+                    info.update(margin=margin, coarse=coarse, probe_max_err=s["max_err"])
+                    return info
+        info.update(usable=False, margin=None)
+        return info
+
+    def _extract_filtered(self, planes, R, mc, dkw, density_events):
+        info = self.filter_info
+        if info["margin"] is None:
+            self.calibrate_decoder_filter(planes)
+            if not info["usable"]:
+                return mc(ops.density_grid(planes, self.decoder, R, precision="bf16l3", events=density_events, **dkw))
+        host = getattr(self, "_filter_stats_host", None)
+        if host is None:
+            host = self._filter_stats_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        vol, _ = ops.density_grid_filtered(planes, self.decoder, R, info["margin"], coarse=info["coarse"], events=density_events,
+                                           stats_host=host, **dkw)
+        err = None
+        try:
+            mesh = mc(vol)   # waits for the stream (sculpt_mc_count reads its counts back): the statistics have landed with it
+        except Exception as e:  # an empty / out-of-range surface raises in both evaluations; checked below before it is believed
+            mesh, err = None, e
+        st = ops.filter_stats(host)
+        info["last"] = st
+        if st["max_err"] <= self.FILTER_GUARD * info["margin"]:
+            info["filtered"] += 1
+            if err is not None:
+                raise err
+            return mesh
+        # the coarse pass was further off than the calibration allows for: this grid in full, and a margin that covers what was seen
+        info["fallbacks"] += 1
+        info["margin"] = None
+        vol = ops.density_grid(planes, self.decoder, R, precision="bf16l3", out=vol, **dkw)
+        mesh = mc(vol)
+        self.calibrate_decoder_filter(planes)
+        if info["usable"] and info["margin"] is not None:
+            info["margin"] = min(max(info["margin"], self.FILTER_SAFETY * st["max_err"]), self.FILTER_MAX_MARGIN)
+        return mesh
 
     def extract_mesh_sharded(self, scene_code, resolution: int = 512, threshold: float = 25.0, enable_texture=False):
         """BASELINE config 5: the voxel grid of ONE image split into slabs along the slowest lattice axis over

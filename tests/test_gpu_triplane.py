@@ -300,7 +300,7 @@ def test_bf16l3_keeps_the_fp32_range_no_fallback(cuda):
     planes = torch.from_numpy(synth.smooth_triplane(seed=5, size=16, scale=2.0)).to(cuda)[None]
     meshes, dens = {}, {}
     for prec in ("fp32", "bf16l3"):
-        m = TSR(SMALL_CFG, decoder_precision=prec)
+        m = TSR(SMALL_CFG, decoder_precision=prec, decoder_filter=False)   # the two-pass grid: tests/test_gpu_density_filter.py
         m.load_state_dict(sd)
         m.to(cuda)
         dens[prec] = ops.density_grid(planes[0], m.decoder, 32, precision=prec).clone()
