@@ -288,7 +288,9 @@ def batched_rates(model, imgs, steps):
     one-image step; this is the throughput form."""
     res = {"entry": "TSR.forward([B images resident in HBM]) as one batched pass + TSR.extract_meshes(codes, 256); forward_ms = HIP "
                     "events around forward() (tokenizer + backbone + upsampler of the B images)"}
+    keep = model.max_batch
     for B in (2, 4, 8):
+        model.max_batch = B   # forward() batches only when asked to (default 1: image by image)
         group = [imgs[i % len(imgs)] for i in range(B)]
         n = max(2, min(steps, 24) // B + 1)
         for _ in range(2):
@@ -308,6 +310,7 @@ def batched_rates(model, imgs, steps):
                           "forward_ms": fwd, "passes_timed": n,
                           # 2.96 TFLOP per image over the forward time: the transformer's fraction of the bf16 peak
                           "transformer_tflops": 2.96 * B / (fwd * 1e-3), "transformer_frac": 2.96 * B / (fwd * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
+    model.max_batch = keep
     torch.cuda.empty_cache()
     return res
 
@@ -769,6 +772,9 @@ def main():
                        "decoder_precision": mode, "decoder_filter": use_filter,
                        # test plumbing made visible (tests/test_gpu_bench_ranks.py): ranks sharing one device are NOT a multi-GPU figure
                        "shared_gpu": share_gpu, "collective_backend": backend if dist is not None else None,
+                       # what the process group itself reports (RCCL's communicator when the backend is nccl): a SCALE line
+                       # whose collective_ranks != n_gpus did not run the job it claims
+                       "collective_ranks": int(dist.get_world_size()) if dist is not None else None,
                        "mesh": {"vertices": nv, "faces": nf}, "parallelism": "dp%d (replicas, no collectives)" % args.gpus},
             # achieved / frac: the FLOPs the kernel's MFMA instructions execute (cross-check: SQ_INSTS_VALU_MFMA_MOPS_* x 512 in
             # profiles/round3/pmc_summary.txt) over the live HIP-event launch time, against the dense peak of that pipe

@@ -43,8 +43,11 @@ extern "C" {
 #endif
 
 /* 2: sculpt_attention_bf16 no longer takes scale == 0 for pre-scaled queries (sculpt_attention_bf16_prescaled); batched
- *    attention, host-side PLY face records */
-#define SCULPT_ABI_VERSION 2
+ *    attention, host-side PLY face records; sculpt_gemm_f32 forwards to sculpt_gemm_f32_ex and takes its two preconditions
+ *    (bias 16-byte aligned; without a bias at most 65 532 output columns, see there)
+ * 3: the two-pass dense density grid (sculpt_density_grid_filtered, sculpt_density_filter_workspace_bytes,
+ *    sculpt_density_filter_stats) */
+#define SCULPT_ABI_VERSION 3
 
 typedef void *sculpt_stream_t;
 
@@ -264,7 +267,10 @@ int sculpt_row_slice_stats(const float *x, int ldx, int rows, int cols, float *s
 
 /* fp32 "parity mode" of the same stack (exact-fp32 MFMA, ~5x slower; not timed by bench.py):
  *   out[m][n] = epi(alpha * A[m][:].W[n][:] + bias[n]) (+ residual); A, W, out fp32; K % 16 == 0; N % 4 == 0
- *   (w_rows = valid rows of W when N is padded; 0 = N); n_split / out_t as in sculpt_gemm_bf16. */
+ *   (w_rows = valid rows of W when N is padded; 0 = N); n_split / out_t as in sculpt_gemm_bf16.
+ *   Preconditions since ABI 2 (both entries; a violation is refused with an error, never computed wrongly):
+ *     - bias, when given, is 16-byte aligned (the epilogue reads it as float4; a view at a 4- or 8-byte offset must be copied);
+ *     - without a bias the per-column vector comes from a 256 KiB zero page: N (2 N with the GEGLU epilogue) + 4 <= 65 536. */
 int sculpt_gemm_f32(const float *A, int lda, const float *W, int ldw, const float *bias, const float *residual, int ldr,
                     float *out, int ldo, float *out_t, int ldt, int n_split, int w_rows, int M, int N, int K,
                     float alpha, int epilogue, sculpt_stream_t stream);

@@ -230,10 +230,14 @@ def main(argv=None):
     cap_host_threads(world)
     if not torch.cuda.is_available():
         raise SystemExit("sculptmate_amd.batch needs MI355X GPUs: there is no CPU path")
-    if local_rank >= torch.cuda.device_count():
+    # Test plumbing for 1-GPU boxes (tests/test_batch_sharded.py), as in bench.py: SCULPT_BATCH_SHARE_GPU=1 puts every rank on
+    # cuda:0 (then --backend gloo: RCCL refuses two ranks on one device).  A real run sets neither: one rank per GPU over RCCL.
+    share_gpu = bool(os.environ.get("SCULPT_BATCH_SHARE_GPU"))
+    dev_index = 0 if share_gpu else local_rank
+    if not share_gpu and local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d has no GPU of its own (%d visible): one rank per GPU" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = parallel.init(args.backend or "nccl", device) if world > 1 else None
 
     from . import synth

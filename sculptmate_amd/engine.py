@@ -70,13 +70,32 @@ class KernelEngine:
             return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
         # bf16l3: one fused launch, no score matrix; SCULPT_L3_ATTN_FUSED=0 keeps the three-launch composition (A/B)
         fused = self.l3 and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0"
-        scores = None if fused else self._b("attn_scores", (heads, Tq, ((Tk + 31) // 32) * 32), torch.float32)
-        if batch == 1:
-            return ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=self.l3)
-        assert q_bs % Q.stride(0) == 0 and k_bs % K.stride(0) == 0 and o_bs % O.stride(0) == 0 and vt_bs < Vt.stride(0)
+        if fused:
+            chunks = [(0, heads, None)]
+        else:
+            # the [heads][Tq][Tk] fp32 score scratch is capped (ATTN_SCRATCH_BYTES): heads go through it in chunks, and ONE
+            # grow-only buffer serves every attention shape of the model (SF3D's 27 648 x 3 089 fuse attentions would otherwise
+            # keep 2 x 5.6 GB resident)
+            ld = ((Tk + 31) // 32) * 32
+            per_head = Tq * ld
+            n = max(1, min(heads, self.ATTN_SCRATCH_BYTES // (4 * per_head)))
+            flat = self._buf.get("attn_scores_flat")
+            if flat is None or flat.numel() < n * per_head:
+                flat = self._buf["attn_scores_flat"] = torch.empty(n * per_head, dtype=torch.float32, device=self.device)
+            chunks = [(h0, min(n, heads - h0), flat[:min(n, heads - h0) * per_head].view(min(n, heads - h0), Tq, ld))
+                      for h0 in range(0, heads, n)]
+        if batch > 1:
+            assert q_bs % Q.stride(0) == 0 and k_bs % K.stride(0) == 0 and o_bs % O.stride(0) == 0 and vt_bs < Vt.stride(0)
+            Tkp = ((Tk + 31) // 32) * 32 if self.l3 else ((Tk + 15) // 16) * 16
+            assert (batch - 1) * vt_bs + Tkp <= Vt.shape[1], "V^T too narrow for the last batch entry (%d + %d > %d)" % (
+                (batch - 1) * vt_bs, Tkp, Vt.shape[1])
         for b in range(batch):
-            ops.attention_f32(Q[b * q_bs // Q.stride(0):], K[b * k_bs // K.stride(0):], Vt[:, b * vt_bs:], O[b * o_bs // O.stride(0):],
-                              Tq, Tk, heads, scale, scores, l3=self.l3)
+            q, k = Q[b * q_bs // Q.stride(0):] if b else Q, K[b * k_bs // K.stride(0):] if b else K
+            vt, o = Vt[:, b * vt_bs:] if b else Vt, O[b * o_bs // O.stride(0):] if b else O
+            for h0, nh, scores in chunks:
+                ops.attention_f32(q[:, 64 * h0:], k[:, 64 * h0:], vt[64 * h0:], o[:, 64 * h0:], Tq, Tk, nh, scale, scores, l3=self.l3)
+
+    ATTN_SCRATCH_BYTES = 512 << 20
 
     def _ln(self, x, gamma, beta, eps, y):
         if self.precision == "bf16":

@@ -12,12 +12,23 @@ ROOT_DIR = os.path.dirname(os.path.abspath(__file__))
 
 
 class TripoGenerator(GeneratorFacade):
+    """One attribute beyond the reference's: `precision`, the arithmetic of the transformer, read when the model is constructed
+    (initiate_model):
+      "bf16"   (default; BASELINE config 2) bf16 storage, fp32 accumulate -- the fast mode; the scene code moves by ~0.8 % against
+               the fp32 reference, i.e. the mesh is within 1e-4 of it only GIVEN the same scene code;
+      "bf16l3" the mode that meets the 1e-4 vertex tolerance against the reference's fp32 CPU path end to end: fp32 storage, every
+               matrix product with both operands split exactly into three bf16 limbs, fp32 accumulate (~3x the forward time);
+      "fp32"   the exact-fp32 matrix instruction (slowest; the parity yard-stick).
+    The environment variable SCULPT_PRECISION overrides the default for an add-on that cannot be edited."""
+
     def __init__(self, device):
-        super().__init__(device, checkpoint_dir=ROOT_DIR + "/checkpoints/", chunk_size=8192, mc_resolution=256)
+        super().__init__(device, checkpoint_dir=ROOT_DIR + "/checkpoints/", chunk_size=8192, mc_resolution=256,
+                         precision=os.environ.get("SCULPT_PRECISION", "bf16"))
         self.last_meshes = None  # headless callers read the result here (inside Blender it goes to the scene)
 
     def _construct_model(self):
-        model = TSR.from_pretrained(self.checkpoint_dir, config_name="config.yaml", weight_name="model.ckpt")
+        model = TSR.from_pretrained(self.checkpoint_dir, config_name="config.yaml", weight_name="model.ckpt",
+                                    precision=self.precision)
         model.renderer.set_chunk_size(self.chunk_size)
         return model.to(self.device)
 

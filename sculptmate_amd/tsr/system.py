@@ -234,21 +234,26 @@ class TSR(KernelEngine):
         self.isosurface_helper = None
         self.decoder = None  # ops.PackedMLP after to(device)
         self.mesh_sink = None  # callable(verts, faces, colors, name); default: bpy if importable
-        self.max_batch = 8     # forward(): images per batched pass (system.py:82-115 takes the whole batch at once); 1 = one by one
+        # forward(): images per transformer pass.  1 (default): image by image -- forward([a, b]) is the stack of the single-image
+        # passes bit for bit.  > 1 (opt in, like run(batch=...)): the reference's batched pass (system.py:82-115), whose launches
+        # take other tile shapes, so the scene codes differ from the single-image pass by bf16 rounding
+        self.max_batch = 1
         self._w = None
         self._pos_cache = {}
         self._buf = {}
 
     # ------------------------------------------------------------------ loading
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path: str, config_name: str, weight_name: str):
+    def from_pretrained(cls, pretrained_model_name_or_path: str, config_name: str, weight_name: str, **model_kwargs):
         """system.py:51-66.  config.yaml is read with PyYAML (the ${tokenizer.num_channels}
-        interpolation is resolved by hand); ViT hyper-parameters come from checkpoints/config.json."""
+        interpolation is resolved by hand); ViT hyper-parameters come from checkpoints/config.json.
+        model_kwargs (beyond the reference's signature): TSR's own keyword arguments -- precision="bf16" | "bf16l3" | "fp32",
+        decoder_precision, decoder_filter, pos_embed_mode."""
         if not os.path.isdir(pretrained_model_name_or_path):
             raise FileNotFoundError("Checkpoint directory given doesnt exist")
         cfg = load_config(os.path.join(pretrained_model_name_or_path, config_name),
                           os.path.join(pretrained_model_name_or_path, "config.json"))
-        model = cls(cfg)
+        model = cls(cfg, **model_kwargs)
         ckpt = torch.load(os.path.join(pretrained_model_name_or_path, weight_name), map_location="cpu")
         model.load_state_dict(ckpt)
         return model
@@ -394,6 +399,8 @@ class TSR(KernelEngine):
         pos = self._pos(n_side, imgs[0].device)
         for b in range(B):
             ops.vit_assemble(pout[b * npatch:(b + 1) * npatch], w["cls"], pos, h[b * Ts:b * Ts + T])
+            if Ts > T:   # the pad rows of the stacked stream take part in every Linear: start them from zero on every call, or
+                h[b * Ts + T:(b + 1) * Ts].zero_()   # they drift without bound in a long-running process
         st = self._stream_state("vit", h)     # the residual stream + its bf16 copy + slice statistics (LayerNorm fold)
         self._stats_of(st)                    # rows that do not come out of a GEMM: one small kernel
         qk = self._b("vit_qk", (M, 2 * H), self.adt)
@@ -428,7 +435,8 @@ class TSR(KernelEngine):
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
         D, M = nh * hd, st["h"].shape[0]
         T = M // batch
-        Mp = ((M + 63) // 64) * 64
+        # V^T columns: entry b is read at column b * T for round64(T) columns (the same formula as ldc / ldt below: ADVICE r4)
+        Mp = ((((batch - 1) * T + ((T + 63) // 64) * 64) + 63) // 64) * 64
         qk = self._b("bb_qk", (M, 2 * D), self.adt)
         vt = self._b("bb_vt", (D, Mp), self.adt, zero=True)
         att = self._b("bb_att", (M, D), self.adt)

@@ -266,6 +266,43 @@ def test_batch_cli_writer_keeps_up_with_the_gpu(tmp_path):
         shutil.rmtree(out, ignore_errors=True)
 
 
+@pytest.mark.gpu
+def test_batch_cli_two_ranks_batched_passes_write_the_one_rank_files(tmp_path):
+    """`python -m sculptmate_amd.batch --synthetic 16 --batch 4` launched as two ranks (both on the one GPU of
+    the box, the count exchange over gloo) writes, file for file and byte for byte, what the one-rank run writes: every image
+    exactly once, each in a 4-image transformer pass whose other members differ between the two runs (an image's rows do not see
+    its neighbours'), the two-pass density grid calibrated by each rank on its own first image."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    out = os.path.join(base, "sculpt_batch_cli_%d" % os.getpid())
+    common = [sys.executable, "-m", "sculptmate_amd.batch", "--synthetic", "16", "--batch", "4", "--resolution", "128",
+              "--backend", "gloo"]
+    try:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SCULPT_BATCH_SHARE_GPU="1", PYTHONPATH=ROOT)
+        p = subprocess.run(common + ["--out", os.path.join(out, "one")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        port = 29100 + (os.getpid() * 11) % 800
+        procs = []
+        for r in range(2):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen(common + ["--out", os.path.join(out, "two")], env=e, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True, cwd=ROOT))
+        outs = [q.communicate(timeout=900)[0] for q in procs]
+        for q, o in zip(procs, outs):
+            assert q.returncode == 0, o[-3000:]
+        lines = [ln for ln in outs[0].splitlines() if ln.startswith("synthetic_")]
+        assert len(lines) == 16 and sum("rank 1" in ln for ln in lines) == 8     # rank 0 prints the summary of all images
+        files = sorted(os.listdir(os.path.join(out, "one")))
+        assert files == ["synthetic_%05d.ply" % i for i in range(16)] == sorted(os.listdir(os.path.join(out, "two")))
+        for f in files:
+            with open(os.path.join(out, "one", f), "rb") as a, open(os.path.join(out, "two", f), "rb") as b:
+                x, y = a.read(), b.read()
+            assert len(x) > 100000 and x == y, f
+    finally:
+        import shutil
+
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def test_run_sharded_batched_passes_with_a_stand_in_model(tmp_path):
     """run_sharded(batch=3): this rank's images go through model.run_batched in groups, the previous group is collected while the
     next is queued, every image is written exactly once and the summary is complete (single process, stand-in model)."""

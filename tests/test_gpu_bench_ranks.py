@@ -27,6 +27,8 @@ def test_two_ranks_one_json_line(cuda):
     assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["cpu_baseline"] is None and "boundary" not in d and "sf3d" not in d   # N = 1 extras stay out of the N > 1 line
     assert d["config"]["parallelism"].startswith("dp2")
+    assert d["config"]["collective_ranks"] == 2 and d["config"]["collective_backend"] == "gloo" and d["config"]["shared_gpu"] is True
+    assert d["config"]["decoder_filter"] is True and d["density"]["filtered"]["mesh_identical"] is True
     # refusing a mismatched launch: --gpus 2 without two ranks
     q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=dict(os.environ), cwd=ROOT)

@@ -728,6 +728,38 @@ def test_generator_facade_end_to_end(cuda, tmp_path):
     assert name == "mesh0" and v.dtype == np.float32 and f.dtype == np.int64 and c.shape == (len(v), 3)
 
 
+def test_generator_facade_in_the_tolerance_mode(cuda, tmp_path):
+    """the mode that meets north_star's 1e-4 (precision="bf16l3") is selectable at the add-on's own entry
+    point -- TripoGenerator.precision -> TSR.from_pretrained(..., precision=) -- and delivers the fp32 model's mesh: same
+    topology, vertices within 1e-4 of the extent of TSR(precision="fp32") on the same checkpoint."""
+    import types
+
+    from _meshcmp import assert_mesh_close
+    from test_host_logic import _write_checkpoint
+
+    from sculptmate_amd.generate import TripoGenerator
+
+    _write_checkpoint(str(tmp_path), SMALL_CFG, seed=61)
+    img = (synth.composite_rgb(synth.image_rgba(seed=62, size=SMALL_CFG["cond_image_size"])) * 255).astype(np.uint8)
+    meshes = {}
+    for prec in ("bf16l3", "fp32"):
+        g = TripoGenerator(cuda)
+        assert g.precision == "bf16"
+        g.precision = prec
+        g.checkpoint_dir = str(tmp_path)
+        g.mc_resolution = 32
+        assert g.initiate_model() == 0 and g.model.precision == prec
+        got = []
+        g.model.mesh_sink = lambda v, f, c, name, got=got: got.append((v, f))
+        orig = g.model.extract_mesh
+        if prec == "bf16l3":
+            thr = float(_median_density(g.model, g.model([img], device=cuda), 32))
+        g.model.extract_mesh = types.MethodType(lambda self, codes, orig=orig, **kw: orig(codes, **dict(kw, threshold=thr)), g.model)
+        assert g.generate_mesh(img, "m") == 0
+        meshes[prec] = got[-1]
+    assert_mesh_close(meshes["bf16l3"][0], meshes["bf16l3"][1], meshes["fp32"][0], meshes["fp32"][1], tol=1e-4 * 1.74)
+
+
 def _median_density(model, codes, R):
     from sculptmate_amd import ops
 

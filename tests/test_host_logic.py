@@ -70,10 +70,31 @@ def test_generator_facade_return_codes(tmp_path):
 
     g = TripoGenerator(torch.device("cpu"))
     assert g.chunk_size == 8192 and g.mc_resolution == 256 and g.model is None
+    assert g.precision == "bf16"   # the one attribute beyond the reference's: the transformer's arithmetic
     assert g.generate_mesh(np.zeros((512, 512, 3), np.float32)) == 1
     g.checkpoint_dir = str(tmp_path / "nope")
     assert g.initiate_model() == 2
     assert g.model is None
+
+
+def test_generator_facade_precision_from_environment(monkeypatch):
+    from sculptmate_amd.generate import TripoGenerator
+
+    monkeypatch.setenv("SCULPT_PRECISION", "bf16l3")
+    assert TripoGenerator(torch.device("cpu")).precision == "bf16l3"
+    monkeypatch.delenv("SCULPT_PRECISION")
+    assert TripoGenerator(torch.device("cpu")).precision == "bf16"
+
+
+def test_from_pretrained_passes_model_arguments(tmp_path):
+    from sculptmate_amd.tsr import TSR
+
+    _write_checkpoint(str(tmp_path), SMALL_CFG, seed=5)
+    m = TSR.from_pretrained(str(tmp_path), "config.yaml", "model.ckpt", precision="bf16l3", decoder_filter=False)
+    assert m.precision == "bf16l3" and m.decoder_filter is False and m.decoder_precision == "bf16l3"
+    assert TSR.from_pretrained(str(tmp_path), "config.yaml", "model.ckpt").precision == "bf16"
+    with pytest.raises(ValueError):
+        TSR.from_pretrained(str(tmp_path), "config.yaml", "model.ckpt", precision="fp8")
 
 
 def test_tsr_refuses_cpu_device():
