@@ -218,10 +218,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)a0, (lds_ptr_t)(ab + adst), 16, 0, 0);                   \
         if (AI >= 2)                                                                                         \
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)a1, (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);        \
-        if (AI == 4) {                                                                                       \
+        if (AI >= 3) {                                                                                       \
             const uint16_t *a2 = (!CONV || ((amask2 >> tap) & 1u)) ? asrc2 + ao : zsrc;                      \
-            const uint16_t *a3 = (!CONV || ((amask3 >> tap) & 1u)) ? asrc3 + ao : zsrc;                      \
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)a2, (lds_ptr_t)(ab + adst + 2048), 16, 0, 0);        \
+        }                                                                                                    \
+        if (AI == 4) {                                                                                       \
+            const uint16_t *a3 = (!CONV || ((amask3 >> tap) & 1u)) ? asrc3 + ao : zsrc;                      \
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)a3, (lds_ptr_t)(ab + adst + 3072), 16, 0, 0);        \
         }                                                                                                    \
     } while (0)
@@ -1165,6 +1167,18 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             // (~57 GB/s, whatever the ring depth or the number of barriers: a six-stage ring and two K-tiles per barrier both
             // measured +-0); 64 x 64 tiles put the same bytes through up to twice as many CUs.
             static const int bm64_env = [] { const char *e = getenv("SCULPT_GEMM_BM64"); return e ? atoi(e) : 1; }();
+            // One round of 192 x 64 tiles (round 5): M = 3072, N = 1024 is exactly 16 x 16 = 256 tiles, one per CU, where the 128 x 64
+            // tiles are 384 (1.5 per CU) and move 14 % more bytes through L2 -> LDS -- these launches run at the chip's L2 -> LDS
+            // rate (~17 TB/s; hipBLASLt's 128 x 96 stream-K kernel on the same shape moves 486 MB at the same rate), so the bytes
+            // are the time.  SCULPT_GEMM_BM192=0 / 1: never / whenever legal (A/B); read per call.
+            const char *e192r = getenv("SCULPT_GEMM_BM192");
+            const int f192r = e192r ? atoi(e192r) : -1;
+            const long t192r = (long)(N / 64) * (M / 192);
+            const bool one_round = M % 192 == 0 && t192r <= (long)num_cus() && t192r * 4 >= 3L * num_cus();
+            if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
+                g.gm = 0;
+                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
+            } else
             if (small && underfilled && bm64_env && (long)(N / 64) * cdiv(M, 64) <= 2L * num_cus())
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 64>), dim3(N / 64, cdiv(M, 64)), dim3(512), 0, st, g);
             else if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
