@@ -122,6 +122,51 @@ __device__ __forceinline__ V8 cstate_operand(const CState &s) {
 // LDS image of pass A: [leading parts of the hidden weights: NH * 2048 floats][bacc][wlast][blast]
 __host__ __device__ __forceinline__ int coarse_lds_floats(int NH) { return NH * 2048 + (NH + 1) * 64 + 256 + 4; }
 
+// One hidden layer of pass A for a tile of 32 points: in x0 / x1 the pre-activations (accumulator layout), out the next layer's.
+// k-step software pipeline like l3_kstep: the SiLU + conversion of the 8 values of k-step g + 1 is issued behind the two MFMAs
+// of k-step g (the MFMAs are 3 % of the layer: the SiLU is what it costs, tools/micro/silu_cost.hip).
+template <typename V8>
+__device__ __forceinline__ void coarse_layer(const LdsView &L, const V8 *Al, int l, int h, const f32x16 &x0, const f32x16 &x1,
+                                             f32x16 &o0, f32x16 &o1) {
+    f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
+    f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
+    V8 a0 = Al[0], a1 = Al[256];
+    V8 b;
+    {   // k-step 0's SiLU has no MFMA of this tile to run behind
+        CState s;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.x[i] = x0[i];
+        cchunk<0, V8>(s); cchunk<1, V8>(s); cchunk<2, V8>(s); cchunk<3, V8>(s); cchunk<4, V8>(s); cchunk<5, V8>(s);
+        cchunk<6, V8>(s);
+        b = cstate_operand<V8>(s);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        CState s;
+        V8 a0n = a0, a1n = a1;
+        if (g < 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s.x[i] = (g + 1 < 2 ? x0 : x1)[8 * ((g + 1) & 1) + i];
+        }
+        acc0 = mfma16(a0, b, acc0);
+        if (g < 3) {
+            cchunk<0, V8>(s); cchunk<1, V8>(s); cchunk<2, V8>(s);
+            a0n = Al[(g + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = mfma16(a1, b, acc1);
+        if (g < 3) {
+            cchunk<3, V8>(s); cchunk<4, V8>(s); cchunk<5, V8>(s); cchunk<6, V8>(s);
+            a1n = Al[256 + (g + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < 3) b = cstate_operand<V8>(s);
+        a0 = a0n; a1 = a1n;
+    }
+    o0 = acc0;
+    o1 = acc1;
+}
+
 template <typename V8>
 __global__ __launch_bounds__(1024) void density_coarse_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
@@ -184,45 +229,21 @@ __global__ __launch_bounds__(1024) void density_coarse_kernel(
         load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
         x0 += fb0; x1 += fb1;
         x0 += y0; x1 += y1;
-        for (int l = 0; l < NH; ++l) {
-            const V8 *Al = A + (long)l * 512;
-            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
-            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
-            V8 a0 = Al[0], a1 = Al[256];
-            V8 b;
-            {   // k-step 0's SiLU has no MFMA of this tile to run behind
-                CState s;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s.x[i] = x0[i];
-                cchunk<0, V8>(s); cchunk<1, V8>(s); cchunk<2, V8>(s); cchunk<3, V8>(s); cchunk<4, V8>(s); cchunk<5, V8>(s);
-                cchunk<6, V8>(s);
-                b = cstate_operand<V8>(s);
+        // two layers per trip: x -> y -> x, so that the accumulators of one layer ARE the inputs of the next without the 32
+        // register copies a loop-carried `x = acc` costs (16 v_mov_b64 of ~1050 issue cycles per layer)
+        {
+            int l = 0;
+            for (; l + 1 < NH; l += 2) {
+                f32x16 y0, y1;
+                coarse_layer<V8>(L, A + (long)l * 512, l, h, x0, x1, y0, y1);
+                coarse_layer<V8>(L, A + (long)(l + 1) * 512, l + 1, h, y0, y1, x0, x1);
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                CState s;
-                V8 a0n = a0, a1n = a1;
-                if (g < 3) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s.x[i] = (g + 1 < 2 ? x0 : x1)[8 * ((g + 1) & 1) + i];
-                }
-                acc0 = mfma16(a0, b, acc0);
-                if (g < 3) {
-                    cchunk<0, V8>(s); cchunk<1, V8>(s); cchunk<2, V8>(s);
-                    a0n = Al[(g + 1) * 64];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc1 = mfma16(a1, b, acc1);
-                if (g < 3) {
-                    cchunk<3, V8>(s); cchunk<4, V8>(s); cchunk<5, V8>(s); cchunk<6, V8>(s);
-                    a1n = Al[256 + (g + 1) * 64];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (g < 3) b = cstate_operand<V8>(s);
-                a0 = a0n; a1 = a1n;
+            if (l < NH) {
+                f32x16 y0, y1;
+                coarse_layer<V8>(L, A + (long)l * 512, l, h, x0, x1, y0, y1);
+                x0 = y0;
+                x1 = y1;
             }
-            x0 = acc0;
-            x1 = acc1;
         }
         x0 = silu16_scalar(x0);
         x1 = silu16_scalar(x1);

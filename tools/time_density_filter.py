@@ -93,6 +93,18 @@ def main():
                 tg.append(e2[0].elapsed_time(e2[1]))
         print("   full %.3f ms (min %.3f)   filtered %.3f ms (min %.3f)   ratio %.3f"
               % (np.median(tf), min(tf), np.median(tg), min(tg), np.median(tg) / np.median(tf)))
+        tp = {"A": [], "B": [], "C": []}
+        for rnd in range(3 * args.rounds + 1):
+            es = {}
+            for k, ps in enumerate("ABC"):
+                es[ps] = ev()
+                ops.density_grid_filtered(tri, mlp, R, margin, out_add=-thr, coarse=coarse, out=out, events=es[ps], passes=ps, tables=(k == 0))
+            torch.cuda.synchronize()
+            if rnd:
+                for ps in "ABC":
+                    tp[ps].append(es[ps][0].elapsed_time(es[ps][1]))
+        print("   pass A %.3f ms (min %.3f)   pass B %.3f ms   pass C %.3f ms (min %.3f)"
+              % (np.median(tp["A"]), min(tp["A"]), np.median(tp["B"]), np.median(tp["C"]), min(tp["C"])))
 
 
 if __name__ == "__main__":
