@@ -201,7 +201,7 @@ def filter_identity_check(model, img_dev, rounds=5):
         if rnd:
             for k, (a, b) in evs.items():
                 times[k].append(a.elapsed_time(b))
-    med = {k: float(np.median(v)) for k, v in times.items()}
+    med = {k: (float(np.median(v)) if v else None) for k, v in times.items()}
     res.update({"pass_a_ms": med["A"], "pass_b_ms": med["B"], "pass_c_ms": med["C"], "all_passes_ms": med["ABC"],
                 "full_evaluation_ms": med["full"],
                 "refined_fraction": stt["n_refined"] / stt["n_points"], "marked_fraction": stt["n_marked"] / stt["n_points"],
@@ -660,6 +660,9 @@ def main():
     ap.add_argument("--decoder-precision", choices=("bf16l3", "fp32", "fp16x3", "bf16x3"), default="bf16l3",
                     help="bf16l3 (default = TSR's default: fp32-equivalent three-limb bf16 split), fp32 (exact-fp32 MFMA kernel), "
                          "or a two-limb experiment mode")
+    ap.add_argument("--check-rounds", type=int, default=5,
+                    help="timing rounds of the three passes inside the identity check of the two-pass grid (0: profiling runs, the "
+                         "check alone)")
     ap.add_argument("--no-decoder-filter", action="store_true",
                     help="every lattice point through the six-product kernel (TSR(decoder_filter=False), round 4's path) as the headline")
     args = ap.parse_args()
@@ -704,7 +707,7 @@ def main():
             model.decoder_filter = False
         if model.decoder_filter and DECODER_PRECISION == "bf16l3":
             # the two-pass grid may carry `value` only if it reproduces the full evaluation on the bench's own field
-            filt = filter_identity_check(model, imgs[0])
+            filt = filter_identity_check(model, imgs[0], rounds=args.check_rounds)
             if not (filt.get("usable") and filt.get("sign_mismatches_vs_full") == 0 and filt.get("mesh_identical")):
                 model.decoder_filter = False
                 filt["used_for_value"] = False

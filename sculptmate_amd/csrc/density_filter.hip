@@ -388,7 +388,11 @@ __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
     const int p = lane & 31, h = lane >> 5;
     const long ntiles = ((long)n + 31) / 32;
     const long nw_total = (long)gridDim.x * nwave;
-    const long wid = (long)blockIdx.x * nwave + wave;
+    // the workgroups of one XCD (blockIdx % 8) take one contiguous eighth of the list: the list follows the lattice order inside a
+    // filter_points workgroup (128 rows), so an XCD's L2 then serves one band of the FA / FB tables instead of all of them -- with
+    // the round-robin order every XCD gathered from the whole 50 MB of tables (FETCH_SIZE 854 MB per launch, round 5 first trace)
+    long wid = (long)blockIdx.x * nwave + wave;
+    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
     const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
     const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;
     const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;

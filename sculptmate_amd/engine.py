@@ -74,14 +74,17 @@ class KernelEngine:
             chunks = [(0, heads, None)]
         else:
             # the [heads][Tq][Tk] fp32 score scratch is capped (ATTN_SCRATCH_BYTES): heads go through it in chunks, and ONE
-            # grow-only buffer serves every attention shape of the model (SF3D's 27 648 x 3 089 fuse attentions would otherwise
-            # keep 2 x 5.6 GB resident)
+            # grow-only buffer per stream serves every attention shape of the model (SF3D's 27 648 x 3 089 fuse attentions would
+            # otherwise keep 2 x 5.6 GB resident)
             ld = ((Tk + 31) // 32) * 32
             per_head = Tq * ld
             n = max(1, min(heads, self.ATTN_SCRATCH_BYTES // (4 * per_head)))
-            flat = self._buf.get("attn_scores_flat")
+            # ... per HIP stream: TSR.encode_image runs the image-independent head of the backbone on a second stream beside the
+            # image tokenizer, and both come through here
+            key = ("attn_scores_flat", torch.cuda.current_stream(self.device).cuda_stream)
+            flat = self._buf.get(key)
             if flat is None or flat.numel() < n * per_head:
-                flat = self._buf["attn_scores_flat"] = torch.empty(n * per_head, dtype=torch.float32, device=self.device)
+                flat = self._buf[key] = torch.empty(n * per_head, dtype=torch.float32, device=self.device)
             chunks = [(h0, min(n, heads - h0), flat[:min(n, heads - h0) * per_head].view(min(n, heads - h0), Tq, ld))
                       for h0 in range(0, heads, n)]
         if batch > 1:

@@ -26,6 +26,44 @@ def per_launch(sub, counter):
     return big[len(big) // 2], len(big)
 
 
+def filtered_traffic(sub, counter):
+    """Two-pass grid (round 5): per kernel of the pipeline the median counter value over its FULL-SIZE launches (the calibration
+    probe's 64^3 launches are far below half the maximum) -> {kernel: (value, launches)}; empty when the trace has no coarse pass."""
+    byk = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"]
+            if r["Counter_Name"] == counter and any(k in n for k in ("density_coarse_kernel", "density_list_l3k", "filter_cells", "filter_points")):
+                byk[n.split("(")[0].replace("void sculpt::", "")].append(float(r["Counter_Value"]))
+    res = {}
+    for k, vals in byk.items():
+        big = sorted(v for v in vals if v > 0.5 * max(vals)) if max(vals) > 0 else sorted(vals)
+        res[k] = (big[len(big) // 2], len(big))
+    return res
+
+
+ff, fw = filtered_traffic("pmc_fetch", "FETCH_SIZE"), filtered_traffic("pmc_write", "WRITE_SIZE")
+if any("density_coarse_kernel" in k for k in ff):
+    R = 256
+    fetch_kb = sum(v for v, _ in ff.values())
+    write_kb = sum(v for v, _ in fw.values())
+    res = {
+        "kernel": "density_coarse_kernel + filter_cells + filter_points + density_list_l3k_kernel (one 256^3 call of sculpt_density_grid_filtered)",
+        "mode": "bf16l3+filter",
+        "FETCH_SIZE_KB_raw": {k: v for k, (v, _) in ff.items()}, "WRITE_SIZE_KB_raw": {k: v for k, (v, _) in fw.items()},
+        "full_size_launches": {k: n for k, (_, n) in ff.items()},
+        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+        "algorithmic_bytes_per_launch": int(R ** 3 * 4 + 3 * R * R * 64 * 4),
+        "note": "per call: pass A streams the plane tables (FC once per XCD) and writes the coarse volume + two bitmaps; pass C gathers three "
+                "table rows per re-evaluated point and rewrites those points; sum of the per-kernel medians over the full-size launches",
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+                  "--no-optional-modes --no-extras --no-siblings`, tools/profile_bench.sh, round 5",
+    }
+    json.dump(res, open(dst, "w"), indent=1)
+    print(json.dumps(res))
+    sys.exit(0)
+
 fetch_kb, nf = per_launch("pmc_fetch", "FETCH_SIZE")
 write_kb, nw = per_launch("pmc_write", "WRITE_SIZE")
 R = 256

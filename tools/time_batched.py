@@ -24,6 +24,7 @@ def timed(fn, n=12, warm=3):
     return float(np.median(ts)), float(np.min(ts))
 
 
+m.max_batch = 8   # forward() batches only when asked to (default 1 since round 5)
 with torch.no_grad():
     if "--prof" in sys.argv:
         B = int(sys.argv[sys.argv.index("--prof") + 1])
