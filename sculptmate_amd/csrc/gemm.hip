@@ -119,8 +119,10 @@ static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 til
 // EPI: epilogue; BW: weight rows per block (GEGLU: 128 weight rows = 64 value + 64 gate columns)
 // NW: waves per workgroup.  4 = 2x2 waves of 64 activation x BW/2 weight rows; 8 = 2 (weight) x 4 (activation)
 // waves of 32 x BW/2: twice the waves per SIMD to hide LDS / barrier latency, at 1.5x the LDS bytes per MFMA.
-template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT>
+// NWR: waves along the weight rows (2, or 4 for the 96 x 128 one-round tile: 4 x 2 waves of 32 weight x 48 activation rows).
+template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT, int NWR = 2>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
+    static_assert(NWR == 2 || (EPI == SCULPT_EPI_NONE && !CONV), "the 4 x 2 wave grid is for the plain / residual / LayerNorm-fold form");
     constexpr int WT = BW * 128;  // bytes of a weight tile
     constexpr int AT = BM * 128;
     // LDS ring depth: 3 stages (two K-tiles in flight) for the 64-row tile, 2 for the 128-row tile --
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // workgroup per CU leaves the epilogue and the ramp-up uncovered).
     // (A 256 x 128 tile -- one 144-KiB workgroup per CU, 25 % fewer L2 -> LDS bytes per flop -- measured slower on every shape
     // of the two transformers, as did a 96 x 64 tile inside the pipeline: DESIGN.md 3.3.)
-    constexpr int NSTAGE = BW == 64 ? 3 : 2;
+    constexpr int NSTAGE = (BW == 64 || NWR == 4) ? 3 : 2;
     constexpr int DIST = NSTAGE - 1;  // prefetch distance in K-tiles
     // [stage][W | A], then 2 KiB of exchange space for the LayerNorm statistics (ONE shared array: a second __shared__ object
     // beside the LDS-DMA ring can make hipcc drain the DMA queue before every fragment read)
@@ -136,11 +138,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[XCH + 2 * BM * 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NWC = NW / 2;          // waves along the activation rows
+    constexpr int NWC = NW / NWR;        // waves along the activation rows
+    constexpr int WPW = BW / NWR;        // weight rows (output columns) per wave
     constexpr int TJ = BM / 16 / NWC;    // 16-row activation sub-tiles per wave (4 or 2)
     const int wr = wave / NWC, wc = wave % NWC;
     constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? BW / 2 : BW;  // output columns per block
-    constexpr int TI = BW / 32;                                     // 16-row weight sub-tiles per wave
+    constexpr int TI = WPW / 16;                                    // 16-row weight sub-tiles per wave
     // XCD-aware order: the workgroups of one XCD (private L2) take a contiguous band of the tile grid -- a band of
     // activation rows with every weight tile, or (n_major, when W is the larger operand) a band of weight rows with
     // every activation tile -- so the band's panel is fetched into that L2 once and only the smaller operand streams.
@@ -153,7 +156,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // therefore READ source chunk slot ^ ((row>>1)&7) of that row.
     const int srow = lane >> 3, sslot = lane & 7;
     constexpr int WI = BW / 8 / NW;  // wave instructions per wave for the weight tile (BW/8 rows-of-8 over NW waves)
-    constexpr int AI = BM / 8 / NW;  // ... and for the activation tile
+    // ... and for the activation tile: AG row groups of 8 dealt to the waves -- evenly, or (96 rows on 8 waves: 12 groups) the
+    // first AFULL waves take AI groups and the others AI - 1
+    constexpr int AG = BM / 8, AI = (AG + NW - 1) / NW, AFULL = AG - NW * (AI - 1);
+    constexpr bool UNEVEN = AG % NW != 0;
+    const int acnt = (!UNEVEN || wave < AFULL) ? AI : AI - 1;                                   // wave-uniform
+    const int abase = (!UNEVEN || wave < AFULL) ? wave * AI : AFULL * AI + (wave - AFULL) * (AI - 1);
     const uint16_t *wsrc0, *wsrc1, *wsrc2, *wsrc3;
     const uint16_t *asrc0, *asrc1, *asrc2, *asrc3;
     unsigned amask0 = 0, amask1 = 0, amask2 = 0, amask3 = 0;  // CONV: bit t = tap t of this staged row is inside the image
@@ -171,13 +179,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             return g.W + (long)wrow(r) * g.ldw + ((sslot ^ ((r >> 1) & 7)) << 3);
         };
         auto ap = [&](int q) -> const uint16_t * {
-            const int r = 8 * (wave * AI + q) + srow;
+            const int r = 8 * (abase + q) + srow;
             const int m = min(m0 + r, g.M - 1);
             return g.A + (long)m * g.lda + ((sslot ^ ((r >> 1) & 7)) << 3);
         };
         auto am = [&](int q) -> unsigned {
             if (!CONV) return 0u;
-            const int r = 8 * (wave * AI + q) + srow;
+            const int r = 8 * (abase + q) + srow;
             const int m = min(m0 + r, g.M - 1);
             const int x = m % g.cv_W, y = (m / g.cv_W) % g.cv_H;
             unsigned mask = 0;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         asrc0 = ap(0); asrc1 = ap(1 % AI); asrc2 = ap(2 % AI); asrc3 = ap(3 % AI);
         amask0 = am(0); amask1 = am(1 % AI); amask2 = am(2 % AI); amask3 = am(3 % AI);
     }
-    const int wdst = (wave * WI) * 1024, adst = (wave * AI) * 1024;  // wave-uniform LDS byte offsets
+    const int wdst = (wave * WI) * 1024, adst = abase * 1024;  // wave-uniform LDS byte offsets
 
 #define STAGE(buf, kt)                                                                                       \
     do {                                                                                                     \
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         const uint16_t *a0 = (!CONV || ((amask0 >> tap) & 1u)) ? asrc0 + ao : zsrc;                          \
         const uint16_t *a1 = (!CONV || ((amask1 >> tap) & 1u)) ? asrc1 + ao : zsrc;                          \
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)a0, (lds_ptr_t)(ab + adst), 16, 0, 0);                   \
-        if (AI >= 2)                                                                                         \
+        if (AI >= 2 && (!UNEVEN || acnt >= 2))                                                               \
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)a1, (lds_ptr_t)(ab + adst + 1024), 16, 0, 0);        \
         if (AI >= 3) {                                                                                       \
             const uint16_t *a2 = (!CONV || ((amask2 >> tap) & 1u)) ? asrc2 + ao : zsrc;                      \
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // fragment read offsets (bytes) for ks = 0; ks = 1 flips chunk bit 2 -> XOR 64 bytes
     int aoff[TI], boff[TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) aoff[i] = lds_off(wr * (BW / 2) + i * 16 + fr, fq);
+    for (int i = 0; i < TI; ++i) aoff[i] = lds_off(wr * WPW + i * 16 + fr, fq);
 #pragma unroll
     for (int j = 0; j < TJ; ++j) boff[j] = lds_off(wc * (16 * TJ) + j * 16 + fr, fq);
 
@@ -278,7 +286,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         const int buf = kt % NSTAGE;
         // wait until tile kt has landed; tiles kt+1 .. kt+DIST-1 (if issued) stay in flight
         if (DIST > 1 && kt + 1 < nk && !(kt == 0 && g.ln_stats)) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            if (!UNEVEN || acnt == AI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT - 1) : "memory");   // this wave issued one LDS-DMA fewer per K-tile
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int wrow = (EPI == SCULPT_EPI_GEGLU) ? ((i & 1) ? g.N : 0) + n0 + (wr * (TI / 2) + (i >> 1)) * 16 + fq * 4
-                                                   : n0 + wr * (BW / 2) + i * 16 + fq * 4;
+                                                   : n0 + wr * WPW + i * 16 + fq * 4;
         b4[i] = *reinterpret_cast<const float4 *>(biasp + wrow);
         c4[i] = *reinterpret_cast<const float4 *>(csp + wrow);
     }
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             const int m = min(m0 + wc * (16 * TJ) + j * 16 + fr, g.M - 1);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
-                rs[i][j] = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n0 + wr * (BW / 2) + i * 16 + fq * 4);
+                rs[i][j] = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n0 + wr * WPW + i * 16 + fq * 4);
         }
     }
     // phase 1: the whole tile in registers (acc is overwritten by the results): every loaded value is consumed here, so the
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         } else {
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                const int n = n0 + wr * (BW / 2) + i * 16 + fq * 4;
+                const int n = n0 + wr * WPW + i * 16 + fq * 4;
                 if (n >= g.n_store) continue;
                 const f32x4 o = acc[i][j];
                 // (statistics of the fp32 result: after the store loops, below)
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     //   BW = 128: the wave's 64 columns are one slice.   BW = 64: the two waves (wr = 0, 1) that share the rows each reduce
     //   their 32 columns and wr = 0 merges the pair through LDS (Chan: M2 = M2a + M2b + n/2 (mean_a - mean_b)^2).
     if (EPI == SCULPT_EPI_NONE && g.stats_out) {
-        constexpr int WCOLS = BW / 2;  // columns of this wave
+        constexpr int WCOLS = WPW;  // columns of this wave
         float pm[TJ], pq[TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
@@ -499,19 +508,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             }
         } else {
             static_assert(WCOLS == LN_SLOT || 2 * WCOLS == LN_SLOT, "statistics slice = one or two waves' columns");
-            if (wr == 1 && fq == 0) {
+            // the waves wr = 2p and 2p + 1 share a slice: the odd one hands its half to the even one (pair p in xch[p][row])
+            if ((wr & 1) == 1 && fq == 0) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) xch[wc * (16 * TJ) + j * 16 + fr] = make_float2(pm[j], pq[j]);
+                for (int j = 0; j < TJ; ++j) xch[(wr >> 1) * BM + wc * (16 * TJ) + j * 16 + fr] = make_float2(pm[j], pq[j]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw barrier: the output stores above stay in flight
             __builtin_amdgcn_s_barrier();
-            if (wr == 0 && fq == 0) {
+            if ((wr & 1) == 0 && fq == 0) {
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     const int m = m0 + wc * (16 * TJ) + j * 16 + fr;
-                    const float2 o = xch[wc * (16 * TJ) + j * 16 + fr];
+                    const float2 o = xch[(wr >> 1) * BM + wc * (16 * TJ) + j * 16 + fr];
                     const float d = pm[j] - o.x;
-                    if (m < g.m_store) so[(long)(n0 / LN_SLOT) * g.stats_ld + m] = make_float2(0.5f * (pm[j] + o.x), pq[j] + o.y + (0.5f * WCOLS) * d * d);
+                    if (m < g.m_store) so[(long)((n0 + wr * WCOLS) / LN_SLOT) * g.stats_ld + m] = make_float2(0.5f * (pm[j] + o.x), pq[j] + o.y + (0.5f * WCOLS) * d * d);
                 }
             }
         }
@@ -1175,7 +1185,15 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             const int f192r = e192r ? atoi(e192r) : -1;
             const long t192r = (long)(N / 64) * (M / 192);
             const bool one_round = M % 192 == 0 && t192r <= (long)num_cus() && t192r * 4 >= 3L * num_cus();
-            if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
+            // ... and 96 x 128 (activation x weight rows; 4 x 2 waves of 32 x 48, three-stage ring): the same 256 tiles with 12.5 %
+            // fewer bytes again ((96 + 128) against (192 + 64) rows of K per tile) -- bit-identical and NOT faster (FF2 43.6 against
+            // 42.6 us, to_out 18.3 / 18.1, tools/gemm_bm192_ab.py): below ~540 MB per launch the bytes stop being the time.  Kept
+            // behind SCULPT_GEMM_BM96=1 for A/B only.
+            const char *e96 = getenv("SCULPT_GEMM_BM96");
+            if (e96 && atoi(e96) != 0 && M % 96 == 0 && N % 128 == 0) {
+                g.gm = 0;
+                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8, false, 96, 4>), dim3(N / 128, M / 96), dim3(512), 0, st, g);
+            } else if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
                 g.gm = 0;
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
             } else

@@ -259,8 +259,8 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
 @pytest.mark.parametrize("M,K,N,residual", [(3072, 1024, 1024, True), (3072, 4096, 1024, True), (3072, 1024, 1024, False),
                                             (1536, 256, 2048, True), (960, 128, 1024, False)])
 def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, K, N, residual):
-    """gemm_bf16_kernel<NONE, 64, 8, false, 192> (round 5: M = 3072, N = 1024 as ONE round of 256 tiles of 192 x 64) against the
-    128 x 64 tiles on the same operands: the same k order per output, so h, bf16(h), the slice statistics (residual form) or the
+    """gemm_bf16_kernel<NONE, 64, 8, false, 192> and <NONE, 128, 8, false, 96, 4> (round 5: M = 3072, N = 1024 as ONE round of 256
+    tiles of 192 x 64 or 96 x 128) against the 128 x 64 tiles on the same operands: the same k order per output, so h, bf16(h), the slice statistics (residual form) or the
     LayerNorm-folded bf16 output are equal bit for bit, over repeated in-place launches."""
     from sculptmate_amd import ops
 
@@ -274,8 +274,9 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
     stats_in[..., 1] = 64.0 + torch.rand(K // 64, M, device=cuda)
     cs = W.float().sum(1).contiguous()
 
-    def run(flag):
-        monkeypatch.setenv("SCULPT_GEMM_BM192", flag)
+    def run(bm192, bm96):
+        monkeypatch.setenv("SCULPT_GEMM_BM192", bm192)
+        monkeypatch.setenv("SCULPT_GEMM_BM96", bm96)
         if residual:
             h = h0.clone()
             hb = torch.empty(M, N, dtype=BF, device=cuda)
@@ -287,12 +288,13 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
         ops.gemm(A, W, bias=b, out_bf16=o, ln_stats=stats_in, ln_colsum=cs, ln_eps=1e-5)
         return (o,)
 
-    a, c = run("0"), run("1")
-    for x, y in zip(a, c):
-        assert torch.equal(x, y)
+    a = run("0", "0")
+    for c in (run("1", "0"), run("0", "1")):   # 192 x 64 tiles; 96 x 128 tiles (4 x 2 waves, uneven staging, three-stage ring)
+        for x, y in zip(a, c):
+            assert torch.equal(x, y)
     if residual:
         ref = h0.double().cpu() + 2 * (A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
-        assert _rel(c[0], ref.float())[0] < 1e-5
+        assert _rel(a[0], ref.float())[0] < 1e-5
 
 
 @pytest.mark.parametrize("M,K,N,epi,split,bm192", [(3072, 1024, 4096, 2, 0, 1), (3072, 1024, 3072, 0, 2048, 1), (12288, 1024, 1024, 0, 0, 1),
