@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // workgroup per CU leaves the epilogue and the ramp-up uncovered).
     // (A 256 x 128 tile -- one 144-KiB workgroup per CU, 25 % fewer L2 -> LDS bytes per flop -- measured slower on every shape
     // of the two transformers, as did a 96 x 64 tile inside the pipeline: DESIGN.md 3.3.)
-    constexpr int NSTAGE = (BW == 64 || NWR == 4) ? 3 : 2;
+    constexpr int NSTAGE = (BW == 64 || BM == 96) ? 3 : 2;
     constexpr int DIST = NSTAGE - 1;  // prefetch distance in K-tiles
     // [stage][W | A], then 2 KiB of exchange space for the LayerNorm statistics (ONE shared array: a second __shared__ object
     // beside the LDS-DMA ring can make hipcc drain the DMA queue before every fragment read)
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         if (kt + DIST < nk) STAGE((kt + DIST) % NSTAGE, kt + DIST);
         const unsigned char *wb = smem + buf * (WT + AT);
         const unsigned char *ab = wb + WT;
-        if (NW == 8 && SCULPT_GEMM_READ_AHEAD) {
+        if ((NW == 8 || (NW == 4 && BM == 96)) && SCULPT_GEMM_READ_AHEAD) {
             // both k-steps' fragments are requested before the first MFMA: one exposed LDS latency per K-tile instead of one
             // per group of four MFMAs (the register budget of the 8-wave tiles allows the 2 (TI + TJ) fragments)
             bf16x8_t af[2][TI], bfr[2][TJ];
@@ -1190,7 +1190,11 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             // 42.6 us, to_out 18.3 / 18.1, tools/gemm_bm192_ab.py): below ~540 MB per launch the bytes stop being the time.  Kept
             // behind SCULPT_GEMM_BM96=1 for A/B only.
             const char *e96 = getenv("SCULPT_GEMM_BM96");
-            if (e96 && atoi(e96) != 0 && M % 96 == 0 && N % 128 == 0) {
+            if (e96 && atoi(e96) == 2 && M % 96 == 0 && N % 128 == 0) {
+                // 4 waves of 64 weight x 48 activation rows (hipBLASLt's wave tile on this shape: 7 fragment reads per 12 MFMAs)
+                g.gm = 0;
+                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 4, false, 96, 2>), dim3(N / 128, M / 96), dim3(256), 0, st, g);
+            } else if (e96 && atoi(e96) != 0 && M % 96 == 0 && N % 128 == 0) {
                 g.gm = 0;
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8, false, 96, 4>), dim3(N / 128, M / 96), dim3(512), 0, st, g);
             } else if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
