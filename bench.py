@@ -537,16 +537,29 @@ def slab512_extra(model, img_dev, world=8, iters=2):
     cfg = model.renderer.cfg
     kw = dict(radius=cfg.radius, density_bias=cfg.density_bias, threshold=THRESHOLD)
     res = {}
-    for w in (1, world):
-        v, f = slab.extract_mesh_slabs_local(planes, model.decoder, 512, w, **kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            v, f = slab.extract_mesh_slabs_local(planes, model.decoder, 512, w, **kw)
-        torch.cuda.synchronize()
-        res["slabs_%d_ms" % w] = (time.perf_counter() - t0) / iters * 1e3
-        res["vertices"], res["faces"] = int(v.shape[0]), int(f.shape[0])
-        del v, f
+    variants = [("", kw)]
+    if filtered_active(model):   # every slab through the two-pass grid, as TSR.extract_mesh_sharded runs it (the default)
+        dkw = dict(radius=cfg.radius, density_bias=cfg.density_bias, out_add=-THRESHOLD)
+        fkw = dict(kw, run=lambda x0, x1, mc: model._extract_filtered(planes, 512, mc, dkw, None, x0, x1))
+        variants = [("", fkw), ("full_evaluation_", kw)]
+    meshes = {}
+    for tag, k in variants:
+        for w in (1, world):
+            v, f = slab.extract_mesh_slabs_local(planes, model.decoder, 512, w, **k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                v, f = slab.extract_mesh_slabs_local(planes, model.decoder, 512, w, **k)
+            torch.cuda.synchronize()
+            res["%sslabs_%d_ms" % (tag, w)] = (time.perf_counter() - t0) / iters * 1e3
+            res["vertices"], res["faces"] = int(v.shape[0]), int(f.shape[0])
+            meshes[(tag, w)] = (v, f)
+    if len(variants) == 2:
+        res["decoder_filter"] = True
+        res["mesh_identical_to_full_evaluation"] = bool(all(
+            torch.equal(meshes[("", w)][0].view(torch.int32), meshes[("full_evaluation_", w)][0].view(torch.int32))
+            and torch.equal(meshes[("", w)][1], meshes[("full_evaluation_", w)][1]) for w in (1, world)))
+    del meshes
     res["what"] = ("extract_mesh at 512^3 (density grid + marching cubes) on 1 GPU: single pass vs %d slabs one after the other + "
                    "assemble (the per-rank work and the assembly of config 5; the RCCL gather itself needs %d GPUs)" % (world, world))
     torch.cuda.empty_cache()

@@ -28,18 +28,26 @@ def slab_ranges(R, world):
     return out
 
 
-def extract_slab(planes, mlp, R, rank, world, radius=0.87, density_bias=-1.0, threshold=25.0, precision="bf16l3"):
-    """Density + marching cubes of this rank's slab -> dict of device tensors (local ids, refs < 0)."""
+def extract_slab(planes, mlp, R, rank, world, radius=0.87, density_bias=-1.0, threshold=25.0, precision="bf16l3", run=None):
+    """Density + marching cubes of this rank's slab -> dict of device tensors (local ids, refs < 0).
+    run(x_begin, x_end, mc) (optional): evaluates lattice planes [x_begin, x_end) and returns mc(volume) -- TSR passes its two-pass
+    grid with the run-time guard here (TSR._extract_filtered); default: the full evaluation in `precision`."""
     c0, c1 = slab_ranges(R, world)[rank]
     if c1 <= c0:
         dev = planes.device
         return dict(verts=torch.empty((0, 3), device=dev), faces=torch.empty((0, 3), dtype=torch.int64, device=dev),
                     top=torch.full((2, R, R), -1, dtype=torch.int32, device=dev), minmax=(float("inf"), float("-inf")))
-    vol = ops.density_grid(planes, mlp, R, radius=radius, density_bias=density_bias, x_begin=c0, x_end=c1 + 1,
-                           out_add=-threshold, precision=precision)
-    v, f, top, mm = ops.marching_cubes(vol.view(c1 - c0 + 1, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
-                                       vert_mul=radius - (-radius), vert_add=-radius,
-                                       slab=dict(axis0_offset=c0, halo_low=rank > 0 and c0 > 0))
+
+    def mc(vol):
+        return ops.marching_cubes(vol.view(c1 - c0 + 1, R, R), 0.0, reference_order=True, vert_div=R - 1.0,
+                                  vert_mul=radius - (-radius), vert_add=-radius,
+                                  slab=dict(axis0_offset=c0, halo_low=rank > 0 and c0 > 0))
+
+    if run is not None:
+        v, f, top, mm = run(c0, c1 + 1, mc)
+    else:
+        v, f, top, mm = mc(ops.density_grid(planes, mlp, R, radius=radius, density_bias=density_bias, x_begin=c0, x_end=c1 + 1,
+                                            out_add=-threshold, precision=precision))
     return dict(verts=v, faces=f, top=top, minmax=mm)
 
 

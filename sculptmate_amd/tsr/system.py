@@ -771,8 +771,11 @@ class TSR(KernelEngine):
         info.update(usable=False, margin=None)
         return info
 
-    def _extract_filtered(self, planes, R, mc, dkw, density_events):
+    def _extract_filtered(self, planes, R, mc, dkw, density_events=None, x_begin=0, x_end=None):
+        """The two-pass grid of lattice planes [x_begin, x_end) + mc(volume) (marching cubes: its count read-back waits for the
+        stream, so the statistics of the grid call have landed when it returns), under the run-time guard."""
         info = self.filter_info
+        dkw = dict(dkw, x_begin=x_begin, x_end=x_end)
         if info["margin"] is None:
             self.calibrate_decoder_filter(planes)
             if not info["usable"]:
@@ -817,6 +820,10 @@ class TSR(KernelEngine):
         planes = scene_code.contiguous()
         kw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, threshold=threshold,
                   precision="fp32" if self.decoder_precision == "fp16x3" else self.decoder_precision)
+        if self._filter_applies(planes, resolution, threshold):
+            # every slab through the two-pass grid (cells inside the slab's planes only: the halo plane is part of the slab)
+            dkw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, out_add=-threshold)
+            kw["run"] = lambda x0, x1, mc: self._extract_filtered(planes, resolution, mc, dkw, None, x0, x1)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             part = slab.extract_slab(planes, self.decoder, resolution, dist.get_rank(), dist.get_world_size(), **kw)
             v_pos, t_pos_idx = slab.gather_and_assemble(part, planes.device)

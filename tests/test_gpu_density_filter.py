@@ -272,6 +272,34 @@ def test_tsr_filter_with_activations_beyond_the_fp16_range(cuda):
     assert b.filter_info["fallbacks"] == 0
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_tsr_slabs_through_the_filtered_grid_equal_the_full_evaluation(cuda, world):
+    """BASELINE config 5's per-rank work (TSR.extract_mesh_sharded's slabs, emulated one after the other) with every slab through
+    the two-pass grid: the assembled mesh equals the one from fully evaluated slabs bit for bit, every slab under the guard."""
+    from sculptmate_amd import ops, slab
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+
+    R = 72
+    sd = synth.tsr_state(3, SMALL_CFG)
+    planes = _small_scene(cuda)[0]
+    m = _small_tsr(cuda, sd)
+    thr = float(np.quantile(ops.density_grid(planes, m.decoder, 48, precision="bf16l3").cpu().numpy(), 0.9))
+    cfg = m.renderer.cfg
+    kw = dict(radius=cfg.radius, density_bias=cfg.density_bias, threshold=thr)
+    dkw = dict(radius=cfg.radius, density_bias=cfg.density_bias, out_add=-thr)
+    fv, ff = slab.extract_mesh_slabs_local(planes, m.decoder, R, world, **kw)
+    v, f = slab.extract_mesh_slabs_local(planes, m.decoder, R, world,
+                                         run=lambda x0, x1, mc: m._extract_filtered(planes, R, mc, dkw, None, x0, x1), **kw)
+    assert torch.equal(f, ff) and torch.equal(v.view(torch.int32), fv.view(torch.int32)) and v.shape[0] > 1000
+    assert m.filter_info["filtered"] == world and m.filter_info["fallbacks"] == 0
+    # ... and through the model's own entry point (no process group: one slab)
+    mesh = m.extract_mesh_sharded(planes, resolution=R, threshold=thr)
+    m2 = _small_tsr(cuda, sd, decoder_filter=False)
+    ref = m2.extract_mesh_sharded(planes, resolution=R, threshold=thr)
+    assert torch.equal(mesh.faces, ref.faces) and torch.equal(mesh.vertices.view(torch.int32), ref.vertices.view(torch.int32))
+    assert m.filter_info["filtered"] == world + 1 and m2.filter_info["filtered"] == 0
+
+
 def test_tsr_filter_leaves_other_decoder_modes_alone(cuda):
     from sculptmate_amd.tsr.spec import SMALL_CFG
 
