@@ -31,7 +31,11 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from sculptmate_amd import _lib
 
-    assert _lib.lib.sculpt_version() == 2
+    import re
+
+    hdr = open(os.path.join(ROOT, "include", "sculpt_hip.h")).read()
+    want = int(re.search(r"#define\s+SCULPT_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert want == 3 and _lib.lib.sculpt_version() == want   # 3: the two-pass dense density grid (round 5)
     assert isinstance(_lib.last_error(), str)
     assert _lib.lib.sculpt_device_count() >= 0
 
