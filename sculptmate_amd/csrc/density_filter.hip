@@ -388,16 +388,28 @@ __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
     const int p = lane & 31, h = lane >> 5;
     const long ntiles = ((long)n + 31) / 32;
     const long nw_total = (long)gridDim.x * nwave;
-    // the workgroups of one XCD (blockIdx % 8) take one contiguous eighth of the list: the list follows the lattice order inside a
-    // filter_points workgroup (128 rows), so an XCD's L2 then serves one band of the FA / FB tables instead of all of them -- with
-    // the round-robin order every XCD gathered from the whole 50 MB of tables (FETCH_SIZE 854 MB per launch, round 5 first trace)
-    long wid = (long)blockIdx.x * nwave + wave;
-    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
-    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
+    // Tile order.  The list follows the lattice (x slowest) inside a filter_points workgroup, and every re-evaluated point gathers
+    // its own FC row (iy, iz) -- 256 B per point, 714 MB per launch on the bench field if none is reused.  Neighbouring x planes cut
+    // the surface at nearly the same (iy, iz), so: the workgroups of one XCD (blockIdx % 8, one private L2) take one contiguous
+    // eighth of the list, and inside it the tiles are dealt ROUND-ROBIN to the XCD's waves -- at any time the XCD works on ~512
+    // consecutive tiles (one or two x planes) whose FC rows fit its L2 and are still there when the next plane comes by.  (A
+    // contiguous range per wave put 32 different planes into an XCD's L2 at once: FETCH_SIZE 373 MB raw per launch.)
+    long t_begin, t_end, t_step;
+    if (gridDim.x % 8 == 0) {
+        const long nxw = (long)(gridDim.x >> 3) * nwave, xcd = blockIdx.x & 7;
+        const long c_begin = ntiles * xcd / 8, c_end = ntiles * (xcd + 1) / 8;
+        t_begin = c_begin + (long)(blockIdx.x >> 3) * nwave + wave;
+        t_end = c_end;
+        t_step = nxw;
+    } else {
+        t_begin = (long)blockIdx.x * nwave + wave;
+        t_end = ntiles;
+        t_step = nw_total;
+    }
     const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;
     const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;
     float worst = 0.f;
-    for (long t = t_begin; t < t_end; ++t) {
+    for (long t = t_begin; t < t_end; t += t_step) {
         const long j = t * 32 + p;
         const bool valid = j < n;
         const uint32_t e = list[valid ? j : n - 1];
