@@ -211,6 +211,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--images", nargs="*", default=[], help="image files, directories or glob patterns")
     ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic 512x512 images and random-init weights instead")
+    ap.add_argument("--synthetic-model", choices=("full", "small"), default="full",
+                    help="with --synthetic: the reference architecture at full size, or the small test configuration (seconds to build)")
     ap.add_argument("--checkpoint", default=None, help="directory with model.ckpt + config.yaml (TSR.from_pretrained)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--resolution", type=int, default=256)
@@ -244,10 +246,18 @@ def main(argv=None):
     from .tsr import TSR
 
     if args.synthetic:
-        model = TSR(pos_embed_mode="scale_factor")
-        sd_syn = synth.tsr_state(seed=0)
+        if args.synthetic_model == "small":
+            from .tsr.spec import SMALL_CFG
+
+            model = TSR(SMALL_CFG, pos_embed_mode="scale_factor")
+            sd_syn = synth.tsr_state(seed=0, cfg=SMALL_CFG)
+            size = SMALL_CFG["cond_image_size"]
+        else:
+            model = TSR(pos_embed_mode="scale_factor")
+            sd_syn = synth.tsr_state(seed=0)
+            size = 512
         model.load_state_dict(sd_syn)
-        images = [(lambda i=i: synth.composite_rgb(synth.image_rgba(seed=100 + i))) for i in range(args.synthetic)]
+        images = [(lambda i=i: synth.composite_rgb(synth.image_rgba(seed=100 + i, size=size))) for i in range(args.synthetic)]
         names = ["synthetic_%05d" % i for i in range(args.synthetic)]
     else:
         if not args.checkpoint:

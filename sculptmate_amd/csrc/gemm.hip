@@ -768,6 +768,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     constexpr int TSB = BM * 2 + 16;     // transposed staging: a row = the BM activation rows of one weight row
     static_assert(BM * RSB <= XCH + 2 * BM * 8 && 256 * TSB <= XCH + 2 * BM * 8, "the staged tile fits the LDS of the ring");
     const bool staged = !RES && g.stage != 0;
+    // token-major staging: a lane writes the 8-byte piece of its column group fq of tile row fr; rows are 68 (132) dwords apart,
+    // so the 16 lanes of one fq group -- one 128-byte pass of a ds_write_b64 -- hit banks 4 fr (mod 32): rows fr and fr + 8 collide
+    // (the 7-9 % conflict cycles of the counters, gone with direct stores).  Rows 8..15 of every 16 therefore swap their even /
+    // odd pieces (fq ^ 1): the 16 lanes then cover 32 distinct banks; the 16-byte read-out swaps the halves back for those rows.
+    const int fqs = fq ^ (fr >> 3);
     const bool tileT = staged && EPI != SCULPT_EPI_GEGLU && g.out_t && n0 >= g.n_split;   // workgroup-uniform
     const float *biasp = g.bias ? g.bias : g.zeros;
     const float *csp = g.ln_stats ? g.ln_colsum : g.zeros;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                     uint2 pk;
                     pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
                     pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-                    *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + ((wr * (TI / 2) + ip) * 16 + fq * 4) * 2) = pk;
+                    *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + ((wr * (TI / 2) + ip) * 16 + fqs * 4) * 2) = pk;
                 } else if (m < g.m_store) {
                     if (g.out_bf16) {
                         uint2 pk;
@@ -884,14 +889,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                 }
                 if (staged) {
                     if (tileT) {   // [tile row n][activation row m], 2 bytes each
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            *reinterpret_cast<uint16_t *>(smem + (wr * 128 + i * 16 + fq * 4 + r) * TSB + (wc * WROWS + j * 16 + fr) * 2) = f32_to_bf16(o[r]);
+                        // The lanes fr = 2k and 2k + 1 hold the neighbouring activation rows m, m + 1 of the same four tile rows:
+                        // they swap two values each, so that the even lane writes the (m, m + 1) pairs of tile rows r = 0, 1 and
+                        // the odd lane those of r = 2, 3 as whole dwords -- two ds_write_b32 per lane on 64 distinct banks instead
+                        // of four 2-byte writes with two lanes per dword (the LDS conflicts of round 4's counters)
+                        const bool odd = fr & 1;
+                        const float s0 = odd ? o[0] : o[2], s1 = odd ? o[1] : o[3];
+                        const float g0 = __shfl_xor(s0, 1, 64), g1 = __shfl_xor(s1, 1, 64);   // the partner's values of MY tile rows
+                        const float a0 = odd ? g0 : o[0], b0 = odd ? o[2] : g0;   // (row m_even, row m_odd) of my first tile row
+                        const float a1 = odd ? g1 : o[1], b1 = odd ? o[3] : g1;   // ... and of my second
+                        const int r0 = odd ? 2 : 0;
+                        unsigned char *dst = smem + (wr * 128 + i * 16 + fq * 4 + r0) * TSB + (wc * WROWS + j * 16 + (fr & ~1)) * 2;
+                        *reinterpret_cast<uint32_t *>(dst) = (uint32_t)f32_to_bf16(a0) | ((uint32_t)f32_to_bf16(b0) << 16);
+                        *reinterpret_cast<uint32_t *>(dst + TSB) = (uint32_t)f32_to_bf16(a1) | ((uint32_t)f32_to_bf16(b1) << 16);
                     } else {
                         uint2 pk;
                         pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
                         pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
-                        *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + (wr * 128 + i * 16 + fq * 4) * 2) = pk;
+                        *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + (wr * 128 + i * 16 + fqs * 4) * 2) = pk;
                     }
                     continue;
                 }
@@ -932,8 +947,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int c0 = 0; c0 < BM * CPR; c0 += 512) {
                 const int c = c0 + tid, row = c / CPR, cc = c - row * CPR;
-                if (c < BM * CPR && m0 + row < g.m_store)
-                    *reinterpret_cast<uint4 *>(ob + (long)row * g.ldo + cc * 8) = *reinterpret_cast<const uint4 *>(smem + row * RSB + cc * 16);
+                if (c < BM * CPR && m0 + row < g.m_store) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(smem + row * RSB + cc * 16);
+                    if (row & 8) v = make_uint4(v.z, v.w, v.x, v.y);   // rows 8..15 of every 16 hold their piece pairs swapped (fqs above)
+                    *reinterpret_cast<uint4 *>(ob + (long)row * g.ldo + cc * 8) = v;
+                }
             }
         }
     }

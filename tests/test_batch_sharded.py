@@ -268,14 +268,15 @@ def test_batch_cli_writer_keeps_up_with_the_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_batch_cli_two_ranks_batched_passes_write_the_one_rank_files(tmp_path):
-    """`python -m sculptmate_amd.batch --synthetic 16 --batch 4` launched as two ranks (both on the one GPU of
+    """`python -m sculptmate_amd.batch --synthetic 16 --batch 4` (the small test configuration of the model: the
+    full-size CLI run is test_batch_cli_writer_keeps_up_with_the_gpu) launched as two ranks (both on the one GPU of
     the box, the count exchange over gloo) writes, file for file and byte for byte, what the one-rank run writes: every image
     exactly once, each in a 4-image transformer pass whose other members differ between the two runs (an image's rows do not see
     its neighbours'), the two-pass density grid calibrated by each rank on its own first image."""
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path)
     out = os.path.join(base, "sculpt_batch_cli_%d" % os.getpid())
-    common = [sys.executable, "-m", "sculptmate_amd.batch", "--synthetic", "16", "--batch", "4", "--resolution", "128",
-              "--backend", "gloo"]
+    common = [sys.executable, "-m", "sculptmate_amd.batch", "--synthetic", "16", "--synthetic-model", "small", "--batch", "4",
+              "--resolution", "96", "--backend", "gloo"]
     try:
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SCULPT_BATCH_SHARE_GPU="1", PYTHONPATH=ROOT)
         p = subprocess.run(common + ["--out", os.path.join(out, "one")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -296,7 +297,7 @@ def test_batch_cli_two_ranks_batched_passes_write_the_one_rank_files(tmp_path):
         for f in files:
             with open(os.path.join(out, "one", f), "rb") as a, open(os.path.join(out, "two", f), "rb") as b:
                 x, y = a.read(), b.read()
-            assert len(x) > 100000 and x == y, f
+            assert len(x) > 20000 and x == y, f
     finally:
         import shutil
 

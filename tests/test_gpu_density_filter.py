@@ -174,6 +174,23 @@ def test_filtered_grid_at_full_size_over_thresholds(cuda):
         assert _same_mesh(ops.marching_cubes(vol.view(R, R, R), 0.0), ops.marching_cubes(full.view(R, R, R), 0.0))
 
 
+def test_statistics_through_the_c_entry_point(cuda):
+    """sculpt_density_filter_stats (device -> host copy + wait, for callers without torch) returns the words of the header."""
+    import ctypes
+
+    from sculptmate_amd import _lib, ops
+
+    tri, mlp, _, _ = _field(cuda, 21, inside=0.1)
+    margin, _ = _margin(tri, mlp, "fp16")
+    _, st = ops.density_grid_filtered(tri, mlp, 40, margin, out_add=-THR)
+    want = st.cpu().numpy()
+    fws = ops._ws_cache[("dgf", tri.device)]
+    got = np.zeros(8, np.int32)
+    _lib.check(_lib.lib.sculpt_density_filter_stats(ctypes.c_void_p(fws.data_ptr()), ctypes.c_void_p(got.ctypes.data),
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.array_equal(got, want) and got[5] == 40 ** 3 and 0 < got[0] < 40 ** 3
+
+
 def test_bad_arguments_are_refused(cuda):
     from sculptmate_amd import _lib, ops
 
