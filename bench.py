@@ -42,8 +42,9 @@ EXECUTED_FLOP_PER_POINT = {"bf16l3": 8 * 48 * 32768 / 32, "fp32": 8 * 64 * 4096 
 # EVERY point (8 MFMAs per layer and 32 points), pass C = the six-product arithmetic at the re-evaluated points only
 COARSE_FLOP_PER_POINT = 8 * 8 * 32768 / 32
 FILTER_KERNEL_NAME = ("density_coarse_kernel<f16> (every lattice point: fused triplane-sum + NeRF-MLP, one fp16 product per hidden layer "
-                      "on v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 SiLU) + filter_cells / filter_points (bit arithmetic) + "
-                      "density_list_l3k_kernel (six exact bf16-limb products at the corners of every possibly active cell)")
+                      "on v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 SiLU) + filter_cells / filter_points (bit arithmetic) + 2 x "
+                      "density_list_l3k_kernel (six exact bf16-limb products at the points near the level, then at the values "
+                      "marching cubes reads)")
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak
 KERNEL_NAME = {"bf16l3": "density_grid_l3k_kernel (fused triplane-sum + NeRF-MLP; hidden layers as six exact bf16-limb products on "
@@ -205,7 +206,9 @@ def filter_identity_check(model, img_dev, rounds=5):
     res.update({"pass_a_ms": med["A"], "pass_b_ms": med["B"], "pass_c_ms": med["C"], "all_passes_ms": med["ABC"],
                 "full_evaluation_ms": med["full"],
                 "refined_fraction": stt["n_refined"] / stt["n_points"], "marked_fraction": stt["n_marked"] / stt["n_points"],
-                "possibly_active_cells": stt["n_cells"], "nonfinite_coarse_values": stt["n_nonfinite"],
+                "active_cells": stt["n_cells"], "nonfinite_coarse_values": stt["n_nonfinite"],
+                "passes": "A = one fp16 product per layer at every point; B = the marked points exactly (every sign certain after it); "
+                          "C = the values marching cubes reads (end points of sign-changing edges, corners of ambiguous cells)",
                 "guard_max_err_log_density": stt["max_err"], "guard_over_margin": stt["max_err"] / info["margin"],
                 "sign_mismatches_vs_full": mism, "mesh_identical": bool(same),
                 "mesh": {"vertices": int(mcb[0].shape[0]), "faces": int(mcb[1].shape[0])},
@@ -777,9 +780,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE[mode] + (" [two-pass grid: an fp16 one-product pass decides the SIGN away from the surface, every corner of every "
-                                    "active marching-cubes cell carries the three-limb value: mesh bit-identical to the full evaluation, "
-                                    "checked in-bench under density.filtered]" if filtered_active(model) else ""),
+            "dtype": DTYPE[mode] + (" [filtered grid: an fp16 one-product pass decides the SIGN away from the level, every value marching "
+                                    "cubes reads carries the three-limb value: mesh bit-identical to the full evaluation, checked "
+                                    "in-bench under density.filtered]" if filtered_active(model) else ""),
             "data": "synthetic 512x512 RGBA composited on grey; random-init weights (seeded), calibrated density bias",
             "config": {"workload": "TripoSR single image -> mesh, mc_resolution=256, 1 image per GPU per step",
                        "entry_points_timed": "TSR.forward([image resident in HBM]) + TSR.extract_meshes(codes, resolution=256): mesh "

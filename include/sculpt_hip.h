@@ -145,22 +145,23 @@ int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_be
 int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                            float density_bias, float out_add, const void *workspace, float *out, unsigned flags,
                            sculpt_stream_t stream);
-/* The dense grid for marching cubes in two passes (csrc/density_filter.hip): marching cubes (isosurface.py:41-54) reads the
- * magnitude of the volume only at the corners of active cells and the sign everywhere else, so
+/* The dense grid for marching cubes, filtered (csrc/density_filter.hip): marching cubes (isosurface.py:41-54) reads the magnitude
+ * of the volume only at the end points of sign-changing lattice edges and at all corners of the cells whose sign pattern is
+ * ambiguous (Lewiner's face / interior tests, centre vertex), and the sign everywhere else, so
  *   pass A evaluates every lattice point with ONE 16-bit product per hidden layer (bf16 operands, or IEEE half with
  *          SCULPT_FILTER_COARSE_FP16; fp32 accumulate) and marks the points with |log(density_act) - log(level)| < margin
  *          (level = -out_add > 0) or a non-finite coarse value,
- *   pass B finds the cells whose coarse corner signs differ or that touch a marked point, and lists all their corners,
- *   pass C re-evaluates the listed points with the SCULPT_DENSITY_BF16L3 arithmetic (bit for bit the values
- *          sculpt_density_grid_ex gives there) over the coarse values.
- * out then holds the exact value at every corner of every active cell and a value of the right sign elsewhere, i.e. marching
- * cubes gives the mesh of the full evaluation bit for bit, PROVIDED no coarse error |log d~ - log d| reaches `margin`.  The
- * caller calibrates the margin: SCULPT_FILTER_MARK_ALL marks every point (margin and level unused), so that stats[1] is the
- * largest coarse error over the lattice; at run time stats[1] is the largest coarse error over the re-evaluated points
- * within 2 margins of the level (the guard).  flags must contain SCULPT_DENSITY_BF16L3; n_hidden_64 >= 1; R <= 1024.
+ *   pass B re-evaluates the marked points with the SCULPT_DENSITY_BF16L3 arithmetic (bit for bit the values
+ *          sculpt_density_grid_ex gives there): after it the sign of every lattice point is certain,
+ *   pass C lists, from the signs, the values marching cubes reads (minus the marked points) and re-evaluates those.
+ * out then holds the exact value wherever marching cubes reads one and a value of the right sign elsewhere, i.e. marching cubes
+ * gives the mesh of the full evaluation bit for bit, PROVIDED no coarse error |log d~ - log d| reaches `margin`.  The caller
+ * calibrates the margin: SCULPT_FILTER_MARK_ALL marks every point (margin and level unused), so that stats[1] is the largest
+ * coarse error over the lattice; at run time stats[1] is the largest coarse error over the re-evaluated points within 2 margins
+ * of the level (the guard).  flags must contain SCULPT_DENSITY_BF16L3; n_hidden_64 >= 1; R <= 1024.
  * filter_workspace: sculpt_density_filter_workspace_bytes(R, x_end - x_begin) bytes; its first 8 words are the statistics
  *   [0] points re-evaluated  [1] float bits of the largest coarse error seen (see above)  [2] points marked in pass A
- *   [3] non-finite coarse values (all marked)  [4] possibly active cells  [5] lattice points  [6..7] reserved
+ *   [3] non-finite coarse values (all marked)  [4] active cells  [5] lattice points  [6] list entries of pass B  [7] of pass C
  * valid once the stream has passed this call (sculpt_density_filter_stats copies them to the host and waits). */
 #define SCULPT_FILTER_COARSE_FP16 8u
 #define SCULPT_FILTER_MARK_ALL 16u

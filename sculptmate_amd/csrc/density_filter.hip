@@ -12,18 +12,21 @@
 //                                    accumulate: 8 instead of 48 MFMAs per layer and 32 points, no limb split).  Writes the coarse
 //                                    value exp(d~ + bias) + out_add, and per 32 points along z one word of SIGN bits (value > 0)
 //                                    and one word of MARK bits: |d~ + bias - log(level)| < margin, or not finite.
-//   pass B  filter_*_kernel          bit arithmetic on those 2 x R^3/8 bytes: a cell is POSSIBLY ACTIVE when the coarse signs of
-//                                    its 8 corners differ or a corner is marked; a point is REFINED when it is a corner of a possibly
-//                                    active cell (which includes every marked point), and goes into a packed point list.
-//   pass C  density_list_l3k_kernel  the exact three-limb arithmetic of density_grid_l3k_kernel (the same device function, so the
-//                                    same bits: a point's value depends on its own MFMA column only) on the listed points,
-//                                    scattered over the coarse values.
+//   pass B  filter_points<0> +       the MARKED points (list of them, then the exact three-limb arithmetic of
+//           density_list_l3k_kernel  density_grid_l3k_kernel -- the same device function, so the same bits: a point's value depends
+//                                    on its own MFMA column only); a sign that comes out different is corrected in the sign plane.
+//                                    After this pass the sign of EVERY lattice point is certain.
+//   pass C  filter_cells +           bit arithmetic on the sign planes: the points whose VALUE marching cubes reads -- the end
+//           filter_points<1> +       points of the lattice edges whose signs differ, and all corners of the cells whose sign
+//           density_list_l3k_kernel  pattern is one of the 128 ambiguous ones (face / interior tests, centre vertex): see
+//                                    filter_cells_kernel -- minus the marked points; list, exact arithmetic, scatter.
 //
-// If no coarse error |d~ - d| reaches the margin, every truly active cell is possibly active (a corner whose coarse sign is wrong
-// lies within the margin, hence is marked), so all corners of every active cell and the sign of every lattice point equal the
-// full evaluation's, and the mesh is bit-identical to it.  The margin is calibrated by the caller (8 x the largest coarse error
-// measured with SCULPT_FILTER_MARK_ALL on a probe lattice of the same scene code) and guarded at run time: pass C knows both
-// values at every refined point near the level and records the largest |d~ - d| it sees (FilterHeader::max_err).
+// If no coarse error |d~ - d| reaches the margin, a point whose coarse sign is wrong lies within the margin, hence is marked, hence
+// re-evaluated in pass B: every sign is then the full evaluation's, pass C lists exactly the values marching cubes reads for those
+// signs, and every one of them carries the full evaluation's bits -- the mesh is bit-identical to it.  The margin is calibrated by
+// the caller (8 x the largest coarse error measured with SCULPT_FILTER_MARK_ALL on a probe lattice of the same scene code) and
+// guarded at run time: the list kernel knows both values at every re-evaluated point near the level and records the largest
+// |d~ - d| it sees (FilterHeader::max_err).
 #include <math.h>
 #include <stdlib.h>
 
@@ -35,13 +38,15 @@
 namespace sculpt {
 
 struct FilterHeader {        // first 64 bytes of the filter workspace; zeroed by every call
-    int32_t n_refined;       // points re-evaluated exactly (pass C)
+    int32_t n_refined;       // points re-evaluated exactly (passes B + C)
     uint32_t max_err_bits;   // bits of max |log coarse - log exact| over the refined points within 2 margins of the level
     int32_t n_marked;        // points within the margin of the level in pass A, non-finite ones included
     int32_t n_nonfinite;     // non-finite coarse values (all marked, all re-evaluated)
-    int32_t n_cells;         // possibly active cells
+    int32_t n_cells;         // active cells (corner signs differ) once every sign is certain
     int32_t n_points;        // nx * R * R
-    int32_t pad[10];
+    int32_t n_first;         // list entries of pass B: the marked points
+    int32_t n_second;        // list entries of pass C: the values marching cubes reads, marked points excluded
+    int32_t pad[8];
 };
 static_assert(sizeof(FilterHeader) == 64, "header is 16 words");
 
@@ -272,14 +277,27 @@ __global__ __launch_bounds__(1024) void density_coarse_kernel(
 // ---------------------------------------------------------------------------------------------
 // pass B: possibly active cells, refined points, packed list (bit arithmetic on the sign / mark words)
 // ---------------------------------------------------------------------------------------------
-// cell (x, y, z) has corners (x..x+1, y..y+1, z..z+1); one thread per word of 32 cells along z
-__global__ __launch_bounds__(1024) void filter_cells_kernel(const uint32_t *__restrict__ sign, const uint32_t *__restrict__ mark,
-                                                            int R, int nx, uint32_t *__restrict__ cell, FilterHeader *__restrict__ hdr) {
+// Which corner VALUES does marching cubes read?  (skimage's Lewiner implementation, oracle/mc_lewiner.c, csrc/mc.hip::classify)
+//   * the case of a cell comes from the 8 corner SIGNS alone;
+//   * cases 1, 2, 5, 8, 9, 11, 14 pick their tiling from the sign pattern, and every Lewiner tiling places its vertices on the
+//     sign-changing edges of the cell: the only values read are the two END POINTS of each sign-changing lattice edge;
+//   * cases 3, 4, 6, 7, 10, 12, 13 (128 of the 256 sign patterns) run face / interior tests on the corner values and may add the
+//     centre vertex (a weighted mean of all 8): ALL 8 corners.  Those patterns are exactly the ones with a "checkerboard" face
+//     (diagonal corners equal, neighbours different) or with exactly two minority corners at opposite ends of a space diagonal --
+//     checked against the case table for all 256 patterns (tests/test_oracle_mc.py).
+// So, once every sign is certain (pass B), a lattice point needs the exact value iff it is an end point of a lattice edge whose
+// signs differ or a corner of a cell whose sign pattern is one of the 128 ambiguous ones: 6.2 % of the lattice on the bench field,
+// where all corners of all possibly active cells (the first version's rule) were 16.7 %.
+//
+// cell (x, y, z) has corners (x..x+1, y..y+1, z..z+1); one thread per word of 32 cells along z.  Runs when every sign is certain
+// (after pass B).  Output: the cells ALL of whose corners are read (an ambiguous sign pattern).
+__global__ __launch_bounds__(1024) void filter_cells_kernel(const uint32_t *__restrict__ sign, int R, int nx,
+                                                            uint32_t *__restrict__ cell, FilterHeader *__restrict__ hdr) {
     __shared__ int wsum[16];
     const int nw = (R + 31) / 32;
     const long words = (long)nx * R * nw;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = 0;
+    uint32_t c = 0, active = 0;
     if (i < words) {
         const int w = (int)(i % nw);
         const long row = i / nw;
@@ -288,20 +306,31 @@ __global__ __launch_bounds__(1024) void filter_cells_kernel(const uint32_t *__re
             const long r00 = row * nw, r01 = (row + 1) * nw, r10 = (row + R) * nw, r11 = (row + R + 1) * nw;
             const bool hi = w + 1 < nw;
             auto w64 = [&](const uint32_t *a, long r) { return (uint64_t)a[r + w] | (hi ? (uint64_t)a[r + w + 1] << 32 : 0); };
-            const uint64_t s00 = w64(sign, r00), s01 = w64(sign, r01), s10 = w64(sign, r10), s11 = w64(sign, r11);
-            const uint64_t A = s00 & s01 & s10 & s11, O = s00 | s01 | s10 | s11;
-            const uint64_t M = w64(mark, r00) | w64(mark, r01) | w64(mark, r10) | w64(mark, r11);
+            // corner planes c[dx][dy][dz]: bit z = sign of lattice point (x + dx, y + dy, z + dz)
+            const uint64_t c000 = w64(sign, r00), c010 = w64(sign, r01), c100 = w64(sign, r10), c110 = w64(sign, r11);
+            const uint64_t c001 = c000 >> 1, c011 = c010 >> 1, c101 = c100 >> 1, c111 = c110 >> 1;
+            const uint64_t A = c000 & c010 & c100 & c110, O = c000 | c010 | c100 | c110;
             const uint64_t same = (A & (A >> 1)) | (~O & ~(O >> 1));   // bit z: the 8 corners (z, z + 1) agree
-            const uint64_t poss = ~same | M | (M >> 1);
+            // a face (a, b, d, e in cyclic order) is a checkerboard: a == d, b == e, a != b
+            auto chk = [](uint64_t a, uint64_t b, uint64_t d, uint64_t e) { return ~(a ^ d) & ~(b ^ e) & (a ^ b); };
+            uint64_t amb = chk(c000, c010, c011, c001) | chk(c100, c110, c111, c101) | chk(c000, c100, c101, c001) |
+                           chk(c010, c110, c111, c011) | chk(c000, c100, c110, c010) | chk(c001, c101, c111, c011);
+            // exactly two minority corners at the ends of a space diagonal (case 4): p, q of one sign, the other six of the other
+            auto diag = [](uint64_t p, uint64_t q, uint64_t o1, uint64_t o2, uint64_t o3, uint64_t o4, uint64_t o5, uint64_t o6) {
+                return (p & q & ~(o1 | o2 | o3 | o4 | o5 | o6)) | (~p & ~q & (o1 & o2 & o3 & o4 & o5 & o6));
+            };
+            amb |= diag(c000, c111, c001, c010, c011, c100, c101, c110) | diag(c001, c110, c000, c010, c011, c100, c101, c111) |
+                   diag(c010, c101, c000, c001, c011, c100, c110, c111) | diag(c011, c100, c000, c001, c010, c101, c110, c111);
             // cells exist for z <= R - 2
             const int zmax = R - 2 - 32 * w;                            // last valid bit of this word
             const uint32_t valid = zmax >= 31 ? 0xffffffffu : (zmax < 0 ? 0u : ((2u << zmax) - 1u));
-            c = (uint32_t)poss & valid;
+            c = (uint32_t)amb & valid;
+            active = (uint32_t)~same & valid;
         }
         cell[i] = c;
     }
-    // possibly active cells, for the statistics: one atomic per workgroup
-    int tot = __popc(c);
+    // active cells, for the statistics: one atomic per workgroup
+    int tot = __popc(active);
 #pragma unroll
     for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
@@ -310,14 +339,18 @@ __global__ __launch_bounds__(1024) void filter_cells_kernel(const uint32_t *__re
         int t = 0;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += wsum[k];
         if (t) atomicAdd(&hdr->n_cells, t);
-        if (blockIdx.x == 0) hdr->n_points = nx * R * R;
     }
 }
 
-// point (x, y, z) is a corner of the cells (x-1..x, y-1..y, z-1..z); one thread per word of 32 points along z.  A workgroup
-// reserves one contiguous range of the list for its points (one atomic): the list is ordered inside a workgroup's 1024 words and
-// unordered between workgroups -- the order of the list is irrelevant to the values pass C writes.
-__global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__restrict__ cell, int R, int nx,
+// One thread per word of 32 points along z; a workgroup reserves one contiguous range of the list for its points (one atomic):
+// the list is ordered inside a workgroup's 1024 words and unordered between workgroups -- its order is irrelevant to the values.
+//   STAGE 0 (pass B): the MARKED points -> list[0 .. n_first).
+//   STAGE 1 (pass C): the points whose value marching cubes reads -- point (x, y, z) is a corner of the cells (x-1..x, y-1..y,
+//           z-1..z): all corners of an ambiguous cell; and an end point of the six lattice edges to its neighbours: the edges
+//           whose signs differ -- minus the marked ones (exact already) -> list[n_first .. n_first + n_second).
+template <int STAGE>
+__global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__restrict__ cell, const uint32_t *__restrict__ sign,
+                                                             const uint32_t *__restrict__ mark, int R, int nx,
                                                              uint32_t *__restrict__ list, FilterHeader *__restrict__ hdr) {
     __shared__ int wsum[16];
     __shared__ int base_s;
@@ -330,19 +363,37 @@ __global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__r
         const int w = (int)(i % nw);
         const long row = i / nw;
         const int y = (int)(row % R), x = (int)(row / R);
-        uint32_t c = 0, prev = 0;
+        const int zrem = R - 32 * w;                                  // points exist for z < R
+        const uint32_t pvalid = zrem < 32 ? (1u << zrem) - 1u : 0xffffffffu;
+        if (STAGE == 0) {
+            r = mark[i] & pvalid;
+        } else {
+            // all corners of the ambiguous cells
+            uint32_t c = 0, prev = 0;
 #pragma unroll
-        for (int dx = -1; dx <= 0; ++dx)
+            for (int dx = -1; dx <= 0; ++dx)
 #pragma unroll
-            for (int dy = -1; dy <= 0; ++dy)
-                if (x + dx >= 0 && y + dy >= 0) {
-                    const long q = (row + (long)dx * R + dy) * nw + w;
-                    c |= cell[q];
-                    if (w) prev |= cell[q - 1];
-                }
-        r = c | (c << 1) | (prev >> 31);
-        const int zrem = R - 32 * w;  // points exist for z < R
-        if (zrem < 32) r &= (1u << zrem) - 1u;
+                for (int dy = -1; dy <= 0; ++dy)
+                    if (x + dx >= 0 && y + dy >= 0) {
+                        const long q = (row + (long)dx * R + dy) * nw + w;
+                        c |= cell[q];
+                        if (w) prev |= cell[q - 1];
+                    }
+            r = c | (c << 1) | (prev >> 31);
+            // end points of the lattice edges whose signs differ
+            const uint32_t S = sign[i];
+            const uint32_t next0 = (w + 1 < nw) ? (sign[i + 1] & 1u) : 0u;
+            uint32_t dz = S ^ ((S >> 1) | (next0 << 31));             // bit z: the edge (z, z + 1) changes sign ...
+            const int ez = zrem - 1;                                  // ... where z + 1 < R: ez valid bits
+            dz &= ez >= 32 ? 0xffffffffu : (ez <= 0 ? 0u : ((1u << ez) - 1u));
+            uint32_t e = dz | (dz << 1);
+            if (w) e |= ((sign[i - 1] >> 31) ^ S) & 1u;               // the edge (32 w - 1, 32 w) of the previous word
+            if (y + 1 < R) e |= S ^ sign[i + nw];
+            if (y > 0) e |= S ^ sign[i - nw];
+            if (x + 1 < nx) e |= S ^ sign[i + (long)R * nw];
+            if (x > 0) e |= S ^ sign[i - (long)R * nw];
+            r = (r | e) & ~mark[i] & pvalid;
+        }
         entry = ((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)(32 * w);
     }
     const int n = __popc(r);
@@ -357,7 +408,9 @@ __global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__r
     if (threadIdx.x == 0) {
         int t = 0;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { const int v = wsum[k]; wsum[k] = t; t += v; }
-        base_s = t ? atomicAdd(&hdr->n_refined, t) : 0;
+        // (stage 1 starts behind stage 0's entries: n_first is final, pass B's list kernel has run)
+        base_s = (t ? atomicAdd(STAGE == 0 ? &hdr->n_first : &hdr->n_second, t) : 0) + (STAGE == 0 ? 0 : hdr->n_first);
+        if (STAGE == 0 && blockIdx.x == 0) hdr->n_points = nx * R * R;
     }
     __syncthreads();
     int o = base_s + wsum[wv] + incl - n;
@@ -375,11 +428,17 @@ template <int NT>
 __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
     const float *__restrict__ FC, int R, float density_bias, float out_add, float level_log, float guard_band,
-    const uint32_t *__restrict__ list, FilterHeader *__restrict__ hdr, float *__restrict__ out) {
+    const uint32_t *__restrict__ list_all, FilterHeader *__restrict__ hdr, float *__restrict__ out, int stage,
+    uint32_t *__restrict__ signbits) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
-    const int n = hdr->n_refined;
+    // stage 0 (pass B): the marked points, whose coarse sign may be wrong -- a sign that comes out different is corrected in the
+    // sign plane (rare: one atomic per such point), so that every sign is certain when pass C's bit kernels read the planes;
+    // stage 1 (pass C): the second part of the list
+    const int n = stage ? hdr->n_second : hdr->n_first;
+    const uint32_t *list = list_all + (stage ? hdr->n_first : 0);
+    if (stage && blockIdx.x == 0 && threadIdx.x == 0) hdr->n_refined = hdr->n_first + hdr->n_second;
     if (n <= 0) return;
     l3_load_lds(smem, blob, hd);
     const LdsView L = lds_view(smem, NH);
@@ -421,12 +480,17 @@ __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
         if (h == 0 && valid) {
             const long idx = ((long)ixl * R + iy) * R + iz;
             const float dl = d + density_bias;
+            const float coarse = out[idx], exact = exp_f(dl) + out_add;
             if (fabsf(dl - level_log) < guard_band) {
                 // the coarse value was exp(d~ + bias) + out_add: near the level the subtraction below is exact to an ulp of the level
-                const float err = fabsf(__logf(out[idx] - out_add) - dl);
+                const float err = fabsf(__logf(coarse - out_add) - dl);
                 if (err < INFINITY) worst = fmaxf(worst, err);
             }
-            out[idx] = exp_f(dl) + out_add;
+            out[idx] = exact;
+            if ((coarse > 0.0f) != (exact > 0.0f)) {
+                const int nzb = (R + 31) / 32;
+                atomicXor(&signbits[((long)ixl * R + iy) * nzb + (iz >> 5)], 1u << (iz & 31));
+            }
         }
     }
 #pragma unroll
@@ -483,19 +547,26 @@ int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R,
                            margin, mark_all ? 1 : 0, out, v.sign, v.mark, v.hd);
         SC_LAUNCH_CHECK();
     }
-    if (passes & SCULPT_FILTER_PASS_B) {
-        const long rows = (long)nx * R, words = rows * ((R + 31) / 32);
-        hipLaunchKernelGGL(filter_cells_kernel, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.sign, v.mark, R, nx, v.cell, v.hd);
-        hipLaunchKernelGGL(filter_points_kernel, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.cell, R, nx, v.list, v.hd);
-        SC_LAUNCH_CHECK();
-    }
-    if (passes & SCULPT_FILTER_PASS_C) {
+    auto list_pass = [&](int stage) -> int {
         auto kern = density_list_l3k_kernel<1024>;
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_x, st, blob, FA, FB, FC, R, density_bias, out_add, level_log,
-                           mark_all ? INFINITY : 2.0f * margin, v.list, v.hd, out);
+                           mark_all ? INFINITY : 2.0f * margin, v.list, v.hd, out, stage, v.sign);
         SC_LAUNCH_CHECK();
+        return 0;
+    };
+    const long rows = (long)nx * R, words = rows * ((R + 31) / 32);
+    if (passes & SCULPT_FILTER_PASS_B) {   // the marked points: exact values, and with them a certain sign everywhere
+        hipLaunchKernelGGL(filter_points_kernel<0>, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.cell, v.sign, v.mark, R, nx, v.list, v.hd);
+        SC_LAUNCH_CHECK();
+        if (int rc = list_pass(0)) return rc;
+    }
+    if (passes & SCULPT_FILTER_PASS_C) {   // the values marching cubes reads
+        hipLaunchKernelGGL(filter_cells_kernel, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.sign, R, nx, v.cell, v.hd);
+        hipLaunchKernelGGL(filter_points_kernel<1>, dim3(cdiv(words, 1024)), dim3(1024), 0, st, v.cell, v.sign, v.mark, R, nx, v.list, v.hd);
+        SC_LAUNCH_CHECK();
+        if (int rc = list_pass(1)) return rc;
     }
     return 0;
 }

@@ -173,11 +173,12 @@ def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begi
 
 def density_grid_filtered(planes, mlp, resolution, margin, radius=0.87, density_bias=-1.0, x_begin=0, x_end=None, out=None,
                           out_add=0.0, events=None, coarse="fp16", mark_all=False, stats_host=None, passes="ABC", tables=True):
-    """density_grid(precision="bf16l3") for marching cubes in two passes (sculpt_density_grid_filtered): every lattice point with
-    one 16-bit product per hidden layer (`coarse`: "fp16" or "bf16"), then the exact three-limb arithmetic at the corners of every
-    cell whose coarse corner signs differ or that has a corner within `margin` (natural-log units of density_act) of the level
-    -out_add.  Returns (volume, stats): the volume holds the bits of the full evaluation at those corners and a value of the
-    right sign elsewhere as long as no coarse error reaches the margin; stats = device int32[8] view of the call's statistics
+    """density_grid(precision="bf16l3") for marching cubes, filtered (sculpt_density_grid_filtered): every lattice point with one
+    16-bit product per hidden layer (`coarse`: "fp16" or "bf16"; pass A), then the exact three-limb arithmetic at the points
+    within `margin` (natural-log units of density_act) of the level -out_add (pass B: every sign certain) and at the values
+    marching cubes reads -- end points of sign-changing lattice edges, all corners of ambiguous cells (pass C).  Returns (volume,
+    stats): the volume holds the bits of the full evaluation wherever marching cubes reads a value and a value of the right sign
+    elsewhere as long as no coarse error reaches the margin; stats = device int32[8] view of the call's statistics
     (include/sculpt_hip.h), valid once the stream has passed the call -- stats_host (a pinned int32[8] tensor) receives an
     asynchronous copy.  mark_all=True re-evaluates every point and stats[1] is the largest coarse error (calibration).
     passes / tables: timing aids -- run only the named passes ("A", "B", "C" one after the other on the same workspace give what
@@ -216,7 +217,7 @@ def filter_stats(stats):
     """int32[8] statistics of density_grid_filtered (host or device tensor; a device tensor is read back here) -> dict."""
     s = stats.cpu().numpy() if isinstance(stats, torch.Tensor) else np.asarray(stats)
     return {"n_refined": int(s[0]), "max_err": float(s[1:2].view(np.float32)[0]), "n_marked": int(s[2]),
-            "n_nonfinite": int(s[3]), "n_cells": int(s[4]), "n_points": int(s[5])}
+            "n_nonfinite": int(s[3]), "n_cells": int(s[4]), "n_points": int(s[5]), "n_first": int(s[6]), "n_second": int(s[7])}
 
 
 _axis_cache = {}

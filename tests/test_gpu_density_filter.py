@@ -34,33 +34,20 @@ def _margin(tri, mlp, coarse, probe=32):
     return max(8.0 * s["max_err"], 1e-3), s["max_err"]
 
 
-def _corners_of_active_cells(full, R, nx=None):
-    """bool [nx*R*R]: lattice points that are a corner of a cell whose 8 corner signs (value > 0) differ."""
+def _needed(full, R, nx=None):
+    """bool [nx*R*R]: lattice points whose VALUE marching cubes reads in `full` (tests/_mcneeds.py), and the active-cell count."""
+    from _mcneeds import needed_points
+
     nx = R if nx is None else nx
-    f3 = (full.view(nx, R, R) > 0)
-    sl = lambda d, n: slice(d, n - 1 + d)  # noqa: E731
-    alls = torch.ones((nx - 1, R - 1, R - 1), dtype=torch.bool, device=full.device)
-    anys = torch.zeros_like(alls)
-    for dx in (0, 1):
-        for dy in (0, 1):
-            for dz in (0, 1):
-                c = f3[sl(dx, nx), sl(dy, R), sl(dz, R)]
-                alls &= c
-                anys |= c
-    active = anys & ~alls
-    need = torch.zeros((nx, R, R), dtype=torch.bool, device=full.device)
-    for dx in (0, 1):
-        for dy in (0, 1):
-            for dz in (0, 1):
-                need[sl(dx, nx), sl(dy, R), sl(dz, R)] |= active
-    return need.view(-1), int(active.sum())
+    need, n_active = needed_points(full.view(nx, R, R) > 0)
+    return need.view(-1), n_active
 
 
 def _assert_same_for_marching_cubes(vol, full, R, nx=None):
     assert int(((vol > 0) != (full > 0)).sum()) == 0, "a lattice point changed its side of the level"
-    need, n_active = _corners_of_active_cells(full, R, nx)
+    need, n_active = _needed(full, R, nx)
     assert n_active > 0
-    assert torch.equal(vol.view(torch.int32)[need], full.view(torch.int32)[need]), "a corner of an active cell carries other bits"
+    assert torch.equal(vol.view(torch.int32)[need], full.view(torch.int32)[need]), "a value marching cubes reads carries other bits"
     return need
 
 
@@ -81,7 +68,7 @@ def test_filtered_grid_gives_marching_cubes_the_full_evaluations_bits(cuda, R, c
     s = ops.filter_stats(st)
     need = _assert_same_for_marching_cubes(vol, full, R)
     assert s["n_points"] == R ** 3 and int(need.sum()) <= s["n_refined"] < R ** 3
-    assert s["n_marked"] <= s["n_refined"] and s["n_nonfinite"] == 0
+    assert s["n_marked"] == s["n_first"] <= s["n_refined"] == s["n_first"] + s["n_second"] and s["n_nonfinite"] == 0
     assert s["max_err"] <= margin / 3.0, (s, margin)   # the run-time guard TSR applies
     assert _same_mesh(ops.marching_cubes(vol.view(R, R, R), 0.0), ops.marching_cubes(full.view(R, R, R), 0.0))
 
@@ -98,7 +85,7 @@ def test_mark_all_reproduces_the_full_volume_bit_for_bit(cuda, R):
     coarse_only = coarse_only.clone()
     vol, st = ops.density_grid_filtered(tri, mlp, R, 0.0, coarse="fp16", mark_all=True)
     s = ops.filter_stats(st)
-    assert s["n_refined"] == R ** 3 == s["n_marked"]
+    assert s["n_refined"] == R ** 3 == s["n_marked"] == s["n_first"] and s["n_second"] == 0
     assert torch.equal(vol.view(torch.int32), full.view(torch.int32))
     err = (torch.log(coarse_only.double()) - torch.log(full.double())).abs().max().item()
     assert abs(err - s["max_err"]) <= 1e-5 + 1e-3 * err, (err, s)
@@ -106,21 +93,22 @@ def test_mark_all_reproduces_the_full_volume_bit_for_bit(cuda, R):
 
 
 def test_refined_set_from_signs_alone_matches_a_host_restatement(cuda):
-    """Pass B with a margin that marks nothing: the refined points are exactly the corners of the cells whose COARSE signs
-    differ -- counted here on the host from the coarse volume of pass A (cells, points), equal to the statistics."""
+    """Pass B with a margin that marks nothing: the refined points are exactly the values marching cubes reads in the COARSE
+    volume of pass A -- end points of its sign-changing lattice edges and all corners of its cells with an ambiguous sign pattern
+    (tests/_mcneeds.py, from the case table) -- counted here on the host, equal to the statistics; the possibly active cells are
+    the cells whose coarse corner signs differ."""
     from sculptmate_amd import ops
 
     R = 48
     tri, mlp, _, _ = _field(cuda, 25, inside=0.15)
     coarse, _ = ops.density_grid_filtered(tri, mlp, R, 1e-30, out_add=-THR, coarse="bf16", passes="A")
     coarse = coarse.clone()
-    _, st = ops.density_grid_filtered(tri, mlp, R, 1e-30, out_add=-THR, coarse="bf16", passes="AB")
-    s = ops.filter_stats(st)
-    need, n_active = _corners_of_active_cells(coarse, R)
-    assert s["n_marked"] == 0 and s["n_cells"] == n_active and s["n_refined"] == int(need.sum())
-    # ... and pass C then rewrites exactly those points
     full = ops.density_grid(tri, mlp, R, out_add=-THR, precision="bf16l3").clone()
-    vol, _ = ops.density_grid_filtered(tri, mlp, R, 1e-30, out_add=-THR, coarse="bf16")
+    vol, st = ops.density_grid_filtered(tri, mlp, R, 1e-30, out_add=-THR, coarse="bf16")
+    s = ops.filter_stats(st)
+    need, n_active = _needed(coarse, R)
+    assert s["n_marked"] == 0 == s["n_first"] and s["n_cells"] == n_active and s["n_refined"] == s["n_second"] == int(need.sum())
+    # ... and pass C rewrote exactly those points
     assert torch.equal(vol.view(torch.int32)[need], full.view(torch.int32)[need])
     assert torch.equal(vol.view(torch.int32)[~need], coarse.view(torch.int32)[~need])
 

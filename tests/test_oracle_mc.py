@@ -129,3 +129,25 @@ def test_live_fuzz_against_skimage(tmp_path):
         v, f = capi.marching_cubes(vol, 0.0)
         assert np.array_equal(f, o[k + "_f"]), k
         assert np.array_equal(v.view(np.uint32), o[k + "_v"].astype(np.float32).view(np.uint32)), k
+
+
+def test_ambiguous_sign_patterns_are_the_checkerboard_and_diagonal_ones():
+    """The two-pass density grid (csrc/density_filter.hip::filter_cells_kernel) decides with bit logic which cells have all 8 corner
+    values read by marching cubes: a face whose diagonal corners agree and whose neighbours differ, or exactly two minority corners
+    at the ends of a space diagonal.  Against the case table for all 256 sign patterns: exactly the patterns of cases 3, 4, 6, 7,
+    10, 12, 13 -- the ones whose classification runs face / interior tests (oracle/mc_lewiner.c)."""
+    from _mcneeds import CORNERS, ambiguous_patterns
+
+    lut = ambiguous_patterns()
+    assert int(lut.sum()) == 128
+    bit = lambda idx, c: (idx >> CORNERS.index(c)) & 1  # noqa: E731
+    faces = [[(0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 0, 1)], [(1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 0, 1)],
+             [(0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1)], [(0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1)],
+             [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)], [(0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]]
+    diagonals = [((0, 0, 0), (1, 1, 1)), ((0, 0, 1), (1, 1, 0)), ((0, 1, 0), (1, 0, 1)), ((0, 1, 1), (1, 0, 0))]
+    for idx in range(256):
+        g = any(bit(idx, a) == bit(idx, d) and bit(idx, b) == bit(idx, e) and bit(idx, a) != bit(idx, b) for a, b, d, e in faces)
+        ones = bin(idx).count("1")
+        g = g or any(ones == (2 if s else 6) and bit(idx, p) == s and bit(idx, q) == s for p, q in diagonals for s in (0, 1))
+        assert g == bool(lut[idx]), idx
+

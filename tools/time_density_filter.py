@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """The two-pass ("filtered") density grid against the full three-limb evaluation on one field (tools/time_density.py's, with the
 last bias calibrated so that ~1.5 % of the lattice is inside, like bench.py's): launch times by HIP events (interleaved rounds),
-coarse error (mark-all calibration at 64^3), refined fraction, and the identity checks -- refined points bit-equal to the full
-volume, no sign mismatch anywhere, marching-cubes output bit-equal.
+coarse error (mark-all calibration at 64^3), refined fraction, and the identity checks -- every value marching cubes reads bit-equal
+to the full volume, no sign mismatch anywhere, marching-cubes output bit-equal.
 
     python tools/time_density_filter.py [--R 256] [--rounds 5] [--inside 0.015] [--safety 8]
 """
@@ -55,28 +55,16 @@ def main():
               % (100.0 * s["n_refined"] / s["n_points"], s["n_points"], 100.0 * s["n_marked"] / s["n_points"],
                  100.0 * s["n_cells"] / s["n_points"], s["max_err"], s["max_err"] / margin))
         sign_mismatch = int(((vol > 0) != (full > 0)).sum())
-        # every corner of every truly active cell must carry the full evaluation's bits
-        f3 = (full.view(R, R, R) > 0)
-        a = f3[:-1, :-1, :-1]
-        alls = torch.ones_like(a)
-        anys = torch.zeros_like(a)
-        for dx in (0, 1):
-            for dy in (0, 1):
-                for dz in (0, 1):
-                    c = f3[dx:R - 1 + dx, dy:R - 1 + dy, dz:R - 1 + dz]
-                    alls &= c
-                    anys |= c
-        active = anys & ~alls
-        need = torch.zeros((R, R, R), dtype=torch.bool, device=dev)
-        for dx in (0, 1):
-            for dy in (0, 1):
-                for dz in (0, 1):
-                    need[dx:R - 1 + dx, dy:R - 1 + dy, dz:R - 1 + dz] |= active
-        need = need.view(-1)
+        # every value marching cubes READS in the full volume (end points of sign-changing edges, all corners of cells with an
+        # ambiguous sign pattern: tests/_mcneeds.py) must carry the full evaluation's bits
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _mcneeds import needed_points
+
+        need3, n_active = needed_points(full.view(R, R, R) > 0, luts=os.path.join(ROOT, "sculptmate_amd", "csrc", "mc_luts.h"))
+        need = need3.view(-1)
         diff_at_need = int((vol.view(torch.int32)[need] != full.view(torch.int32)[need]).sum())
-        print("   sign mismatches vs full %d; active cells %d (%.2f %%), their corners %d (%.2f %%), corners with other bits %d"
-              % (sign_mismatch, int(active.sum()), 100.0 * float(active.float().mean()), int(need.sum()),
-                 100.0 * float(need.float().mean()), diff_at_need))
+        print("   sign mismatches vs full %d; active cells %d (%.2f %%), values marching cubes reads %d (%.2f %% of the lattice), of them with other bits %d"
+              % (sign_mismatch, n_active, 100.0 * n_active / (R - 1) ** 3, int(need.sum()), 100.0 * float(need.float().mean()), diff_at_need))
         v1, f1 = ops.marching_cubes(full.view(R, R, R), 0.0)
         v2, f2 = ops.marching_cubes(vol.view(R, R, R), 0.0)
         same = v1.shape == v2.shape and f1.shape == f2.shape and bool((v1.view(torch.int32) == v2.view(torch.int32)).all()) and bool((f1 == f2).all())
