@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024) void density_coarse_kernel(
 // ---------------------------------------------------------------------------------------------
 // pass B: possibly active cells, refined points, packed list (bit arithmetic on the sign / mark words)
 // ---------------------------------------------------------------------------------------------
-// Which corner VALUES does marching cubes read?  (skimage's Lewiner implementation, oracle/mc_lewiner.c, csrc/mc.hip::classify)
+// Which corner VALUES does marching cubes read?  (skimage's Lewiner implementation as restated in csrc/mc.hip::classify)
 //   * the case of a cell comes from the 8 corner SIGNS alone;
 //   * cases 1, 2, 5, 8, 9, 11, 14 pick their tiling from the sign pattern, and every Lewiner tiling places its vertices on the
 //     sign-changing edges of the cell: the only values read are the two END POINTS of each sign-changing lattice edge;
