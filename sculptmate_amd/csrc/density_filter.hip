@@ -1,12 +1,13 @@
-// Two-pass ("filtered") dense density grid for gfx950 (MI355X): sculpt_density_grid_filtered.
+// Filtered dense density grid for gfx950 (MI355X): sculpt_density_grid_filtered.
 //
 // Replaces, like csrc/triplane.hip (reference file:line):
 //   dense query over MarchingCubeHelper.grid_vertices     TripoSR/tsr/system.py:171-184
 //   TriplaneNeRFRenderer.query_triplane + NeRFMLP.forward  TripoSR/tsr/models/nerf_renderer.py:41-91, network_utils.py:116-124
 // for the one consumer the dense grid has, MarchingCubeHelper.forward (TripoSR/tsr/models/isosurface.py:41-54): marching cubes
-// reads the MAGNITUDE of the volume only at the corners of active cells (vertex interpolation, Lewiner's face / interior tests)
-// and the SIGN everywhere else.  The fp32-equivalent three-limb evaluation (six bf16 products per hidden layer, triplane.hip) is
-// therefore needed at a few per cent of the lattice points; everywhere else a sign that is certainly right is enough.
+// reads the MAGNITUDE of the volume only at the end points of sign-changing lattice edges (vertex interpolation) and at all
+// corners of the cells whose sign pattern is ambiguous (Lewiner's face / interior tests, centre vertex), and the SIGN everywhere
+// else.  The fp32-equivalent three-limb evaluation (six bf16 products per hidden layer, triplane.hip) is therefore needed at a
+// few per cent of the lattice points; everywhere else a sign that is certainly right is enough.
 //
 //   pass A  density_coarse_kernel    every lattice point with ONE 16-bit product per hidden layer (fp16 or bf16 operands, fp32
 //                                    accumulate: 8 instead of 48 MFMAs per layer and 32 points, no limb split).  Writes the coarse
