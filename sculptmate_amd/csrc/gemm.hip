@@ -120,9 +120,17 @@ static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 til
 // NW: waves per workgroup.  4 = 2x2 waves of 64 activation x BW/2 weight rows; 8 = 2 (weight) x 4 (activation)
 // waves of 32 x BW/2: twice the waves per SIMD to hide LDS / barrier latency, at 1.5x the LDS bytes per MFMA.
 // NWR: waves along the weight rows (2, or 4 for the 96 x 128 one-round tile: 4 x 2 waves of 32 weight x 48 activation rows).
-template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT, int NWR = 2>
+// KS: the two waves (wr = 0, 1) that share a band of activation rows split the K-tile between them instead of the weight rows --
+// wave (wr, wc) multiplies k-step wr of every K-tile into ALL BW weight rows x its activation rows (2 TI x TJ accumulator tiles,
+// TI + ... fragments: (2 TI + TJ) reads per 2 TI TJ MFMAs where the weight-row split reads 2 (TI + TJ)), and after the K loop the
+// pair exchanges halves through the (free) LDS ring, so that every wave ends with the sums of its usual TI x TJ tiles and the
+// epilogue is unchanged.  Same MFMAs, 30 % fewer LDS fragment bytes (192 x 64 tile: 7 instead of 10 reads per K-tile and wave):
+// these K loops are bound by LDS read bandwidth.  The sum is (even k-steps) + (odd k-steps): not the
+// k order of the other tile forms, i.e. equal to them to fp32 rounding, not bit for bit.
+template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT, int NWR = 2, bool KS = false>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     static_assert(NWR == 2 || (EPI == SCULPT_EPI_NONE && !CONV), "the 4 x 2 wave grid is for the plain / residual / LayerNorm-fold form");
+    static_assert(!KS || (NWR == 2 && NW == 8 && EPI == SCULPT_EPI_NONE && !CONV), "the k-split pairs are for the 8-wave plain form");
     constexpr int WT = BW * 128;  // bytes of a weight tile
     constexpr int AT = BM * 128;
     // LDS ring depth: 3 stages (two K-tiles in flight) for the 64-row tile, 2 for the 128-row tile --
@@ -241,6 +249,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2[KS ? 2 * TI : 1][KS ? TJ : 1];   // KS: partial sums of k-step wr over both weight halves
+    if (KS) {
+#pragma unroll
+        for (int i = 0; i < 2 * TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc2[KS ? i : 0][KS ? j : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int nk = g.K / BK;
     const int fr = lane & 15, fq = lane >> 4;
@@ -248,6 +263,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     int aoff[TI], boff[TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) aoff[i] = lds_off(wr * WPW + i * 16 + fr, fq);
+    int aoff2[KS ? 2 * TI : 1];   // KS: fragments of all BW weight rows, k-step wr (chunk bit 2 = the k-step: XOR 64 bytes)
+    if (KS) {
+#pragma unroll
+        for (int i = 0; i < 2 * TI; ++i) aoff2[KS ? i : 0] = lds_off((i / TI) * WPW + (i % TI) * 16 + fr, fq) ^ (wr << 6);
+    }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) boff[j] = lds_off(wc * (16 * TJ) + j * 16 + fr, fq);
 
@@ -296,7 +316,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         if (kt + DIST < nk) STAGE((kt + DIST) % NSTAGE, kt + DIST);
         const unsigned char *wb = smem + buf * (WT + AT);
         const unsigned char *ab = wb + WT;
-        if ((NW == 8 || (NW == 4 && BM == 96)) && SCULPT_GEMM_READ_AHEAD) {
+        if constexpr (KS) {
+            bf16x8_t af[2 * TI], bfr[TJ];
+#pragma unroll
+            for (int i = 0; i < 2 * TI; ++i) af[i] = *reinterpret_cast<const bf16x8_t *>(wb + aoff2[i]);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t *>(ab + (boff[j] ^ (wr << 6)));
+#pragma unroll
+            for (int i = 0; i < 2 * TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc2[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TI + TJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 2 * TI * TJ, 0);
+        } else if ((NW == 8 || (NW == 4 && BM == 96)) && SCULPT_GEMM_READ_AHEAD) {
             // both k-steps' fragments are requested before the first MFMA: one exposed LDS latency per K-tile instead of one
             // per group of four MFMAs (the register budget of the 8-wave tiles allows the 2 (TI + TJ) fragments)
             bf16x8_t af[2][TI], bfr[2][TJ];
@@ -334,6 +367,39 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         }
     }
 #undef STAGE
+    if constexpr (KS) {
+        // the pair (wr = 0, 1) of a band swaps halves: wave wr keeps the tiles of ITS weight rows (i2 = wr TI + i) and adds the
+        // partner's partial sums of them.  Exchange buffer = the LDS ring, free once every wave is past its last fragment read.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 *xb = reinterpret_cast<f32x4 *>(smem);
+        const int partner = (1 - wr) * NWC + wc;
+        static_assert(NW * TI * TJ * 64 * 16 <= NSTAGE * (WT + AT), "the exchange fits the ring");
+        if (wr == 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) xb[(wave * TI * TJ + i * TJ + j) * 64 + lane] = acc2[TI + i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) xb[(wave * TI * TJ + i * TJ + j) * 64 + lane] = acc2[i][j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = acc2[i][j] + xb[(partner * TI * TJ + i * TJ + j) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = xb[(partner * TI * TJ + i * TJ + j) * 64 + lane] + acc2[TI + i][j];
+        }
+    }
 
     float ln_mean[TJ], ln_rstd[TJ];
 #pragma unroll
@@ -1217,7 +1283,13 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8, false, 96, 4>), dim3(N / 128, M / 96), dim3(512), 0, st, g);
             } else if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
                 g.gm = 0;
-                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
+                // k-split pairs (see the kernel): FF2 + residual 41.6 -> 38.4 us, plain K = 4096 37.5 -> 33.9, K = 1024 -0.3 us
+                // (tools/gemm_bm192_ab.py); SCULPT_GEMM_KS=0: the weight-row split, bit-identical to the 128 x 64 tiles (A/B, tests)
+                const char *eks = getenv("SCULPT_GEMM_KS");
+                if (!(eks && atoi(eks) == 0))
+                    hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192, 2, true>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
+                else
+                    hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
             } else
             if (small && underfilled && bm64_env && (long)(N / 64) * cdiv(M, 64) <= 2L * num_cus())
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 64>), dim3(N / 64, cdiv(M, 64)), dim3(512), 0, st, g);

@@ -237,6 +237,8 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
     b = torch.randn(N, generator=g).to(cuda)
     h0 = (torch.randn(M, N, generator=g) + 2.0 * torch.randn(M, 1, generator=g)).to(cuda)
 
+    monkeypatch.setenv("SCULPT_GEMM_KS", "0")   # the 128-row side in its k order (the k-split pairs differ by fp32 rounding)
+
     def run(flag):
         monkeypatch.setenv("SCULPT_GEMM_RES256", flag)
         h = h0.clone()
@@ -260,7 +262,7 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
                                             (1536, 256, 2048, True), (960, 128, 1024, False)])
 def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, K, N, residual):
     """gemm_bf16_kernel<NONE, 64, 8, false, 192> and <NONE, 128, 8, false, 96, 4> (round 5: M = 3072, N = 1024 as ONE round of 256
-    tiles of 192 x 64 or 96 x 128) against the 128 x 64 tiles on the same operands: the same k order per output, so h, bf16(h), the slice statistics (residual form) or the
+    tiles of 192 x 64 or 96 x 128; SCULPT_GEMM_KS=0: the weight-row split) against the 128 x 64 tiles on the same operands: the same k order per output, so h, bf16(h), the slice statistics (residual form) or the
     LayerNorm-folded bf16 output are equal bit for bit, over repeated in-place launches."""
     from sculptmate_amd import ops
 
@@ -274,9 +276,10 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
     stats_in[..., 1] = 64.0 + torch.rand(K // 64, M, device=cuda)
     cs = W.float().sum(1).contiguous()
 
-    def run(bm192, bm96):
+    def run(bm192, bm96, ks="0"):
         monkeypatch.setenv("SCULPT_GEMM_BM192", bm192)
         monkeypatch.setenv("SCULPT_GEMM_BM96", bm96)
+        monkeypatch.setenv("SCULPT_GEMM_KS", ks)
         if residual:
             h = h0.clone()
             hb = torch.empty(M, N, dtype=BF, device=cuda)
@@ -292,9 +295,18 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
     for c in (run("1", "0"), run("0", "1")):   # 192 x 64 tiles; 96 x 128 tiles (4 x 2 waves, uneven staging, three-stage ring)
         for x, y in zip(a, c):
             assert torch.equal(x, y)
+    # the shipped form of the 192 x 64 tiles: the two waves of a band split the K-tile instead of the weight rows (30 % fewer LDS
+    # fragment bytes) -- the sum is (even k-steps) + (odd k-steps): equal to fp32 rounding, bf16 outputs to one rounding flip
+    c = run("1", "0", ks="1")
+    assert _rel(c[0].float(), a[0].float())[0] < (1e-6 if residual else 1e-3)   # fp32 h: rounding of two partial sums; bf16: flips
     if residual:
+        assert (c[1].float() - a[1].float()).abs().max() <= 2.0 ** -7 * a[1].float().abs().max()
+        assert _rel(c[2], a[2])[0] < 1e-5
         ref = h0.double().cpu() + 2 * (A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
-        assert _rel(a[0], ref.float())[0] < 1e-5
+        assert _rel(a[0], ref.float())[0] < 1e-5 and _rel(c[0], ref.float())[0] < 1e-5
+        for _ in range(2):   # and it is reproducible
+            c2 = run("1", "0", ks="1")
+            assert all(torch.equal(x, y) for x, y in zip(c, c2))
 
 
 @pytest.mark.parametrize("M,K,N,epi,split,bm192", [(3072, 1024, 4096, 2, 0, 1), (3072, 1024, 3072, 0, 2048, 1), (12288, 1024, 1024, 0, 0, 1),

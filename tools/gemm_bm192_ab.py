@@ -22,8 +22,9 @@ def case(name, M, K, N, residual, ln):
     h0 = torch.randn(M, N, generator=g).to(dev)
     res, outs = {}, {}
     for rnd in range(6):
-        for v in ("0", "1", "96", "96w4"):
-            os.environ["SCULPT_GEMM_BM192"] = "1" if v == "1" else "0"
+        for v in ("0", "1", "96", "96w4", "ks"):
+            os.environ["SCULPT_GEMM_BM192"] = "1" if v in ("1", "ks") else "0"
+            os.environ["SCULPT_GEMM_KS"] = "1" if v == "ks" else "0"
             os.environ["SCULPT_GEMM_BM96"] = {"96": "1", "96w4": "2"}.get(v, "0")
             if residual:
                 h = h0.clone()
@@ -44,9 +45,10 @@ def case(name, M, K, N, residual, ln):
     same = all(torch.equal(outs["0"][0], outs[v][0]) and torch.equal(outs["0"][1], outs[v][1]) for v in ("1", "96", "96w4"))
     st = "" if not residual else " stats max dev %.2e / %.2e" % tuple(float((outs["0"][2] - outs[v][2]).abs().max()) for v in ("1", "96"))
     fl = 2.0 * M * N * K
-    print("%-22s M=%d K=%d N=%d  128x64 tiles %.1f us (%.0f TF/s) | one round of 192x64 %.1f us (%.0f TF/s) | one round of 96x128 %.1f us (%.0f TF/s) | the same with 4 waves of 64x48 %.1f us | outputs identical: %s%s"
+    print("%-22s M=%d K=%d N=%d  128x64 tiles %.1f us (%.0f TF/s) | one round of 192x64 %.1f us (%.0f TF/s) | one round of 96x128 %.1f us (%.0f TF/s) | the same with 4 waves of 64x48 %.1f us | 192x64 with k-split pairs %.1f us (max rel dev of the fp32 / bf16 output %.1e) | outputs identical (all but k-split): %s%s"
           % (name, M, K, N, np.median(res["0"]), fl / np.median(res["0"]) / 1e6, np.median(res["1"]), fl / np.median(res["1"]) / 1e6,
-             np.median(res["96"]), fl / np.median(res["96"]) / 1e6, np.median(res["96w4"]), same, st), flush=True)
+             np.median(res["96"]), fl / np.median(res["96"]) / 1e6, np.median(res["96w4"]), np.median(res["ks"]),
+             float((outs["ks"][1].float() - outs["0"][1].float()).abs().max() / outs["0"][1].float().abs().max()), same, st), flush=True)
 
 
 case("cross-attn q (LN fold)", 3072, 1024, 1024, False, True)
