@@ -5,6 +5,7 @@
 //   V0  fp32:  v_exp_f32, v_add_f32, v_rcp_f32, v_mul_f32 per value + v_cvt_pk_f16_f32 per pair        (shipped first)
 //   V1  fp16:  v_cvt_pk_f16_f32 per pair, then v_exp_f16 x2 (low / high half by SDWA), v_pk_add_f16, v_rcp_f16 x2, v_pk_mul_f16
 //   V2  fp16, transcendentals on the low half only of two registers + v_pack / v_perm to rebuild the pair (no SDWA)
+//   V3  fp32 like V0 with the add and the multiply on register pairs: v_pk_add_f32 / v_pk_mul_f32
 // and the bare instruction costs the variants are made of.
 //   hipcc -O3 --offload-arch=gfx950 -o silu_cost silu_cost.hip && ./silu_cost
 #include <hip/hip_runtime.h>
@@ -34,6 +35,19 @@ __device__ __forceinline__ void silu8(float *x, unsigned *out) {
             const f2 v = {t[2 * q], t[2 * q + 1]};
             out[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
         }
+    } else if constexpr (V == 3) {
+        // fp32 with the add and the multiply as packed pairs (v_pk_add_f32 / v_pk_mul_f32: two values per 4-cycle issue)
+        f2 t[4], xx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { t[q][0] = __builtin_amdgcn_exp2f(-x[2 * q]); t[q][1] = __builtin_amdgcn_exp2f(-x[2 * q + 1]); xx[q][0] = x[2 * q]; xx[q][1] = x[2 * q + 1]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = t[q] + 1.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { t[q][0] = __builtin_amdgcn_rcpf(t[q][0]); t[q][1] = __builtin_amdgcn_rcpf(t[q][1]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = t[q] * xx[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(t[q], h2));
     } else if constexpr (V == 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -145,9 +159,9 @@ int main() {
     printf("s_memtime ticks (10 ns) per SiLU value and SIMD x 1000; w = waves per SIMD\n");
     const char *names[3] = {"V0 fp32 exp/add/rcp/mul + cvt_pk", "V1 fp16 packed, SDWA halves", "V2 fp16, pack instead of SDWA"};
     for (int w : {1, 2, 4}) {
-        printf("w=%d with 2 MFMAs per 8 values: V0 %.3f  V1 %.3f  V2 %.3f | no MFMA: V0 %.3f  V1 %.3f  V2 %.3f\n", w,
-               1e3 * run<0, true>(w, d, s), 1e3 * run<1, true>(w, d, s), 1e3 * run<2, true>(w, d, s),
-               1e3 * run<0, false>(w, d, s), 1e3 * run<1, false>(w, d, s), 1e3 * run<2, false>(w, d, s));
+        printf("w=%d with 2 MFMAs per 8 values: V0 %.3f  V1 %.3f  V2 %.3f  V3 %.3f | no MFMA: V0 %.3f  V1 %.3f  V2 %.3f  V3 %.3f\n", w,
+               1e3 * run<0, true>(w, d, s), 1e3 * run<1, true>(w, d, s), 1e3 * run<2, true>(w, d, s), 1e3 * run<3, true>(w, d, s),
+               1e3 * run<0, false>(w, d, s), 1e3 * run<1, false>(w, d, s), 1e3 * run<2, false>(w, d, s), 1e3 * run<3, false>(w, d, s));
     }
     (void)names;
     float *o; hipMalloc(&o, 4096 * 4);
