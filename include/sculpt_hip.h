@@ -46,7 +46,8 @@ extern "C" {
  *    attention, host-side PLY face records; sculpt_gemm_f32 forwards to sculpt_gemm_f32_ex and takes its two preconditions
  *    (bias 16-byte aligned; without a bias at most 65 532 output columns, see there)
  * 3: the two-pass dense density grid (sculpt_density_grid_filtered, sculpt_density_filter_workspace_bytes,
- *    sculpt_density_filter_stats) */
+ *    sculpt_density_filter_stats); added without a version change (new symbols only): sculpt_limbs_bytes, sculpt_limbs_split,
+ *    sculpt_gemm_l3p, sculpt_layernorm_limbs, sculpt_attention_f32_l3_limbs */
 #define SCULPT_ABI_VERSION 3
 
 typedef void *sculpt_stream_t;
@@ -296,6 +297,31 @@ int sculpt_gemm_f32_ex(const float *A, int lda, const float *W, int ldw, const f
  * 64 h ..; Vt [heads*64][ldvt] = V transposed, ldvt >= round_up(Tk, 64), columns >= Tk finite; O [Tq][ldo]. */
 int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, int Tq,
                             int Tk, int heads, float scale, sculpt_stream_t stream);
+/* "Limbs once" form of the SCULPT_F32_BF16L3 arithmetic (csrc/gemm_l3p.hip): the exact three-limb split x = x1 + x2 + x3 is done
+ * ONCE -- weights at load time, activations by the kernel that produces them -- instead of by every column tile of every launch.
+ * A limb-tiled matrix X [R][K] (K % 32 == 0) is ceil(R / 32) * K * 192 bytes (sculpt_limbs_bytes), 16-byte aligned:
+ *     byte offset of limb l (0 = leading) of X[r][k] = (((r / 32) * (K / 8) + k / 8) * 3 + l) * 512 + (r % 32) * 16 + (k % 8) * 2
+ * (32-row blocks x 8-k chunks x limb: one matrix-instruction fragment = 512 contiguous bytes, a 16-k step of a row block = 3 KiB that
+ * the GEMM copies into LDS by DMA).  Rows >= R of the last block: zeros from sculpt_limbs_split, unspecified from other producers
+ * (they reach only outputs that are never stored).
+ *   sculpt_limbs_split: fp32 [rows][K] (row stride ld, multiple of 4; src and dst 16-byte aligned) -> limb-tiled.
+ *   sculpt_gemm_l3p:    out[m][n] = epi(A[m][:].W[n][:] + bias[n]) (+ residual) with A [M][K] and W [N][K] limb-tiled: the same
+ *                       products in the same order as sculpt_gemm_f32_ex(SCULPT_F32_BF16L3) -- bit-identical results.  N % 128 == 0
+ *                       (GEGLU: N % 64 == 0 and W stored as 32-row blocks in the order value n..n+31, gate n..n+31, value n+32..,
+ *                       gate n+32.. per 64 output columns).  Outputs: out / out_t / n_split / residual as sculpt_gemm_f32, OR
+ *                       out_lt: the result itself as a limb-tiled [M][N] matrix (what the next Linear reads; excludes the others).
+ *   sculpt_layernorm_limbs:        sculpt_layernorm on fp32 rows with the normalised rows written limb-tiled ([rows][cols]; y_f32
+ *                                  optional: the same rows in fp32 as well).
+ *   sculpt_attention_f32_l3_limbs: sculpt_attention_f32_l3 with O written limb-tiled: query q of this call is row o_row0 + q of a
+ *                                  limb-tiled matrix of o_cols (>= heads * 64, multiple of 32) columns, head h at columns 64 h .. */
+size_t sculpt_limbs_bytes(int rows, int K);
+int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const float *beta, float eps, void *y_lt, float *y_f32, int ldy,
+                           int rows, int cols, sculpt_stream_t stream);
+int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt, int o_row0,
+                                  int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream);
+int sculpt_limbs_split(const float *src, int ld, int rows, int K, void *dst, sculpt_stream_t stream);
+int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const float *residual, int ldr, float *out, int ldo,
+                    float *out_t, int ldt, int n_split, void *out_lt, int M, int N, int K, int epilogue, sculpt_stream_t stream);
 /* in-place softmax over the first `cols` columns of each row; columns [cols, pad_cols) are set to 0 */
 int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, sculpt_stream_t stream);
 

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "attention_tile.h"
+#include "limbs.h"
 
 namespace sculpt {
 
@@ -63,7 +64,8 @@ __device__ __forceinline__ void al_split8(const float (&x)[8], abf16x8 &f1, abf1
 
 __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
                                                               const float *__restrict__ Vt, int ldvt, float *__restrict__ O, int ldo,
-                                                              int Tq, int Tk, float scale_log2e) {
+                                                              int Tq, int Tk, float scale_log2e, unsigned char *__restrict__ O_lt = nullptr,
+                                                              int o_row0 = 0, int o_k8 = 0) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AL_OP];   // [K limbs | V^T limbs]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -208,7 +210,17 @@ __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__res
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < Tq) {
+    if (q < Tq && O_lt) {
+        // the output as three bf16 limbs in the limb-tiled layout (limbs.h): the operand of the to_out Linear (gemm_l3p.hip);
+        // row o_row0 + q of a matrix with o_k8 chunks per row, columns head * 64 ..
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float a[4] = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            const float b[4] = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 8 * g4 + 4 * h, a);
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 32 + 8 * g4 + 4 * h, b);
+        }
+    } else if (q < Tq) {
         float *orow = O + (long)q * ldo + head * 64;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {   // registers 4 g4 .. 4 g4 + 3 = d 8 g4 + 4 h + {0..3} (+ 32 for o1)
@@ -299,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__res
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_l3_pipe_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K,
                                                                    int ldk, const float *__restrict__ Vt, int ldvt,
-                                                                   float *__restrict__ O, int ldo, int Tq, int Tk, float scale_log2e) {
+                                                                   float *__restrict__ O, int ldo, int Tq, int Tk, float scale_log2e,
+                                                                   unsigned char *__restrict__ O_lt = nullptr, int o_row0 = 0, int o_k8 = 0) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AL_OP];   // [K limbs | V^T limbs]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -492,10 +505,20 @@ __global__ __launch_bounds__(NW * 64) void attention_l3_pipe_kernel(const float 
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < Tq) {
-        float *orow = O + (long)q * ldo + head * 64;
+    if (q < Tq && O_lt) {
+        // the output as three bf16 limbs in the limb-tiled layout (limbs.h): the operand of the to_out Linear (gemm_l3p.hip);
+        // row o_row0 + q of a matrix with o_k8 chunks per row, columns head * 64 ..
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
+            const float a[4] = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            const float b[4] = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 8 * g4 + 4 * h, a);
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 32 + 8 * g4 + 4 * h, b);
+        }
+    } else if (q < Tq) {
+        float *orow = O + (long)q * ldo + head * 64;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {   // registers 4 g4 .. 4 g4 + 3 = d 8 g4 + 4 h + {0..3} (+ 32 for o1)
             *reinterpret_cast<float4 *>(orow + 8 * g4 + 4 * h) =
                 make_float4(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv);
             *reinterpret_cast<float4 *>(orow + 32 + 8 * g4 + 4 * h) =
@@ -516,23 +539,38 @@ __global__ __launch_bounds__(NW * 64) void attention_l3_pipe_kernel(const float 
 
 using namespace sculpt;
 
-extern "C" int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo,
-                                       int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
-    SC_REQUIRE(Q && K && Vt && O, "attention_f32_l3: null argument");
+static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, void *O_lt,
+                           int o_row0, int o_k8, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
+    SC_REQUIRE(Q && K && Vt && (O || O_lt), "attention_f32_l3: null argument");
     SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1 && heads <= 65535, "attention_f32_l3: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
     SC_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldvt % 4 == 0 && ldo % 4 == 0, "attention_f32_l3: row strides must keep 16-byte alignment");
     SC_REQUIRE(ldvt >= ((Tk + 63) / 64) * 64, "attention_f32_l3: ldvt=%d must be >= round_up(Tk=%d, 64) (finite padding columns)", ldvt, Tk);
     SC_REQUIRE(scale > 0.f && scale == scale, "attention_f32_l3: scale must be positive");
+    SC_REQUIRE(!O_lt || (o_row0 >= 0 && o_k8 >= heads * 8 && ((uintptr_t)O_lt & 15) == 0),
+               "attention_f32_l3_limbs: the limb output needs o_row0 >= 0, >= heads * 64 columns and 16-byte alignment");
+    unsigned char *olt = reinterpret_cast<unsigned char *>(O_lt);
     // the pipelined 8-wave form (256 queries per workgroup) where it keeps at least 2/3 of the CUs busy -- the backbone's 3072
     // queries x 16 heads = 192 workgroups --; otherwise (the image tokenizer: 1025 queries x 12 heads) the plain 4-wave form
     const char *e = getenv("SCULPT_L3_ATTN_PIPE");   // 0 / 1: never / always the pipelined form (A/B); read per call
     const bool pipe = e ? atoi(e) != 0 : (long)cdiv(Tq, 256) * heads * 3 >= 2L * num_cus();
     if (!pipe)
         hipLaunchKernelGGL(attention_l3_kernel, dim3(cdiv(Tq, 128), heads), dim3(256), 0, as_stream(stream), Q, ldq, K, ldk, Vt, ldvt, O,
-                           ldo, Tq, Tk, scale * 1.44269504088896340736f);
+                           ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8);
     else
         hipLaunchKernelGGL(attention_l3_pipe_kernel<8>, dim3(cdiv(Tq, 256), heads), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk, Vt,
-                           ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f);
+                           ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8);
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo,
+                                       int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
+    SC_REQUIRE(O, "attention_f32_l3: null argument");
+    return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, O, ldo, nullptr, 0, 0, Tq, Tk, heads, scale, stream);
+}
+
+extern "C" int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt,
+                                             int o_row0, int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
+    SC_REQUIRE(O_lt && o_cols % 32 == 0, "attention_f32_l3_limbs: null output or o_cols=%d not a multiple of 32", o_cols);
+    return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, nullptr, 0, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream);
 }

@@ -1,0 +1,273 @@
+// Three-limb GEMM on operands that are ALREADY split ("limbs once"): the same arithmetic as gemm_l3.hip --
+//   W.x = W1x3 + W3x1 + W2x2 + W1x2 + W2x1 + W1x1 per 16 k, fp32 accumulation on v_mfma_f32_32x32x16_bf16, k ascending --
+// so the results are BIT-IDENTICAL to gemm_l3_kernel's, but the exact split x = x1 + x2 + x3 is no longer redone by every column
+// tile of every launch (~5.5 vector instructions per staged value, 2/3 of them on the weights, which never change):
+//   * weights are split once at load time,
+//   * activations are written as limbs by the kernel that produces them (LayerNorm, attention, the GELU / GEGLU epilogue of the
+//     previous Linear; sculpt_limbs_split for the rest),
+// into the LIMB-TILED layout below, which is at the same time the LDS image of this kernel: a K-tile of a 32-row block is 3 KiB
+// of contiguous HBM that three global_load_lds_dwordx4 wave instructions copy straight into the ring -- no register round trip,
+// no vector instruction in the K loop but the MFMAs and their fragment reads.
+//
+// Limb-tiled matrix X [R][K] (K % 32 == 0), rows in blocks of 32, k in chunks of 8:
+//     byte offset of limb l (0 = leading) of X[r][k] = (((r / 32) * (K / 8) + k / 8) * 3 + l) * 512 + (r % 32) * 16 + (k % 8) * 2
+// i.e. [row block][k chunk][limb][32 rows][8 k] of bf16: one MFMA fragment (32 rows x 8 k of one limb) is 512 contiguous bytes, read
+// by ds_read_b128 with lane l31 on row l31 (conflict-free: the 16 lanes of a read group sit on 16 different 16-byte slots), the
+// lanes 32..63 on the next chunk.  ceil(R / 32) blocks are allocated; rows >= R of the last block hold zeros (sculpt_limbs_split)
+// or whatever the producer left there -- they only reach output rows / columns that are never stored.
+//
+// Tile 128 weight rows x BM (128 / 64) activation rows, 2 x 2 waves of 2 x JT accumulator tiles of 32 x 32 like gemm_l3_kernel (same
+// epilogue), K-tile = 16 (one MFMA k-step: 24 KiB per stage at BM = 128), 3-stage ring with two K-tiles in flight (counted vmcnt +
+// raw s_barrier, as gemm.hip), 72 KiB -> two workgroups per CU.
+#include <stdlib.h>
+
+#include "gemm_f32.h"
+#include "limbs.h"
+
+namespace sculpt {
+
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *p_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *p_gbl_ptr_t;
+
+struct GemmL3pArgs {
+    GemmF32Args g;            // A / W unused; everything else as gemm_l3_kernel
+    const unsigned char *A_lt;
+    const unsigned char *W_lt;
+    unsigned char *out_lt;    // when set: the result leaves as limbs (limb-tiled [M][N or N/2 outputs]) instead of g.out
+    int a_blocks;             // 32-row blocks allocated in A_lt
+    int out_k8;               // 16-byte chunks per row of out_lt = output columns / 8
+};
+
+// The epilogue when the result leaves as limbs: a lane holds four consecutive output columns of one row = one 8-byte half of a
+// 16-byte chunk per limb; the 64 lanes of a wave write 512 contiguous bytes per limb and register quad.
+template <int EPI, int JT>
+__device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f32x16 (&acc)[2][JT], int n0, int m0, int wr, int wc,
+                                                   int l31, int lh) {
+    const GemmF32Args &g = a.g;
+    const int out_blocks = (g.M + 31) >> 5;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int m = m0 + wc * (32 * JT) + j * 32 + l31;   // rows >= M of the last block are pad rows: written, never read as results
+        if ((m >> 5) >= out_blocks) continue;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if (EPI == SCULPT_EPI_GEGLU) {
+                const int n = n0 + wr * 32 + 8 * q4 + 4 * lh;
+                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n), bg = *reinterpret_cast<const float4 *>(g.bias + g.N + n);
+                const float bvs[4] = {bv.x, bv.y, bv.z, bv.w}, bgs[4] = {bg.x, bg.y, bg.z, bg.w};
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[0][j][4 * q4 + r] * g.alpha + bvs[r];
+                    const float gt = acc[1][j][4 * q4 + r] * g.alpha + bgs[r];
+                    o[r] = v * gelu_erf_exact(gt);
+                }
+                lt_store4(a.out_lt, a.out_k8, m, n, o);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int n = n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
+                    const float4 b4 = *reinterpret_cast<const float4 *>(g.bias + n);
+                    const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][4 * q4 + r] * g.alpha + bs[r];
+                        if (EPI == SCULPT_EPI_GELU) v = gelu_erf_exact(v);
+                        if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
+                        o[r] = v;
+                    }
+                    lt_store4(a.out_lt, a.out_k8, m, n, o);
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int BM>
+__global__ __launch_bounds__(256, 2) void gemm_l3p_kernel(GemmL3pArgs a) {
+    static_assert(BM == 128 || BM == 64, "128 or 64 activation rows per tile");
+    constexpr int JT = BM / 64;           // 32-row activation sub-tiles per wave
+    constexpr int ARB = BM / 32;          // activation row blocks per tile
+    constexpr int RBK = 3072;             // bytes of one K-tile (16 k = 2 chunks x 3 limbs x 512 B) of one row block
+    constexpr int STG = (4 + ARB) * RBK;  // one ring stage: [4 weight row blocks | ARB activation row blocks]
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STG];
+    const GemmF32Args &g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? FBW / 2 : FBW;
+    const int n0 = blockIdx.x * NOUT, m0 = blockIdx.y * BM;
+    const long kblk = (long)g.K * 192;    // bytes of one 32-row block: K / 8 chunks x 3 limbs x 512
+    // staging: wave w copies weight row block w of the tile (a GEGLU weight is stored with its row blocks already in the tile's
+    // value / gate order: 4 blocks per 64 output columns) and, when w < ARB, activation row block w
+    const unsigned char *wsrc = a.W_lt + ((long)blockIdx.x * 4 + wave) * kblk + lane * 16;
+    const bool astage = wave < ARB;       // wave-uniform
+    const unsigned char *asrc = a.A_lt + (long)min((m0 >> 5) + (astage ? wave : 0), a.a_blocks - 1) * kblk + lane * 16;
+    const int wdst = wave * RBK, adst = (4 + (astage ? wave : 0)) * RBK;
+
+#define L3P_STAGE(buf, kt)                                                                                                  \
+    do {                                                                                                                    \
+        unsigned char *sb = smem + (buf) * STG;                                                                             \
+        const long ko = (long)(kt) * RBK;                                                                                   \
+        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(wsrc + ko), (p_lds_ptr_t)(sb + wdst), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(wsrc + ko + 1024), (p_lds_ptr_t)(sb + wdst + 1024), 16, 0, 0);      \
+        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(wsrc + ko + 2048), (p_lds_ptr_t)(sb + wdst + 2048), 16, 0, 0);      \
+        if (BM == 128 || astage) {                                                                                          \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(asrc + ko), (p_lds_ptr_t)(sb + adst), 16, 0, 0);                 \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(asrc + ko + 1024), (p_lds_ptr_t)(sb + adst + 1024), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(asrc + ko + 2048), (p_lds_ptr_t)(sb + adst + 2048), 16, 0, 0);  \
+        }                                                                                                                   \
+    } while (0)
+
+    f32x16 acc[2][JT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    // fragment of limb l: + l * 512; lane (l31, lh): chunk lh of the K-tile, row l31
+    const int wfo = (wr * 2) * RBK + lh * 1536 + l31 * 16;
+    const int afo = (4 + wc * JT) * RBK + lh * 1536 + l31 * 16;
+
+    const int nk = g.K >> 4;
+    L3P_STAGE(0, 0);
+    if (nk > 1) L3P_STAGE(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // wait until K-tile kt has landed; K-tile kt + 1 (if issued) stays in flight
+        if (kt + 1 < nk) {
+            if (BM == 128 || astage) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // every wave finished reading stage (kt - 1) % 3 == (kt + 2) % 3 before it passed the barrier
+        if (kt + 2 < nk) L3P_STAGE((kt + 2) % NST, kt + 2);
+        const unsigned char *sb = smem + (kt % NST) * STG;
+        pbf16x8 wf[2][3], af[JT][3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i][l] = *reinterpret_cast<const pbf16x8 *>(sb + wfo + i * RBK + l * 512);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) af[j][l] = *reinterpret_cast<const pbf16x8 *>(sb + afo + j * RBK + l * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                f32x16 c = acc[i][j];   // smallest terms first: the order of gemm_l3_kernel
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][2], af[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][1], af[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][1], af[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    }
+#undef L3P_STAGE
+    if (a.out_lt) l3p_epilogue_limbs<EPI, JT>(a, acc, n0, m0, wr, wc, l31, lh);
+    else f32_tile_epilogue<EPI, JT>(g, acc, n0, m0, wr, wc, l31, lh);
+}
+
+// fp32 [R][K] (row stride ld) -> limb-tiled; one thread per (row of a block, k chunk): the 32 threads of a block row group write
+// 512 contiguous bytes per limb.  Rows >= R of the last block are written as zeros.
+__global__ __launch_bounds__(256) void limbs_split_kernel(const float *__restrict__ src, long ld, int R, int K,
+                                                          unsigned char *__restrict__ dst) {
+    const int k8 = K >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)((R + 31) >> 5) * k8 * 32;
+    if (idx >= total) return;
+    const int r32 = (int)(idx & 31);
+    const long bc = idx >> 5;
+    const int kc = (int)(bc % k8);
+    const long rb = bc / k8;
+    const long row = rb * 32 + r32;
+    float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < R) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(src + row * ld + kc * 8);
+        const float4 x1 = *reinterpret_cast<const float4 *>(src + row * ld + kc * 8 + 4);
+        lo[0] = x0.x; lo[1] = x0.y; lo[2] = x0.z; lo[3] = x0.w;
+        hi[0] = x1.x; hi[1] = x1.y; hi[2] = x1.z; hi[3] = x1.w;
+    }
+    uint2 a1, a2, a3, b1, b2, b3;
+    lt_split4(lo, a1, a2, a3);
+    lt_split4(hi, b1, b2, b3);
+    unsigned char *d = dst + (bc * 3) * 512 + r32 * 16;
+    *reinterpret_cast<uint4 *>(d) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+    *reinterpret_cast<uint4 *>(d + 512) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+}
+
+}  // namespace sculpt
+
+using namespace sculpt;
+
+extern "C" {
+
+size_t sculpt_limbs_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * (size_t)K * 192; }
+
+int sculpt_limbs_split(const float *src, int ld, int rows, int K, void *dst, sculpt_stream_t stream) {
+    SC_REQUIRE(src && dst, "limbs_split: null argument");
+    SC_REQUIRE(rows >= 1 && K >= 32 && K % 32 == 0 && ld >= K && ld % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+               "limbs_split: bad shape rows=%d K=%d ld=%d (K %% 32 == 0, ld %% 4 == 0, 16-byte aligned)", rows, K, ld);
+    const long total = (long)((rows + 31) / 32) * (K / 8) * 32;
+    hipLaunchKernelGGL(limbs_split_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, as_stream(stream), src, (long)ld, rows, K,
+                       reinterpret_cast<unsigned char *>(dst));
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const float *residual, int ldr, float *out, int ldo,
+                    float *out_t, int ldt, int n_split, void *out_lt, int M, int N, int K, int epilogue, sculpt_stream_t stream) {
+    SC_REQUIRE(A_lt && W_lt && (out || out_t || out_lt), "gemm_l3p: null argument");
+    SC_REQUIRE(M >= 1 && K >= 32 && K % 32 == 0, "gemm_l3p: bad shape M=%d K=%d (K %% 32 == 0)", M, K);
+    SC_REQUIRE(((uintptr_t)A_lt & 15) == 0 && ((uintptr_t)W_lt & 15) == 0 && ((uintptr_t)out_lt & 15) == 0, "gemm_l3p: limb arrays must be 16-byte aligned");
+    const bool geglu = epilogue == SCULPT_EPI_GEGLU;
+    if (geglu) SC_REQUIRE(N % 64 == 0 && (out || out_lt) && !residual && !out_t, "gemm_l3p(GEGLU): N %% 64 == 0, plain or limb output only");
+    else SC_REQUIRE(N % 128 == 0 && (epilogue == SCULPT_EPI_NONE || epilogue == SCULPT_EPI_GELU || epilogue == SCULPT_EPI_RELU),
+                    "gemm_l3p: N=%d must be a multiple of 128; epilogue %d", N, epilogue);
+    SC_REQUIRE(!out_lt || (!residual && !out_t && !out), "gemm_l3p: a limb output excludes the fp32 outputs and the residual");
+    SC_REQUIRE(ldo % 4 == 0 && (!residual || ldr % 4 == 0), "gemm_l3p: row strides must be multiples of 4");
+    if (n_split <= 0 || n_split > N) n_split = N;
+    SC_REQUIRE(n_split % 4 == 0 && (n_split == N || out_t), "gemm_l3p: bad n_split");
+    if (!bias) {
+        long zn = 0;
+        bias = zero_floats_page(&zn);
+        SC_REQUIRE(bias && (geglu ? 2L * N : (long)N) + 4 <= zn, "gemm_l3p: N=%d too large without a bias", N);
+    }
+    SC_REQUIRE(((uintptr_t)bias & 15) == 0, "gemm_l3p: bias must be 16-byte aligned");
+    GemmL3pArgs a;
+    a.g = GemmF32Args{nullptr, 0, nullptr, 0, bias, residual, ldr, out, ldo, out_t, ldt, M, N, K, n_split, N, 1.0f, 0, 0, 0};
+    a.A_lt = reinterpret_cast<const unsigned char *>(A_lt);
+    a.W_lt = reinterpret_cast<const unsigned char *>(W_lt);
+    a.out_lt = reinterpret_cast<unsigned char *>(out_lt);
+    a.a_blocks = (M + 31) / 32;
+    a.out_k8 = N / 8;
+    hipStream_t st = as_stream(stream);
+    const int gx = geglu ? N / 64 : N / 128;
+    const char *e64 = getenv("SCULPT_L3P_BM64");   // 0 / 1: never / always the 64-row tile (A/B); default: by CU fill
+    const long tiles128 = (long)gx * cdiv(M, 128);
+    const bool bm64 = e64 ? atoi(e64) != 0 : tiles128 < 2L * num_cus();
+#define L3P_GO(E)                                                                                                      \
+    do {                                                                                                               \
+        if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);            \
+        else hipLaunchKernelGGL((gemm_l3p_kernel<E, 128>), dim3(gx, cdiv(M, 128)), dim3(256), 0, st, a);               \
+    } while (0)
+    if (geglu) L3P_GO(SCULPT_EPI_GEGLU);
+    else if (epilogue == SCULPT_EPI_GELU) L3P_GO(SCULPT_EPI_GELU);
+    else if (epilogue == SCULPT_EPI_RELU) L3P_GO(SCULPT_EPI_RELU);
+    else L3P_GO(SCULPT_EPI_NONE);
+#undef L3P_GO
+    SC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -4,6 +4,10 @@ bf16:   bf16 storage / fp32 accumulate on the MFMA kernels (what bench.py times)
 fp32:   every GEMM / attention / norm on the exact-fp32 parity kernels (the reference's own precision).
 bf16l3: fp32 storage and fp32 norms / softmax like "fp32", but every matrix product (Linears, QK^T, PV) on the bf16 matrix pipe
         through the exact three-limb split of both operands, fp32 accumulate (csrc/gemm_l3.hip): fp32-equivalent, ~6x faster.
+        "Limbs once" (default in this mode, SCULPT_L3P=0 restores the form that splits inside every GEMM): a subclass that
+        stores its hot Linear weights as ops.Limbs (split at load time) and allocates the activations that only feed such a
+        Linear with _lt() gets them written as limbs by their producers -- LayerNorm, attention, the GELU / GEGLU epilogue -- and
+        multiplied by csrc/gemm_l3p.hip: the same products in the same order, bit-identical results, no split in any K loop.
 A subclass provides self.precision ("bf16" | "fp32" | "bf16l3"), self.device and self._buf = {}.
 """
 import os
@@ -46,6 +50,14 @@ class KernelEngine:
             self._buf[key] = t
         return t
 
+    def _lt(self, name, rows, cols):
+        """A cached limb-tiled activation buffer (ops.Limbs), zero-initialised once (pad rows stay finite)."""
+        key = (name, "limbs", rows, cols)
+        t = self._buf.get(key)
+        if t is None:
+            t = self._buf[key] = ops.Limbs(rows, cols, self.device, zero=True)
+        return t
+
     # ------------------------------------------------------------------ precision dispatch
     def _gemm(self, A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None, M=None, epilogue=0,
               n_split=0):
@@ -54,6 +66,12 @@ class KernelEngine:
             return ops.gemm(A, W, bias=bias, residual=residual, out_f32=out_f32, out_bf16=out_bf16, out_t=out_t, M=M,
                             epilogue=epilogue, n_split=n_split)
         out = out_f32 if out_f32 is not None else out_bf16
+        if isinstance(W, ops.Limbs):   # limbs once: both operands arrive split (csrc/gemm_l3p.hip)
+            assert isinstance(A, ops.Limbs) and A.cols == W.cols, "a limb-tiled weight needs a limb-tiled activation of the same K"
+            N = W.rows // 2 if epilogue == ops._lib.EPI_GEGLU else W.rows
+            lt = isinstance(out, ops.Limbs)
+            return ops.gemm_l3p(A, W, A.rows if M is None else M, N, W.cols, bias=bias, residual=residual, out=None if lt else out,
+                                out_t=out_t, n_split=n_split, out_lt=out if lt else None, epilogue=epilogue)
         return ops.gemm_f32(A, W, bias=bias, residual=residual, out=out, out_t=out_t, M=M, epilogue=epilogue,
                             n_split=n_split, l3=self.l3)
 
@@ -88,13 +106,19 @@ class KernelEngine:
             chunks = [(h0, min(n, heads - h0), flat[:min(n, heads - h0) * per_head].view(min(n, heads - h0), Tq, ld))
                       for h0 in range(0, heads, n)]
         if batch > 1:
-            assert q_bs % Q.stride(0) == 0 and k_bs % K.stride(0) == 0 and o_bs % O.stride(0) == 0 and vt_bs < Vt.stride(0)
+            assert q_bs % Q.stride(0) == 0 and k_bs % K.stride(0) == 0 and vt_bs < Vt.stride(0)
+            assert o_bs % (O.cols if isinstance(O, ops.Limbs) else O.stride(0)) == 0
             Tkp = ((Tk + 31) // 32) * 32 if self.l3 else ((Tk + 15) // 16) * 16
             assert (batch - 1) * vt_bs + Tkp <= Vt.shape[1], "V^T too narrow for the last batch entry (%d + %d > %d)" % (
                 (batch - 1) * vt_bs, Tkp, Vt.shape[1])
         for b in range(batch):
             q, k = Q[b * q_bs // Q.stride(0):] if b else Q, K[b * k_bs // K.stride(0):] if b else K
-            vt, o = Vt[:, b * vt_bs:] if b else Vt, O[b * o_bs // O.stride(0):] if b else O
+            vt = Vt[:, b * vt_bs:] if b else Vt
+            if isinstance(O, ops.Limbs):   # fused three-limb attention writing limbs: entry b starts at row b * o_bs / cols
+                assert fused
+                ops.attention_f32(q, k, vt, O, Tq, Tk, heads, scale, None, l3=True, o_row0=b * o_bs // O.cols)
+                continue
+            o = O[b * o_bs // O.stride(0):] if b else O
             for h0, nh, scores in chunks:
                 ops.attention_f32(q[:, 64 * h0:], k[:, 64 * h0:], vt[64 * h0:], o[:, 64 * h0:], Tq, Tk, nh, scale, scores, l3=self.l3)
 
@@ -135,6 +159,10 @@ class KernelEngine:
         if self.precision == "bf16":
             return ops.gemm(st["hb"], L[key], bias=L[key + "_b"], ln_stats=st["stats"], ln_colsum=L[key + "_cs"], ln_eps=eps, **kw)
         g, b = L[key + "_ln"]
+        if isinstance(L[key], ops.Limbs):   # limbs once: the LayerNorm writes the GEMM's operand as limbs
+            xn = self._lt(st["name"] + "_xn", st["h"].shape[0], st["h"].shape[1])
+            ops.layernorm(st["h"], g, b, eps, y_lt=xn)
+            return self._gemm(xn, L[key], bias=L[key + "_b"], **kw)
         ops.layernorm(st["h"], g, b, eps, y_f32=st["xn"])
         return self._gemm(st["xn"], L[key], bias=L[key + "_b"], **kw)
 

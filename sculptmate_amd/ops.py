@@ -355,8 +355,14 @@ def attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch=1, q_bs=0, k_bs=0, vt_bs=
                                         O.stride(0), Tq, Tk, heads, float(scale), _stream()))
 
 
-def layernorm(x, gamma, beta, eps, y=None, y_f32=None, rows=None):
+def layernorm(x, gamma, beta, eps, y=None, y_f32=None, rows=None, y_lt=None):
+    """y_lt (a Limbs, fp32 x only): the normalised rows as three bf16 limbs, limb-tiled (sculpt_layernorm_limbs); y_f32 optional."""
     rows = x.shape[0] if rows is None else rows
+    if y_lt is not None:
+        assert x.dtype == torch.float32 and y is None and y_lt.cols == x.shape[1] and y_lt.rows >= rows
+        check(lib.sculpt_layernorm_limbs(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y_lt.data), _ptr(y_f32),
+                                         y_f32.stride(0) if y_f32 is not None else 0, rows, x.shape[1], _stream()))
+        return
     xf = x if x.dtype == torch.float32 else None
     xb = x if x.dtype == BF16 else None
     ldy = (y if y is not None else y_f32).stride(0)
@@ -627,11 +633,73 @@ def gemm_f32(A, W, bias=None, residual=None, out=None, out_t=None, M=None, N=Non
                                  int(o_bs), _stream()))
 
 
+class Limbs:
+    """An fp32 matrix [rows][cols] held as three bf16 limbs per element in the limb-tiled layout of csrc/limbs.h: the operand form
+    of `gemm_l3p` (weights split once at load time, activations written this way by the kernel that produces them)."""
+    __slots__ = ("data", "rows", "cols")
+
+    def __init__(self, rows, cols, device=None, data=None, zero=False):
+        self.rows, self.cols = int(rows), int(cols)
+        self.data = data if data is not None else limbs_empty(rows, cols, device, zero=zero)
+
+    @staticmethod
+    def of(x):
+        return Limbs(x.shape[0], x.shape[1], data=limbs_split(x))
+
+    def float(self):
+        return limbs_join(self.data, self.rows, self.cols)
+
+
+def limbs_bytes(rows, K):
+    return int(lib.sculpt_limbs_bytes(int(rows), int(K)))
+
+
+def limbs_empty(rows, K, device, zero=False):
+    """An uninitialised limb-tiled [rows][K] matrix (sculpt_limbs_split's layout; a flat uint8 tensor)."""
+    return (torch.zeros if zero else torch.empty)(limbs_bytes(rows, K), dtype=torch.uint8, device=device)
+
+
+def limbs_split(x, out=None):
+    """fp32 [rows][K] -> the limb-tiled three-limb form the `gemm_l3p` operands take (exact: x = x1 + x2 + x3 in bf16 limbs)."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, K = x.shape
+    if out is None:
+        out = limbs_empty(rows, K, x.device)
+    check(lib.sculpt_limbs_split(_ptr(x), x.stride(0), rows, K, _ptr(out), _stream()))
+    return out
+
+
+def limbs_join(lt, rows, K):
+    """The fp32 matrix a limb-tiled array stands for (tests): x1 + x2 + x3 per element."""
+    v = lt.view(torch.bfloat16).view(-1, K // 8, 3, 32, 8).to(torch.float32)       # [block][chunk][limb][row][k]
+    x = (v[:, :, 0] + v[:, :, 1]) + v[:, :, 2]                                     # exact: the limbs do not overlap
+    return x.permute(0, 2, 1, 3).reshape(-1, K)[:rows].contiguous()
+
+
+def geglu_row_blocks(W):
+    """A GEGLU weight [2N][K] (value rows, then gate rows) with its 32-row blocks in gemm_l3p's tile order."""
+    N = W.shape[0] // 2
+    assert N % 64 == 0
+    idx = torch.arange(N, device=W.device).view(N // 64, 2, 32)                    # [tile][half][row]
+    order = torch.stack([idx[:, 0], idx[:, 0] + N, idx[:, 1], idx[:, 1] + N], 1).reshape(-1)
+    return W.index_select(0, order)
+
+
+def gemm_l3p(A_lt, W_lt, M, N, K, bias=None, residual=None, out=None, out_t=None, n_split=0, out_lt=None, epilogue=0):
+    """sculpt_gemm_l3p: the three-limb GEMM on operands split once (A_lt [M][K], W_lt [N or 2N][K] limb-tiled; Limbs or raw)."""
+    A_lt, W_lt = getattr(A_lt, "data", A_lt), getattr(W_lt, "data", W_lt)
+    out_lt = getattr(out_lt, "data", out_lt)
+    check(lib.sculpt_gemm_l3p(_ptr(A_lt), _ptr(W_lt), _ptr(bias), _ptr(residual), residual.stride(0) if residual is not None else 0,
+                              _ptr(out), out.stride(0) if out is not None else 0, _ptr(out_t),
+                              out_t.stride(0) if out_t is not None else 0, int(n_split), _ptr(out_lt), int(M), int(N), int(K),
+                              int(epilogue), _stream()))
+
+
 def softmax_rows_f32(x, rows, cols, pad_cols):
     check(lib.sculpt_softmax_rows_f32(_ptr(x), x.stride(0), rows, cols, pad_cols, _stream()))
 
 
-def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False):
+def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False, o_row0=0):
     """softmax(Q K^T scale) V per head in fp32: two GEMMs and a row softmax per head.
     Q [Tq][*], K [Tk][*] with head h at columns 64h..; Vt [heads*64][>= round_up(Tk,32)] (zero padded).
     scores: fp32 scratch.  [Tq][>= round_up(Tk,32)]: the heads run one after the other (three launches each);
@@ -642,6 +710,10 @@ def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False):
     N4 = ((Tk + 3) // 4) * 4
     if scores is None:   # the fused kernel of the three-limb mode: no score matrix in HBM
         assert l3, "the exact-fp32 attention is a composition: it needs the scores scratch"
+        if isinstance(O, Limbs):   # the output as limbs: row o_row0 + q of the limb-tiled matrix O
+            check(lib.sculpt_attention_f32_l3_limbs(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O.data),
+                                                    int(o_row0), O.cols, Tq, Tk, heads, float(scale), _stream()))
+            return
         check(lib.sculpt_attention_f32_l3(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O), O.stride(0),
                                           Tq, Tk, heads, float(scale), _stream()))
         return

@@ -225,6 +225,7 @@ class TSR(KernelEngine):
         self.cfg = cfg or DEFAULT_CFG
         self.pos_embed_mode = pos_embed_mode
         self.precision = precision
+        self.l3p = False   # set by _prepare: the three-limb mode with operands split once (engine.py)
         self.adt = BF16 if precision == "bf16" else torch.float32  # activation / weight storage type
         self._spec = param_spec(self.cfg)
         self._sd = None
@@ -289,6 +290,10 @@ class TSR(KernelEngine):
     def _prepare(self, dev):
         sd, cfg = self._sd, self.cfg
         wt = _bf if self.precision == "bf16" else _f32  # GEMM weight storage
+        # "limbs once" (engine.py): in the three-limb mode the Linears of the two transformers keep their weights split
+        self.l3p = self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0"
+        wh = (lambda x, d, geglu=False: ops.Limbs.of(_f32(ops.geglu_row_blocks(torch.as_tensor(x)) if geglu else x, d))) if self.l3p \
+            else (lambda x, d, geglu=False: wt(x, d))
         v, b = cfg["image_tokenizer"], cfg["backbone"]
         H = v["hidden_size"]
         w = {}
@@ -298,9 +303,9 @@ class TSR(KernelEngine):
         w["cls"] = _f32(sd[p + "embeddings.cls_token"].reshape(H), dev)
         fold = self.precision == "bf16"
 
-        def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, q_scale=1.0):
+        def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, q_scale=1.0, geglu=False):
             """A Linear fed by a LayerNorm (engine.prepare_ln_linear): folded into the GEMM in bf16 mode."""
-            prepare_ln_linear(L, key, W, bias, gamma, beta, fold, lambda x: wt(x, dev), lambda x: _f32(x, dev), q_rows, q_scale)
+            prepare_ln_linear(L, key, W, bias, gamma, beta, fold, lambda x: wh(x, dev, geglu), lambda x: _f32(x, dev), q_rows, q_scale)
 
         w["vit"] = []
         for i in range(v["num_hidden_layers"]):
@@ -310,10 +315,10 @@ class TSR(KernelEngine):
                       torch.cat([sd[q + "attention.attention.%s.bias" % n] for n in ("query", "key", "value")], 0),
                       sd[q + "layernorm_before.weight"], sd[q + "layernorm_before.bias"], q_rows=H,
                       q_scale=LOG2E / math.sqrt(H // v["num_attention_heads"]))
-            L["o_w"], L["o_b"] = wt(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
+            L["o_w"], L["o_b"] = wh(sd[q + "attention.output.dense.weight"], dev), _f32(sd[q + "attention.output.dense.bias"], dev)
             ln_linear(L, "f1_w", sd[q + "intermediate.dense.weight"], sd[q + "intermediate.dense.bias"],
                       sd[q + "layernorm_after.weight"], sd[q + "layernorm_after.bias"])
-            L["f2_w"], L["f2_b"] = wt(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
+            L["f2_w"], L["f2_b"] = wh(sd[q + "output.dense.weight"], dev), _f32(sd[q + "output.dense.bias"], dev)
             w["vit"].append(L)
         w["vit_ln_w"], w["vit_ln_b"] = _f32(sd[p + "layernorm.weight"], dev), _f32(sd[p + "layernorm.bias"], dev)
 
@@ -333,16 +338,17 @@ class TSR(KernelEngine):
             Db, qs = b["num_attention_heads"] * b["attention_head_dim"], LOG2E / math.sqrt(b["attention_head_dim"])
             ln_linear(L, "sa_qkv", torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0),
                       None, sd[q + "norm1.weight"], sd[q + "norm1.bias"], q_rows=Db, q_scale=qs)
-            L["sa_o"], L["sa_ob"] = wt(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
+            L["sa_o"], L["sa_ob"] = wh(sd[q + "attn1.to_out.0.weight"], dev), _f32(sd[q + "attn1.to_out.0.bias"], dev)
             ln_linear(L, "ca_q", sd[q + "attn2.to_q.weight"], None, sd[q + "norm2.weight"], sd[q + "norm2.bias"], q_rows=Db, q_scale=qs)
             L["_ca_k"], L["_ca_v"] = sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]
-            L["ca_o"], L["ca_ob"] = wt(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
-            ln_linear(L, "ff1", sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], sd[q + "norm3.weight"], sd[q + "norm3.bias"])
-            L["ff2"], L["ff2_b"] = wt(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
+            L["ca_o"], L["ca_ob"] = wh(sd[q + "attn2.to_out.0.weight"], dev), _f32(sd[q + "attn2.to_out.0.bias"], dev)
+            ln_linear(L, "ff1", sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], sd[q + "norm3.weight"], sd[q + "norm3.bias"],
+                      geglu=True)
+            L["ff2"], L["ff2_b"] = wh(sd[q + "ff.net.2.weight"], dev), _f32(sd[q + "ff.net.2.bias"], dev)
             w["blocks"].append(L)
         # the cross-attention K/V projections of ALL layers depend only on the image tokens: one GEMM
         # [Tc, 768] x [L*2*D, 768]^T per image, rows ordered [K of layer 0..L-1 | V of layer 0..L-1]
-        w["ca_kv_all"] = wt(torch.cat([L.pop("_ca_k") for L in w["blocks"]] + [L.pop("_ca_v") for L in w["blocks"]], 0), dev)
+        w["ca_kv_all"] = wh(torch.cat([L.pop("_ca_k") for L in w["blocks"]] + [L.pop("_ca_v") for L in w["blocks"]], 0), dev)
         # ConvTranspose2d(k2,s2) as a GEMM: rows (co,dy,dx), K = Cin; rows padded to a multiple of 128
         up = sd["post_processor.upsample.weight"]  # [Cin, Co, 2, 2]
         Co = up.shape[1]
@@ -405,8 +411,11 @@ class TSR(KernelEngine):
         self._stats_of(st)                    # rows that do not come out of a GEMM: one small kernel
         qk = self._b("vit_qk", (M, 2 * H), self.adt)
         vt = self._b("vit_vt", (H, ldt), self.adt, zero=True)
-        att = self._b("vit_att", (M, H), self.adt, zero=True)
-        ff = self._b("vit_ff", (M, v["intermediate_size"]), self.adt)
+        if self.l3p:   # read only by the next Linear: written as limbs by their producers
+            att, ff = self._lt("vit_att", M, H), self._lt("vit_ff", M, v["intermediate_size"])
+        else:
+            att = self._b("vit_att", (M, H), self.adt, zero=True)
+            ff = self._b("vit_ff", (M, v["intermediate_size"]), self.adt)
         eps = v["layer_norm_eps"]
         for L in w["vit"]:
             self._ln_gemm(st, L, "qkv_w", eps, out_bf16=qk, out_t=vt, n_split=2 * H)  # Q|K token-major, V^T
@@ -419,6 +428,9 @@ class TSR(KernelEngine):
         if self.precision == "bf16":
             ctx = self._b("ctx", (M, H), BF16)
             ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y=ctx, y_f32=ctx32)
+        elif self.l3p:   # the cross-attention K / V projection reads the tokens as limbs
+            ctx = self._lt("ctx", M, H)
+            ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y_lt=ctx, y_f32=ctx32)
         else:
             ops.layernorm(h, w["vit_ln_w"], w["vit_ln_b"], eps, y_f32=ctx32)
             ctx = ctx32
@@ -439,7 +451,7 @@ class TSR(KernelEngine):
         Mp = ((((batch - 1) * T + ((T + 63) // 64) * 64) + 63) // 64) * 64
         qk = self._b("bb_qk", (M, 2 * D), self.adt)
         vt = self._b("bb_vt", (D, Mp), self.adt, zero=True)
-        att = self._b("bb_att", (M, D), self.adt)
+        att = self._lt("bb_att", M, D) if self.l3p else self._b("bb_att", (M, D), self.adt)
         self._ln_gemm(st, L, "sa_qkv", 1e-5, out_bf16=qk, out_t=vt, n_split=2 * D)  # one launch: Q|K token-major, V^T
         self._attn(qk[:, :D], qk[:, D:], vt, att, T, T, nh, self._attn_scale(1.0 / math.sqrt(hd)),
                    batch, T * 2 * D, T * 2 * D, T, T * D)
@@ -451,7 +463,9 @@ class TSR(KernelEngine):
         b, w = self.cfg["backbone"], self._w
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
         D = nh * hd
-        M, Mc = st["h"].shape[0], ctx.shape[0]
+        if self.l3p and not isinstance(ctx, ops.Limbs):   # tokens handed over as a plain fp32 matrix (backbone_tokens): split here
+            ctx = ops.Limbs.of(ctx.to(torch.float32).contiguous())
+        M, Mc = st["h"].shape[0], (ctx.rows if isinstance(ctx, ops.Limbs) else ctx.shape[0])
         T, Ts = M // batch, Mc // batch
         Tc = Ts if ctx_tokens is None else ctx_tokens
         ldc = ((((batch - 1) * Ts + ((Tc + 63) // 64) * 64) + 63) // 64) * 64
@@ -460,8 +474,11 @@ class TSR(KernelEngine):
         ck_all = self._b("bb_ck", (Mc, nL * D), self.adt)
         cvt_all = self._b("bb_cvt", (nL * D, ldc), self.adt, zero=True)
         self._gemm(ctx, w["ca_kv_all"], out_bf16=ck_all, out_t=cvt_all, n_split=nL * D, M=Mc)
-        att = self._b("bb_att", (M, D), self.adt)
-        ff = self._b("bb_ff", (M, 4 * D), self.adt)
+        if self.l3p:
+            att, ff = self._lt("bb_att", M, D), self._lt("bb_ff", M, 4 * D)
+        else:
+            att = self._b("bb_att", (M, D), self.adt)
+            ff = self._b("bb_ff", (M, 4 * D), self.adt)
         scale = self._attn_scale(1.0 / math.sqrt(hd))
         for li, L in enumerate(w["blocks"]):
             ck, cvt = ck_all[:, li * D:(li + 1) * D], cvt_all[li * D:(li + 1) * D]
@@ -615,9 +632,14 @@ class TSR(KernelEngine):
             if slot["consumed"] is not None:
                 tok.wait_event(slot["consumed"])
             ctx, _ = self.image_tokens(self._preprocess(image))
-            if slot["ctx"] is None or slot["ctx"].shape != ctx.shape or slot["ctx"].dtype != ctx.dtype:
-                slot["ctx"] = torch.empty_like(ctx)
-            slot["ctx"].copy_(ctx)
+            if isinstance(ctx, ops.Limbs):   # three-limb mode, limbs once: the tokens travel as limbs
+                if not isinstance(slot["ctx"], ops.Limbs) or (slot["ctx"].rows, slot["ctx"].cols) != (ctx.rows, ctx.cols):
+                    slot["ctx"] = ops.Limbs(ctx.rows, ctx.cols, data=torch.empty_like(ctx.data))
+                slot["ctx"].data.copy_(ctx.data)
+            else:
+                if not isinstance(slot["ctx"], torch.Tensor) or slot["ctx"].shape != ctx.shape or slot["ctx"].dtype != ctx.dtype:
+                    slot["ctx"] = torch.empty_like(ctx)
+                slot["ctx"].copy_(ctx)
             ready = torch.cuda.Event()
             ready.record(tok)
         self._tok_last = ready

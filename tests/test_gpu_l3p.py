@@ -1,0 +1,165 @@
+"""The "limbs once" GEMM of the tolerance mode (csrc/gemm_l3p.hip) against the kernel that splits while staging (gemm_l3.hip):
+same products in the same order, so every comparison here is BIT for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand(shape, g, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(_dev())
+
+
+def test_limbs_split_is_exact_and_tiled_as_documented():
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    R, K = 77, 96
+    x = _rand((R, K), g) * torch.exp2(torch.randint(-30, 30, (R, K), generator=g).float()).to(_dev())
+    x[3, 5] = 0.0
+    x[4, 6] = -0.0
+    lt = ops.limbs_split(x)
+    assert lt.numel() == ops.limbs_bytes(R, K) == 3 * 96 * 192
+    assert torch.equal(ops.limbs_join(lt, R, K), x)
+    # the documented byte offset of limb l of X[r][k], element by element on a few positions
+    v = lt.view(torch.bfloat16)
+    for r, k in ((0, 0), (31, 7), (32, 8), (76, 95), (45, 50)):
+        limbs = [float(v[((((r // 32) * (K // 8) + k // 8) * 3 + l) * 512 + (r % 32) * 16 + (k % 8) * 2) // 2]) for l in range(3)]
+        assert limbs[0] == float(x[r, k].to(torch.bfloat16))
+        assert (limbs[0] + limbs[1]) + limbs[2] == float(x[r, k])
+    # pad rows of the last block are zeros
+    assert float(v.view(-1, K // 8, 3, 32, 8)[2, :, :, 77 - 64:].abs().max()) == 0.0
+    # a strided source
+    big = _rand((R, 2 * K), g)
+    assert torch.equal(ops.limbs_join(ops.limbs_split(big[:, K:]), R, K), big[:, K:])
+
+
+@pytest.mark.parametrize("M,N,K,bm64", [(1025, 768, 768, None), (3072, 1024, 1024, "0"), (3072, 1024, 1024, "1"), (200, 256, 64, None),
+                                         (1025, 2304, 768, None)])
+def test_l3p_gemm_equals_the_splitting_kernel_bit_for_bit(M, N, K, bm64, monkeypatch):
+    from sculptmate_amd import ops
+
+    if bm64 is not None:
+        monkeypatch.setenv("SCULPT_L3P_BM64", bm64)
+    g = torch.Generator().manual_seed(M + N)
+    A, W, bias = _rand((M, K), g), _rand((N, K), g, K ** -0.5), _rand((N,), g)
+    res = _rand((M, N), g)
+    A_lt, W_lt = ops.limbs_split(A), ops.limbs_split(W)
+    # plain + bias
+    want = torch.empty(M, N, device=_dev()); got = torch.full((M, N), float("nan"), device=_dev())
+    ops.gemm_f32(A, W, bias=bias, out=want, l3=True)
+    ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=got)
+    assert torch.equal(got, want)
+    # residual in place, no bias
+    want = res.clone(); got = res.clone()
+    ops.gemm_f32(A, W, residual=want, out=want, l3=True)
+    ops.gemm_l3p(A_lt, W_lt, M, N, K, residual=got, out=got)
+    assert torch.equal(got, want)
+    # column split with a transposed part (Q | K token-major, V^T)
+    ns = N // 2
+    ldt = ((M + 63) // 64) * 64
+    w1, w2 = torch.zeros(M, ns, device=_dev()), torch.zeros(N - ns, ldt, device=_dev())
+    g1, g2 = torch.zeros(M, ns, device=_dev()), torch.zeros(N - ns, ldt, device=_dev())
+    ops.gemm_f32(A, W, bias=bias, out=w1, out_t=w2, n_split=ns, l3=True)
+    ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=g1, out_t=g2, n_split=ns)
+    assert torch.equal(g1, w1) and torch.equal(g2, w2)
+    # the result as limbs: exactly the fp32 result, split
+    out_lt = ops.limbs_empty(M, N, _dev(), zero=True)
+    ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out_lt=out_lt)
+    ops.gemm_f32(A, W, bias=bias, out=want, l3=True)
+    assert torch.equal(ops.limbs_join(out_lt, M, N), want)
+
+
+@pytest.mark.parametrize("M,N,K", [(1025, 3072, 768), (3072, 4096, 1024), (96, 128, 64)])
+def test_l3p_gelu_and_geglu_epilogues(M, N, K):
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(N)
+    A, bias = _rand((M, K), g), _rand((N,), g)
+    W = _rand((N, K), g, K ** -0.5)
+    A_lt = ops.limbs_split(A)
+    want = torch.empty(M, N, device=_dev()); got = torch.empty(M, N, device=_dev())
+    ops.gemm_f32(A, W, bias=bias, out=want, epilogue=_lib.EPI_GELU, l3=True)
+    ops.gemm_l3p(A_lt, ops.limbs_split(W), M, N, K, bias=bias, out=got, epilogue=_lib.EPI_GELU)
+    assert torch.equal(got, want)
+    out_lt = ops.limbs_empty(M, N, _dev(), zero=True)
+    ops.gemm_l3p(A_lt, ops.limbs_split(W), M, N, K, bias=bias, out_lt=out_lt, epilogue=_lib.EPI_GELU)
+    assert torch.equal(ops.limbs_join(out_lt, M, N), want)
+    # GEGLU: W [2 No][K] value rows then gate rows; the limb-tiled weight carries its row blocks in tile order
+    No = N // 2
+    want = torch.empty(M, No, device=_dev()); got = torch.empty(M, No, device=_dev())
+    ops.gemm_f32(A, W, bias=bias, out=want, epilogue=_lib.EPI_GEGLU, l3=True)
+    W_lt = ops.limbs_split(ops.geglu_row_blocks(W))
+    ops.gemm_l3p(A_lt, W_lt, M, No, K, bias=bias, out=got, epilogue=_lib.EPI_GEGLU)
+    assert torch.equal(got, want)
+    out_lt = ops.limbs_empty(M, No, _dev(), zero=True)
+    ops.gemm_l3p(A_lt, W_lt, M, No, K, bias=bias, out_lt=out_lt, epilogue=_lib.EPI_GEGLU)
+    assert torch.equal(ops.limbs_join(out_lt, M, No), want)
+
+
+def test_l3p_refuses_what_it_cannot_do():
+    from sculptmate_amd import ops
+
+    A = ops.limbs_empty(64, 64, _dev(), zero=True)
+    out = torch.empty(64, 100, device=_dev())
+    with pytest.raises(ops.SculptError):
+        ops.gemm_l3p(A, A, 64, 100, 64, out=out)        # N % 128
+    with pytest.raises(ops.SculptError):
+        ops.gemm_l3p(A, A, 64, 128, 48, out=out)        # K % 32
+    with pytest.raises(ops.SculptError):
+        ops.limbs_split(torch.zeros(8, 40, device=_dev()))
+
+
+def test_layernorm_and_attention_write_the_limbs_of_their_fp32_results():
+    import math
+
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    rows, cols = 1025, 768
+    x, gamma, beta = _rand((rows, cols), g, 3.0), _rand((cols,), g), _rand((cols,), g)
+    want = torch.empty(rows, cols, device=_dev())
+    ops.layernorm(x, gamma, beta, 1e-5, y_f32=want)
+    lt, also = ops.Limbs(rows, cols, _dev(), zero=True), torch.empty(rows, cols, device=_dev())
+    ops.layernorm(x, gamma, beta, 1e-5, y_lt=lt, y_f32=also)
+    assert torch.equal(lt.float(), want) and torch.equal(also, want)
+    # fused three-limb attention: both kernel forms (4-wave: the tokenizer's shape; pipelined 8-wave: the backbone's), with a row offset
+    for Tq, Tk, heads in ((1025, 1025, 12), (3072, 1025, 16)):
+        D = heads * 64
+        Q, K = _rand((Tq, D), g), _rand((Tk, D), g)
+        ldv = ((Tk + 63) // 64) * 64
+        Vt = torch.zeros(D, ldv, device=_dev()); Vt[:, :Tk] = _rand((D, Tk), g)
+        want = torch.empty(Tq, D, device=_dev())
+        ops.attention_f32(Q, K, Vt, want, Tq, Tk, heads, 1.0 / math.sqrt(64), None, l3=True)
+        row0 = 40
+        O = ops.Limbs(row0 + Tq, D, _dev(), zero=True)
+        ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, 1.0 / math.sqrt(64), None, l3=True, o_row0=row0)
+        got = O.float()
+        assert torch.equal(got[row0:], want) and float(got[:row0].abs().max()) == 0.0
+
+
+def test_limbs_once_forward_is_bit_identical_to_the_splitting_kernels(monkeypatch):
+    """TSR(precision="bf16l3") with the operands split once (default) against SCULPT_L3P=0 (every GEMM splits while staging): the
+    same products in the same order -> the same scene code, bit for bit; one image and a batch of two."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+    from sculptmate_amd.tsr.system import TSR
+
+    sd = synth.tsr_state(3, SMALL_CFG)
+    imgs = [torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=s, size=SMALL_CFG["cond_image_size"]))).to(_dev()) for s in (1, 2)]
+    codes = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SCULPT_L3P", flag)
+        m = TSR(SMALL_CFG, pos_embed_mode="size", precision="bf16l3")
+        m.load_state_dict(sd)
+        m.to(_dev())
+        assert m.l3p == (flag == "1")
+        m.max_batch = 2
+        with torch.no_grad():
+            codes[flag] = (m.forward(imgs[0]).clone(), m.forward(imgs).clone())
+    for a, b in zip(codes["1"], codes["0"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
