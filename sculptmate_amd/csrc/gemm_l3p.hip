@@ -37,6 +37,10 @@ struct GemmL3pArgs {
     unsigned char *out_lt;    // when set: the result leaves as limbs (limb-tiled [M][N or N/2 outputs]) instead of g.out
     int a_blocks;             // 32-row blocks allocated in A_lt
     int out_k8;               // 16-byte chunks per row of out_lt = output columns / 8
+    // XCD-aware tile order (common.h xcd_tile): the workgroups of one XCD (private L2) take a contiguous band of the tile grid -- a
+    // band of activation rows with every weight tile, or (n_major = 1, W the larger operand) a band of weight rows with every
+    // activation tile; -1 = the natural order (A/B)
+    int n_major;
 };
 
 // The epilogue when the result leaves as limbs: a lane holds four consecutive output columns of one row = one 8-byte half of a
@@ -85,40 +89,56 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
     }
 }
 
-template <int EPI, int BM>
-__global__ __launch_bounds__(256, 2) void gemm_l3p_kernel(GemmL3pArgs a) {
-    static_assert(BM == 128 || BM == 64, "128 or 64 activation rows per tile");
-    constexpr int JT = BM / 64;           // 32-row activation sub-tiles per wave
+// NW = 4: 2 x 2 waves of 2 x JT accumulator tiles (64 weight x BM / 2 activation rows per wave).  NW = 8 (BM = 128): 2 x 4 waves of
+// 2 x 1 tiles -- two waves per SIMD inside ONE workgroup, for the launches that put at most one workgroup on a CU (the backbone's
+// N = 1024 projections: 192 tiles): a lone wave per SIMD cannot hide its LDS-DMA issue and fragment-read latency behind MFMAs.
+template <int EPI, int BM, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm_l3p_kernel(GemmL3pArgs a) {
+    static_assert((BM == 128 || BM == 64) && (NW == 4 || (NW == 8 && BM == 128)), "tile forms");
+    constexpr int NWC = NW / 2;           // waves along the activation rows
+    constexpr int JT = BM / 32 / NWC;     // 32-row activation sub-tiles per wave
     constexpr int ARB = BM / 32;          // activation row blocks per tile
+    constexpr int NRB = 4 + ARB;          // row blocks per ring stage: [4 weight | ARB activation]
     constexpr int RBK = 3072;             // bytes of one K-tile (16 k = 2 chunks x 3 limbs x 512 B) of one row block
-    constexpr int STG = (4 + ARB) * RBK;  // one ring stage: [4 weight row blocks | ARB activation row blocks]
+    constexpr int STG = NRB * RBK;
     constexpr int NST = 3;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STG];
     const GemmF32Args &g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / NWC, wc = wave % NWC;
     constexpr int NOUT = (EPI == SCULPT_EPI_GEGLU) ? FBW / 2 : FBW;
-    const int n0 = blockIdx.x * NOUT, m0 = blockIdx.y * BM;
+    int nt = blockIdx.x, mt = blockIdx.y;
+    if (a.n_major >= 0) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int tile = xcd_tile(blockIdx.y * gx + blockIdx.x, gx * gy);
+        nt = a.n_major ? tile / gy : tile % gx;
+        mt = a.n_major ? tile % gy : tile / gx;
+    }
+    const int n0 = nt * NOUT, m0 = mt * BM;
     const long kblk = (long)g.K * 192;    // bytes of one 32-row block: K / 8 chunks x 3 limbs x 512
-    // staging: wave w copies weight row block w of the tile (a GEGLU weight is stored with its row blocks already in the tile's
-    // value / gate order: 4 blocks per 64 output columns) and, when w < ARB, activation row block w
-    const unsigned char *wsrc = a.W_lt + ((long)blockIdx.x * 4 + wave) * kblk + lane * 16;
-    const bool astage = wave < ARB;       // wave-uniform
-    const unsigned char *asrc = a.A_lt + (long)min((m0 >> 5) + (astage ? wave : 0), a.a_blocks - 1) * kblk + lane * 16;
-    const int wdst = wave * RBK, adst = (4 + (astage ? wave : 0)) * RBK;
+    // staging: wave w copies row block w of the stage and (when there are more blocks than waves) row block w + NW; blocks 0..3 are
+    // the tile's weight rows (a GEGLU weight is stored with its row blocks already in the tile's value / gate order: 4 blocks per
+    // 64 output columns), blocks 4.. its activation rows
+    auto src_of = [&](int rb) -> const unsigned char * {
+        return rb < 4 ? a.W_lt + ((long)nt * 4 + rb) * kblk + lane * 16
+                      : a.A_lt + (long)min((m0 >> 5) + rb - 4, a.a_blocks - 1) * kblk + lane * 16;
+    };
+    const bool two = wave + NW < NRB;     // wave-uniform
+    const unsigned char *src0 = src_of(wave), *src1 = src_of(two ? wave + NW : wave);
+    const int dst0 = wave * RBK, dst1 = (wave + NW) * RBK;
 
 #define L3P_STAGE(buf, kt)                                                                                                  \
     do {                                                                                                                    \
         unsigned char *sb = smem + (buf) * STG;                                                                             \
         const long ko = (long)(kt) * RBK;                                                                                   \
-        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(wsrc + ko), (p_lds_ptr_t)(sb + wdst), 16, 0, 0);                     \
-        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(wsrc + ko + 1024), (p_lds_ptr_t)(sb + wdst + 1024), 16, 0, 0);      \
-        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(wsrc + ko + 2048), (p_lds_ptr_t)(sb + wdst + 2048), 16, 0, 0);      \
-        if (BM == 128 || astage) {                                                                                          \
-            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(asrc + ko), (p_lds_ptr_t)(sb + adst), 16, 0, 0);                 \
-            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(asrc + ko + 1024), (p_lds_ptr_t)(sb + adst + 1024), 16, 0, 0);  \
-            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(asrc + ko + 2048), (p_lds_ptr_t)(sb + adst + 2048), 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko), (p_lds_ptr_t)(sb + dst0), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko + 1024), (p_lds_ptr_t)(sb + dst0 + 1024), 16, 0, 0);      \
+        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko + 2048), (p_lds_ptr_t)(sb + dst0 + 2048), 16, 0, 0);      \
+        if (NRB > NW && two) {                                                                                              \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko), (p_lds_ptr_t)(sb + dst1), 16, 0, 0);                 \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko + 1024), (p_lds_ptr_t)(sb + dst1 + 1024), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko + 2048), (p_lds_ptr_t)(sb + dst1 + 2048), 16, 0, 0);  \
         }                                                                                                                   \
     } while (0)
 
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_l3p_kernel(GemmL3pArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         // wait until K-tile kt has landed; K-tile kt + 1 (if issued) stays in flight
         if (kt + 1 < nk) {
-            if (BM == 128 || astage) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (NRB > NW && two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -253,13 +273,27 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const
     a.out_k8 = N / 8;
     hipStream_t st = as_stream(stream);
     const int gx = geglu ? N / 64 : N / 128;
-    const char *e64 = getenv("SCULPT_L3P_BM64");   // 0 / 1: never / always the 64-row tile (A/B); default: by CU fill
+    // XCD band order: measured equal to the natural order on every shape of the two transformers (tools/time_l3p.py; the operands
+    // sit in the Infinity Cache): off unless SCULPT_L3P_ORDER=1
+    const char *eo = getenv("SCULPT_L3P_ORDER");
+    a.n_major = (eo && atoi(eo) == 1) ? ((geglu ? 2 * N : N) > M ? 1 : 0) : -1;
+    // Tile form by the number of 128 x 128 tiles (tools/time_l3p.py, one MI355X, us; 4 waves 128 / 4 waves 64 / 8 waves 128):
+    //   image tokenizer (1025 rows)  o    54 tiles  34.7 / 24.5 / 31.0     f2   54 tiles  115.8 / 82.6 / 108.6
+    //                                qkv 162 tiles  36.8 / 36.6 / 33.4     f1  216 tiles   49.4 / 46.8 /  42.7
+    //   backbone (3072 rows)         o / q 192      52.0 / 53.5 / 49.1     FF2 192        163.6 / 175.3 / 153.6
+    //                                Q|K|V 576     127.5 / 136.5 / 124.0   FF1 1536       248.1 / 297.1 / 253.2
+    // fewer tiles than half the CUs: 64-row tiles (twice the workgroups); up to three per CU: the 8-wave form (two waves per SIMD
+    // even where a CU holds one workgroup); more: 4 waves, two workgroups per CU.
+    const char *e64 = getenv("SCULPT_L3P_BM64");   // 0 / 1: never / always the 64-row tile (A/B)
+    const char *e8 = getenv("SCULPT_L3P_NW8");     // 0 / 1: never / always 8 waves on the 128-row tile (A/B)
     const long tiles128 = (long)gx * cdiv(M, 128);
-    const bool bm64 = e64 ? atoi(e64) != 0 : tiles128 < 2L * num_cus();
+    const bool bm64 = e64 ? atoi(e64) != 0 : 2 * tiles128 < num_cus();
+    const bool nw8 = !bm64 && (e8 ? atoi(e8) != 0 : tiles128 <= 3L * num_cus());
 #define L3P_GO(E)                                                                                                      \
     do {                                                                                                               \
-        if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);            \
-        else hipLaunchKernelGGL((gemm_l3p_kernel<E, 128>), dim3(gx, cdiv(M, 128)), dim3(256), 0, st, a);               \
+        if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64, 4>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);         \
+        else if (nw8) hipLaunchKernelGGL((gemm_l3p_kernel<E, 128, 8>), dim3(gx, cdiv(M, 128)), dim3(512), 0, st, a);   \
+        else hipLaunchKernelGGL((gemm_l3p_kernel<E, 128, 4>), dim3(gx, cdiv(M, 128)), dim3(256), 0, st, a);            \
     } while (0)
     if (geglu) L3P_GO(SCULPT_EPI_GEGLU);
     else if (epilogue == SCULPT_EPI_GELU) L3P_GO(SCULPT_EPI_GELU);

@@ -34,12 +34,17 @@ for name, M, N, K, epi, per_fwd in (("backbone QKV", 3072, 3072, 1024, 0, 16), (
     variants = {"old": f_old}
     for bm in ("0", "1"):
         def f_new(bm=bm):
-            os.environ["SCULPT_L3P_BM64"] = bm
+            os.environ["SCULPT_L3P_BM64"] = bm; os.environ["SCULPT_L3P_NW8"] = "0"
             ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=o2, epilogue=epi)
         variants["new bm%s" % ("64" if bm == "1" else "128")] = f_new
+    def f_nw8():
+        os.environ["SCULPT_L3P_BM64"] = "0"; os.environ["SCULPT_L3P_NW8"] = "1"
+        ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=o2, epilogue=epi)
+        os.environ.pop("SCULPT_L3P_NW8", None)
+    variants["new bm128 8 waves"] = f_nw8
     out_lt = ops.limbs_empty(M, N, dev)
     def f_lt():
-        os.environ.pop("SCULPT_L3P_BM64", None)
+        os.environ.pop("SCULPT_L3P_BM64", None); os.environ.pop("SCULPT_L3P_NW8", None)
         ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out_lt=out_lt, epilogue=epi)
     variants["new, limb output"] = f_lt
     variants["split of A alone"] = lambda: ops.limbs_split(A, out=A_lt)
@@ -51,7 +56,7 @@ for name, M, N, K, epi, per_fwd in (("backbone QKV", 3072, 3072, 1024, 0, 16), (
             res.setdefault(k, []).append(timed(f))
     med = {k: float(np.median(v)) for k, v in res.items()}
     fl = 2.0 * M * rows * K * 6
-    best = min(med["new bm128"], med["new bm64"])
+    best = min(med["new bm128"], med["new bm64"], med["new bm128 8 waves"])
     tot_old += per_fwd * med["old"]; tot_new += per_fwd * best
     print("%-20s M=%d N=%d K=%d: " % (name, M, rows, K) + " | ".join("%s %.1f us (%.2f PF/s)" % (k, v, fl / v / 1e9) if "split" not in k else "%s %.1f us" % (k, v) for k, v in med.items())
           + " | identical %s" % same, flush=True)
