@@ -47,7 +47,8 @@ extern "C" {
  *    (bias 16-byte aligned; without a bias at most 65 532 output columns, see there)
  * 3: the two-pass dense density grid (sculpt_density_grid_filtered, sculpt_density_filter_workspace_bytes,
  *    sculpt_density_filter_stats); added without a version change (new symbols only): sculpt_limbs_bytes, sculpt_limbs_split,
- *    sculpt_gemm_l3p, sculpt_layernorm_limbs, sculpt_attention_f32_l3_limbs */
+ *    sculpt_gemm_l3p, sculpt_layernorm_limbs, sculpt_attention_f32_l3_limbs, sculpt_mc_count_launch, sculpt_mc_count_read,
+ *    sculpt_mc_emit_capped */
 #define SCULPT_ABI_VERSION 3
 
 typedef void *sculpt_stream_t;
@@ -213,6 +214,22 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsig
                    void *workspace, float vert_div, float vert_mul, float vert_add,
                    int axis0_offset /* slab: global index of lattice plane 0 */,
                    float *verts, void *faces, int *top_plane_map /* or NULL */, sculpt_stream_t stream);
+/* The same two phases without the host round trip between them (the stream otherwise idles while the host reads the counts,
+ * allocates and launches: ~50 us of a 0.28 ms stage at 256^3):
+ *   sculpt_mc_count_launch  the count phase, launched only: the totals stay in the workspace header;
+ *   sculpt_mc_emit_capped   the emit phase into buffers of cap_verts vertices / cap_faces faces sized by the CALLER'S ESTIMATE
+ *                           (e.g. the previous mesh + 25 %); the kernels read the totals on the device and write NOTHING when the
+ *                           mesh does not fit either buffer;
+ *   sculpt_mc_count_read    synchronises the stream and returns the totals with sculpt_mc_count's error semantics: when they exceed
+ *                           the capacities the caller allocates exactly and calls sculpt_mc_emit.
+ * sculpt_mc_count == launch + read; sculpt_mc_emit == emit_capped with unbounded capacities. */
+int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
+                           sculpt_stream_t stream);
+int sculpt_mc_count_read(int n0, int n1, int n2, double level, unsigned flags, const void *workspace, int64_t *n_verts_host,
+                         int64_t *n_faces_host, float *minmax_host /* [2] or NULL */, sculpt_stream_t stream);
+int sculpt_mc_emit_capped(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace, float vert_div,
+                          float vert_mul, float vert_add, int axis0_offset, float *verts, int64_t cap_verts, void *faces,
+                          int64_t cap_faces, int *top_plane_map /* or NULL */, sculpt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Transformer primitives (bf16 storage, fp32 accumulate).  bf16 values are uint16_t bit patterns.

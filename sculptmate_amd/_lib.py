@@ -88,6 +88,9 @@ SIGNATURES = {
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "sculpt_mc_count_launch": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _vp]),
+    "sculpt_mc_count_read": (_i, [_i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
+    "sculpt_mc_emit_capped": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _i64, _vp, _i64, _vp, _vp]),
     "sculpt_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_bf16_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_bf16_ln": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

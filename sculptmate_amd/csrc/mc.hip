@@ -958,7 +958,11 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(const float *__restr
                                                             const unsigned *__restrict__ vert_ofs,
                                                             const unsigned long long *__restrict__ group_base,
                                                             int *__restrict__ edge_map, float *__restrict__ verts,
-                                                            float vdiv, float vmul, float vadd, int affine) {
+                                                            float vdiv, float vmul, float vadd, int affine,
+                                                            unsigned long long cap_vert, unsigned long long cap_tri) {
+  // speculative emit (sculpt_mc_emit_capped): the buffers were sized before the counts were read back; a mesh that does not fit
+  // writes nothing at all (the caller sees the counts, allocates and emits again)
+  if (hdr->total_vert > cap_vert || hdr->total_tri > cap_tri) return;
   const unsigned total_active = hdr->total_active;
   for (unsigned ci = blockIdx.x * MC_BLOCK + threadIdx.x; ci < total_active; ci += gridDim.x * MC_BLOCK) {
     int b, k, x, y, z;
@@ -1039,7 +1043,9 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(Grid g, const CellRe
                                                             const unsigned *__restrict__ vert_ofs,
                                                             const unsigned long long *__restrict__ group_base,
                                                             const int *__restrict__ edge_map, IdxT *__restrict__ faces,
-                                                            int ref_order) {
+                                                            int ref_order, unsigned long long cap_vert,
+                                                            unsigned long long cap_tri) {
+  if (hdr->total_vert > cap_vert || hdr->total_tri > cap_tri) return;
   const unsigned total_active = hdr->total_active;
   for (unsigned ci = blockIdx.x * MC_BLOCK + threadIdx.x; ci < total_active; ci += gridDim.x * MC_BLOCK) {
     int b, k, x, y, z;
@@ -1153,13 +1159,13 @@ size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2) {
     return ws_layout(g).total;
 }
 
-int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
-                    int64_t *n_verts_host, int64_t *n_faces_host, float *minmax_host, sculpt_stream_t stream) {
+int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
+                           sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     Grid g;
     if (int rc = make_grid(n0, n1, n2, &g)) return rc;
     g.halo_low = (flags & SCULPT_MC_SLAB_HALO_LOW) ? 1 : 0;
-    SC_REQUIRE(vol && workspace && n_verts_host && n_faces_host, "mc_count: null argument");
+    SC_REQUIRE(vol && workspace, "mc_count: null argument");
     if (int rc = upload_tables()) return rc;
     const WsLayout w = ws_layout(g);
     char *ws = reinterpret_cast<char *>(workspace);
@@ -1197,6 +1203,15 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsi
                        reinterpret_cast<const float2 *>(ws + w.off_gmm), w.ngroups, hdr,
                        reinterpret_cast<unsigned *>(ws + w.off_gact));
     SC_LAUNCH_CHECK();
+    return 0;
+}
+
+int sculpt_mc_count_read(int n0, int n1, int n2, double level, unsigned flags, const void *workspace, int64_t *n_verts_host,
+                         int64_t *n_faces_host, float *minmax_host, sculpt_stream_t stream) {
+    hipStream_t st = as_stream(stream);
+    (void)n0; (void)n1; (void)n2;
+    SC_REQUIRE(workspace && n_verts_host && n_faces_host, "mc_count: null argument");
+    const McHeader *hdr = reinterpret_cast<const McHeader *>(workspace);
     McHeader res;
     SC_HIP(hipMemcpyAsync(&res, hdr, sizeof(res), hipMemcpyDeviceToHost, st));
     SC_HIP(hipStreamSynchronize(st));
@@ -1222,10 +1237,19 @@ int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsi
     return 0;
 }
 
-int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
-                   float vert_div, float vert_mul, float vert_add, int axis0_offset, float *verts, void *faces,
-                   int *top_plane_map, sculpt_stream_t stream) {
+int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
+                    int64_t *n_verts_host, int64_t *n_faces_host, float *minmax_host, sculpt_stream_t stream) {
+    SC_REQUIRE(n_verts_host && n_faces_host, "mc_count: null argument");
+    if (int rc = sculpt_mc_count_launch(vol, n0, n1, n2, level, flags, workspace, stream)) return rc;
+    return sculpt_mc_count_read(n0, n1, n2, level, flags, workspace, n_verts_host, n_faces_host, minmax_host, stream);
+}
+
+int sculpt_mc_emit_capped(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
+                          float vert_div, float vert_mul, float vert_add, int axis0_offset, float *verts, int64_t cap_verts,
+                          void *faces, int64_t cap_faces, int *top_plane_map, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
+    SC_REQUIRE(cap_verts >= 0 && cap_faces >= 0, "mc_emit: negative capacity");
+    const unsigned long long cv = (unsigned long long)cap_verts, cf = (unsigned long long)cap_faces;
     Grid g;
     if (int rc = make_grid(n0, n1, n2, &g)) return rc;
     g.halo_low = (flags & SCULPT_MC_SLAB_HALO_LOW) ? 1 : 0;
@@ -1246,14 +1270,14 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsig
     // packed active cells, grid-stride (the count lives in the workspace header: no second read-back)
     const int egrid = std::min(w.nblocks, num_cus() * 16);
     hipLaunchKernelGGL(mc_verts_kernel, dim3(egrid), dim3(MC_BLOCK), 0, st, vol, g, (double)level, recs, ai, hdr, vrt,
-                       gbase, emap, verts, vert_div, vert_mul, vert_add, ref);
+                       gbase, emap, verts, vert_div, vert_mul, vert_add, ref, cv, cf);
     SC_LAUNCH_CHECK();
     if (flags & SCULPT_MC_FACES_I64)
         hipLaunchKernelGGL(mc_faces_kernel<long long>, dim3(egrid), dim3(MC_BLOCK), 0, st, g, recs, ai, hdr, tri, vrt,
-                           gbase, emap, reinterpret_cast<long long *>(faces), ref);
+                           gbase, emap, reinterpret_cast<long long *>(faces), ref, cv, cf);
     else
         hipLaunchKernelGGL(mc_faces_kernel<int>, dim3(egrid), dim3(MC_BLOCK), 0, st, g, recs, ai, hdr, tri, vrt, gbase,
-                           emap, reinterpret_cast<int *>(faces), ref);
+                           emap, reinterpret_cast<int *>(faces), ref, cv, cf);
     SC_LAUNCH_CHECK();
     if (top_plane_map) {
         hipLaunchKernelGGL(mc_top_plane_kernel, dim3(cdiv(2L * n1 * n2, 256)), dim3(256), 0, st, vol, g, (double)level,
@@ -1261,6 +1285,13 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsig
         SC_LAUNCH_CHECK();
     }
     return 0;
+}
+
+int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
+                   float vert_div, float vert_mul, float vert_add, int axis0_offset, float *verts, void *faces,
+                   int *top_plane_map, sculpt_stream_t stream) {
+    return sculpt_mc_emit_capped(vol, n0, n1, n2, level, flags, workspace, vert_div, vert_mul, vert_add, axis0_offset, verts,
+                                 INT64_MAX, faces, INT64_MAX, top_plane_map, stream);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@ torch is plumbing here: it owns HBM allocations and the current HIP stream; ever
 passes raw device pointers + sizes into libsculpt_hip.so.  No function has a CPU path.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -261,15 +262,36 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
         off = int(slab.get("axis0_offset", 0))
     nv, nf = ctypes.c_int64(), ctypes.c_int64()
     mm = (ctypes.c_float * 2)()
-    rc = lib.sculpt_mc_count(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), ctypes.byref(nv),
-                             ctypes.byref(nf), ctypes.cast(mm, ctypes.c_void_p), _stream())
+    fdt = torch.int64 if reference_order else torch.int32
+    # Speculative emit: a call of a shape / flag combination seen before sizes its outputs by the largest mesh so far + 25 % and
+    # queues count AND emit before it reads the counts back, so the stream does not idle through the host's read-allocate-launch
+    # round trip; the emit kernels write nothing when the mesh does not fit, and the exact path below runs instead.
+    key = (vol.device, n0, n1, n2, flags)
+    cap = _MC_CAPACITY.get(key) if (slab is None and _MC_SPECULATE) else None
+    verts = faces = None
+    if cap is not None:
+        check(lib.sculpt_mc_count_launch(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), _stream()))
+        verts = torch.empty((cap[0], 3), dtype=torch.float32, device=vol.device)
+        faces = torch.empty((cap[1], 3), dtype=fdt, device=vol.device)
+        check(lib.sculpt_mc_emit_capped(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), float(vert_div), float(vert_mul),
+                                        float(vert_add), off, _ptr(verts), cap[0], _ptr(faces), cap[1], None, _stream()))
+        rc = lib.sculpt_mc_count_read(n0, n1, n2, float(level), flags, _ptr(ws), ctypes.byref(nv), ctypes.byref(nf),
+                                      ctypes.cast(mm, ctypes.c_void_p), _stream())
+    else:
+        rc = lib.sculpt_mc_count(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), ctypes.byref(nv),
+                                 ctypes.byref(nf), ctypes.cast(mm, ctypes.c_void_p), _stream())
     if rc == _lib.ERR_MC_LEVEL:
         raise ValueError(_lib.last_error())
     if rc == _lib.ERR_MC_EMPTY:
         raise RuntimeError(_lib.last_error())
     check(rc)
+    if slab is None and _MC_SPECULATE:
+        old = _MC_CAPACITY.get(key, (0, 0))
+        _MC_CAPACITY[key] = (max(old[0], nv.value + nv.value // 4 + 1024), max(old[1], nf.value + nf.value // 4 + 1024))
+    if cap is not None and nv.value <= cap[0] and nf.value <= cap[1]:
+        return verts[:nv.value], faces[:nf.value]      # views of the capacity-sized buffers (fresh per call)
     verts = torch.empty((nv.value, 3), dtype=torch.float32, device=vol.device)
-    faces = torch.empty((nf.value, 3), dtype=torch.int64 if reference_order else torch.int32, device=vol.device)
+    faces = torch.empty((nf.value, 3), dtype=fdt, device=vol.device)
     top = torch.empty((2, n1, n2), dtype=torch.int32, device=vol.device) if slab is not None else None
     if nv.value > 0 or slab is not None:
         # dummy non-null pointers for empty outputs
@@ -280,6 +302,10 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     if slab is not None:
         return verts, faces, top, (float(mm[0]), float(mm[1]))
     return verts, faces
+
+
+_MC_CAPACITY = {}     # (device, n0, n1, n2, flags) -> (vertex capacity, face capacity) of the speculative emit
+_MC_SPECULATE = os.environ.get("SCULPT_MC_SPECULATE", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------------

@@ -151,3 +151,42 @@ def test_nan_volume_is_reported(cuda):
     vol[5, 6, 7] = 0.5
     v, f = ops.marching_cubes(vol, 0.0)
     assert v.shape[0] > 0
+
+
+def test_speculative_emit_equals_the_two_phase_path(cuda, monkeypatch):
+    """ops.marching_cubes queues count and emit before it reads the counts back once it has seen a shape (buffers sized by the
+    largest mesh so far + 25 %): the same vertices and faces as the count -> allocate -> emit path, whether the mesh fits the
+    estimate, is far smaller, or does not fit (nothing written, exact path instead); the error cases keep their exceptions."""
+    from sculptmate_amd import ops
+
+    shape = (48, 50, 52)
+    rng = np.random.default_rng(11)
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n, dtype=np.float32) for n in shape], indexing="ij")
+    small = (0.3 - np.sqrt(xx ** 2 + yy ** 2 + zz ** 2)).astype(np.float32)            # one small sphere
+    medium = (0.7 - np.sqrt(xx ** 2 + yy ** 2 + zz ** 2)).astype(np.float32)
+    noise = rng.standard_normal(shape).astype(np.float32)                                # far more surface than any estimate
+    vols = [torch.from_numpy(v).to(cuda) for v in (medium, medium * 1.01, small, noise, noise, medium)]
+    monkeypatch.setattr(ops, "_MC_SPECULATE", False)
+    want = [ops.marching_cubes(v, 0.0, reference_order=True, vert_div=51.0) for v in vols]
+    monkeypatch.setattr(ops, "_MC_SPECULATE", True)
+    monkeypatch.setattr(ops, "_MC_CAPACITY", {})
+    for i, v in enumerate(vols):
+        gv, gf = ops.marching_cubes(v, 0.0, reference_order=True, vert_div=51.0)
+        assert gf.dtype == torch.int64 and torch.equal(gv, want[i][0]) and torch.equal(gf, want[i][1]), i
+        assert gv.is_contiguous() and gf.is_contiguous()
+    (cap,) = ops._MC_CAPACITY.values()
+    assert cap[0] >= want[3][0].shape[0] and cap[1] >= want[3][1].shape[0]              # grown by the overflowing call
+    # error semantics on the speculative path (the shape has a capacity now)
+    with pytest.raises(ValueError):
+        ops.marching_cubes(torch.ones(shape, device=cuda), 0.0, reference_order=True, vert_div=51.0)
+    e = -torch.ones(shape, device=cuda)
+    e[1, 1, 1] = 0.0
+    with pytest.raises(RuntimeError):
+        ops.marching_cubes(e, 0.0, reference_order=True, vert_div=51.0)
+    bad = vols[0].clone()
+    bad[5, 5, 5] = float("nan")
+    with pytest.raises(ops.SculptError):
+        ops.marching_cubes(bad, 0.0, reference_order=True, vert_div=51.0)
+    # and a good call afterwards is still right
+    gv, gf = ops.marching_cubes(vols[0], 0.0, reference_order=True, vert_div=51.0)
+    assert torch.equal(gv, want[0][0]) and torch.equal(gf, want[0][1])
