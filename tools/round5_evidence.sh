@@ -5,6 +5,7 @@
 #      tools/stress_filter.py          8 images x 3 levels at 256^3 through TSR.extract_meshes, filtered vs unfiltered, bit for bit
 #   3. tools/gemm_bm192_ab.py           128 x 64 tiles against one round of 192 x 64 tiles
 #   4. tools/blas_kernel_names.sh       which kernels hipBLASLt runs on the big shapes (calibration only)
+#   6. tools/time_l3p.py             the tolerance mode's Linears: splitting kernel against limbs once (gemm_l3p), tile forms
 #   5. kernel traces of the batched (B = 4) bf16 forward and of the bf16l3 forward (from the final code)
 set -x
 cd /tmp && export TMPDIR=/tmp
@@ -22,5 +23,6 @@ cp $(find $OUT/l3 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_l3.csv
 python3 tools/time_batched.py > $OUT/batched_forward.txt 2>&1
 tools/pmc_batched.sh > $OUT/pmc_batched.txt 2>&1
 python3 tools/time_parity_modes.py > $OUT/parity_modes.txt 2>&1
+python3 tools/time_l3p.py > $OUT/l3p_gemm.txt 2>&1
 find $OUT -name "*.csv" -size +8M -delete
 ls -la $OUT
