@@ -56,7 +56,7 @@ for name, M, N, K, epi, per_fwd in (("backbone QKV", 3072, 3072, 1024, 0, 16), (
             res.setdefault(k, []).append(timed(f))
     med = {k: float(np.median(v)) for k, v in res.items()}
     fl = 2.0 * M * rows * K * 6
-    best = min(med["new bm128"], med["new bm64"], med["new bm128 8 waves"])
+    best = min(v for k, v in med.items() if k.startswith("new") and "limb" not in k)
     tot_old += per_fwd * med["old"]; tot_new += per_fwd * best
     print("%-20s M=%d N=%d K=%d: " % (name, M, rows, K) + " | ".join("%s %.1f us (%.2f PF/s)" % (k, v, fl / v / 1e9) if "split" not in k else "%s %.1f us" % (k, v) for k, v in med.items())
           + " | identical %s" % same, flush=True)
