@@ -713,6 +713,12 @@ def geglu_row_blocks(W):
 
 def gemm_l3p(A_lt, W_lt, M, N, K, bias=None, residual=None, out=None, out_t=None, n_split=0, out_lt=None, epilogue=0):
     """sculpt_gemm_l3p: the three-limb GEMM on operands split once (A_lt [M][K], W_lt [N or 2N][K] limb-tiled; Limbs or raw)."""
+    rows_w = 2 * N if epilogue == _lib.EPI_GEGLU else N
+    for t, r, c, what in ((A_lt, M, K, "A"), (W_lt, rows_w, K, "W"), (out_lt, M, N, "out")):
+        if isinstance(t, Limbs):
+            assert t.cols == c and t.rows >= r, "gemm_l3p: %s is a limb-tiled [%d][%d], the call needs [>= %d][%d]" % (what, t.rows, t.cols, r, c)
+        elif t is not None:
+            assert t.numel() * t.element_size() >= limbs_bytes(r, c), "gemm_l3p: %s holds fewer bytes than a limb-tiled [%d][%d]" % (what, r, c)
     A_lt, W_lt = getattr(A_lt, "data", A_lt), getattr(W_lt, "data", W_lt)
     out_lt = getattr(out_lt, "data", out_lt)
     check(lib.sculpt_gemm_l3p(_ptr(A_lt), _ptr(W_lt), _ptr(bias), _ptr(residual), residual.stride(0) if residual is not None else 0,

@@ -291,7 +291,9 @@ class TSR(KernelEngine):
         sd, cfg = self._sd, self.cfg
         wt = _bf if self.precision == "bf16" else _f32  # GEMM weight storage
         # "limbs once" (engine.py): in the three-limb mode the Linears of the two transformers keep their weights split
-        self.l3p = self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0"
+        # (the attention must be the fused kernel: the three-launch composition, SCULPT_L3_ATTN_FUSED=0, has no limb output)
+        self.l3p = (self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0"
+                    and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0")
         wh = (lambda x, d, geglu=False: ops.Limbs.of(_f32(ops.geglu_row_blocks(torch.as_tensor(x)) if geglu else x, d))) if self.l3p \
             else (lambda x, d, geglu=False: wt(x, d))
         v, b = cfg["image_tokenizer"], cfg["backbone"]
