@@ -348,6 +348,8 @@ def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps):
            "transformer_tflops_algorithmic": None, "steps_timed": n}
     out["transformer_tflops_algorithmic"] = 2.96 / (out["forward_ms"] * 1e-3)
     out["mfma_executed_tflops"] = 6 * 2.96 / (out["forward_ms"] * 1e-3)
+    # operands split once (weights at load time, activations by their producers; csrc/gemm_l3p.hip) -- SCULPT_L3P=0: in every GEMM
+    out["limbs_once"] = bool(getattr(m, "l3p", False))
     if cpu_verts is not None:
         gm = m.run_async(imgs_np[0], 128, THRESHOLD).result()
         d = mesh_distance(gm.vertices, cpu_verts, 1.74)

@@ -255,3 +255,39 @@ def test_bench_refuses_rank_count_mismatch():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "needs 2 ranks" in (p.stderr + p.stdout)
     assert p.stdout.strip() == ""            # no JSON line
+
+
+def test_limb_tiled_layout_helpers_follow_the_documented_offsets():
+    """The limb-tiled layout of include/sculpt_hip.h / csrc/limbs.h, host side: ops.limbs_join inverts an array assembled element by
+    element from the documented byte offset; ops.geglu_row_blocks orders a GEGLU weight the way gemm_l3p's tiles read it
+    (csrc/gemm_f32.h f32_tile_wrow: tile row j -> value / gate row)."""
+    import numpy as np
+    import torch
+
+    from sculptmate_amd import ops
+
+    rng = np.random.default_rng(0)
+    R, K = 45, 64
+    x = (rng.standard_normal((R, K)) * np.exp2(rng.integers(-20, 20, (R, K)))).astype(np.float32)
+    xt = torch.from_numpy(x)
+    l1 = xt.to(torch.bfloat16)
+    r1 = xt - l1.float()
+    l2 = r1.to(torch.bfloat16)
+    l3 = (r1 - l2.float()).to(torch.bfloat16)
+    assert torch.equal((l1.float() + l2.float()) + l3.float(), xt)          # three bf16 limbs carry an fp32 value exactly
+    nbytes = ops.limbs_bytes(R, K)
+    assert nbytes == 2 * K * 192
+    flat = torch.zeros(nbytes // 2, dtype=torch.bfloat16)
+    for l, limb in enumerate((l1, l2, l3)):
+        for r in range(R):
+            for k in range(K):
+                flat[((((r // 32) * (K // 8) + k // 8) * 3 + l) * 512 + (r % 32) * 16 + (k % 8) * 2) // 2] = limb[r, k]
+    assert torch.equal(ops.limbs_join(flat.view(torch.uint8), R, K), xt)
+    # GEGLU: 2N rows (value rows, then gate rows) -> per 64 output columns the four 32-row blocks value, gate, value, gate
+    N = 128
+    W = torch.arange(2 * N, dtype=torch.float32)[:, None].repeat(1, 4)
+    P = ops.geglu_row_blocks(W)
+    for t in range(N // 64):
+        for j in range(128):
+            sub, within = j >> 5, j & 31
+            assert int(P[t * 128 + j, 0]) == ((N if (sub & 1) else 0) + t * 64 + (sub >> 1) * 32 + within)
