@@ -350,6 +350,24 @@ def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps):
     out["mfma_executed_tflops"] = 6 * 2.96 / (out["forward_ms"] * 1e-3)
     # operands split once (weights at load time, activations by their producers; csrc/gemm_l3p.hip) -- SCULPT_L3P=0: in every GEMM
     out["limbs_once"] = bool(getattr(m, "l3p", False))
+    try:   # the same mode with four images per transformer pass (TSR.forward on a list; every attention one launch over batch x heads)
+        keep = m.max_batch
+        m.max_batch = 4
+        group = [imgs[i % len(imgs)] for i in range(4)]
+        m(group, device=m.device)
+        torch.cuda.synchronize()
+        tb = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            m(group, device=m.device)
+            b.record()
+            torch.cuda.synchronize()
+            tb.append(a.elapsed_time(b))
+        out["batched4_forward_ms_per_image"] = float(np.median(tb)) / 4
+        m.max_batch = keep
+    except Exception as e:  # noqa: BLE001
+        out["batched4_forward_ms_per_image"] = "%s: %s" % (type(e).__name__, e)
     if cpu_verts is not None:
         gm = m.run_async(imgs_np[0], 128, THRESHOLD).result()
         d = mesh_distance(gm.vertices, cpu_verts, 1.74)

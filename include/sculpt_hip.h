@@ -48,7 +48,7 @@ extern "C" {
  * 3: the two-pass dense density grid (sculpt_density_grid_filtered, sculpt_density_filter_workspace_bytes,
  *    sculpt_density_filter_stats); added without a version change (new symbols only): sculpt_limbs_bytes, sculpt_limbs_split,
  *    sculpt_gemm_l3p, sculpt_layernorm_limbs, sculpt_attention_f32_l3_limbs, sculpt_mc_count_launch, sculpt_mc_count_read,
- *    sculpt_mc_emit_capped */
+ *    sculpt_mc_emit_capped, sculpt_attention_f32_l3_batched */
 #define SCULPT_ABI_VERSION 3
 
 typedef void *sculpt_stream_t;
@@ -336,6 +336,13 @@ int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const fl
                            int rows, int cols, sculpt_stream_t stream);
 int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt, int o_row0,
                                   int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream);
+/* `batch` fused three-limb attentions of one shape in ONE launch (TSR.forward on a list of images in the tolerance mode): entry b
+ * reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (element strides, multiples of 4; vt_bs may be a column offset into one
+ * [heads*64][ldvt] array) and writes O + b*o_bs -- or, with O null and O_lt given, rows o_row0 + b*o_row_bs .. of the limb-tiled
+ * output of o_cols columns. */
+int sculpt_attention_f32_l3_batched(const float *Q, int ldq, int64_t q_bs, const float *K, int ldk, int64_t k_bs, const float *Vt,
+                                    int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt, int o_row0, int o_row_bs,
+                                    int o_cols, int Tq, int Tk, int heads, int batch, float scale, sculpt_stream_t stream);
 int sculpt_limbs_split(const float *src, int ld, int rows, int K, void *dst, sculpt_stream_t stream);
 int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const float *residual, int ldr, float *out, int ldo,
                     float *out_t, int ldt, int n_split, void *out_lt, int M, int N, int K, int epilogue, sculpt_stream_t stream);

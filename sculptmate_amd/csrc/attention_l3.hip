@@ -62,11 +62,18 @@ __device__ __forceinline__ void al_split8(const float (&x)[8], abf16x8 &f1, abf1
     f3 = __builtin_bit_cast(abf16x8, v3);
 }
 
+// blockIdx.z = batch entry (`batch` independent attentions of one shape in one launch): element strides of Q, K, Vt (a column
+// offset when the V^T of the entries sit side by side) and O; for a limb output the entry's first ROW
+struct AttnL3Batch { long q_bs, k_bs, vt_bs, o_bs; int o_row_bs; };
+
 __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
                                                               const float *__restrict__ Vt, int ldvt, float *__restrict__ O, int ldo,
-                                                              int Tq, int Tk, float scale_log2e, unsigned char *__restrict__ O_lt = nullptr,
-                                                              int o_row0 = 0, int o_k8 = 0) {
+                                                              int Tq, int Tk, float scale_log2e, unsigned char *__restrict__ O_lt,
+                                                              int o_row0, int o_k8, AttnL3Batch ab) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AL_OP];   // [K limbs | V^T limbs]
+    Q += blockIdx.z * ab.q_bs; K += blockIdx.z * ab.k_bs; Vt += blockIdx.z * ab.vt_bs;
+    if (O) O += blockIdx.z * ab.o_bs;
+    o_row0 += blockIdx.z * ab.o_row_bs;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qc = lane & 31, h = lane >> 5;
@@ -312,9 +319,12 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void attention_l3_pipe_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K,
                                                                    int ldk, const float *__restrict__ Vt, int ldvt,
                                                                    float *__restrict__ O, int ldo, int Tq, int Tk, float scale_log2e,
-                                                                   unsigned char *__restrict__ O_lt = nullptr, int o_row0 = 0, int o_k8 = 0) {
+                                                                   unsigned char *__restrict__ O_lt, int o_row0, int o_k8, AttnL3Batch ab) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * AL_OP];   // [K limbs | V^T limbs]
+    Q += blockIdx.z * ab.q_bs; K += blockIdx.z * ab.k_bs; Vt += blockIdx.z * ab.vt_bs;
+    if (O) O += blockIdx.z * ab.o_bs;
+    o_row0 += blockIdx.z * ab.o_row_bs;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qc = lane & 31, h = lane >> 5;
@@ -540,7 +550,11 @@ __global__ __launch_bounds__(NW * 64) void attention_l3_pipe_kernel(const float 
 using namespace sculpt;
 
 static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, void *O_lt,
-                           int o_row0, int o_k8, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
+                           int o_row0, int o_k8, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream, int batch = 1,
+                           AttnL3Batch ab = AttnL3Batch{0, 0, 0, 0, 0}) {
+    SC_REQUIRE(batch >= 1 && batch <= 65535, "attention_f32_l3: bad batch %d", batch);
+    SC_REQUIRE(batch == 1 || (ab.q_bs % 4 == 0 && ab.k_bs % 4 == 0 && ab.vt_bs % 4 == 0 && ab.o_bs % 4 == 0 && ab.o_row_bs >= 0),
+               "attention_f32_l3: batch strides must be multiples of 4 elements");
     SC_REQUIRE(Q && K && Vt && (O || O_lt), "attention_f32_l3: null argument");
     SC_REQUIRE(Tq >= 1 && Tk >= 1 && heads >= 1 && heads <= 65535, "attention_f32_l3: bad shape Tq=%d Tk=%d heads=%d", Tq, Tk, heads);
     SC_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldvt % 4 == 0 && ldo % 4 == 0, "attention_f32_l3: row strides must keep 16-byte alignment");
@@ -552,13 +566,13 @@ static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, con
     // the pipelined 8-wave form (256 queries per workgroup) where it keeps at least 2/3 of the CUs busy -- the backbone's 3072
     // queries x 16 heads = 192 workgroups --; otherwise (the image tokenizer: 1025 queries x 12 heads) the plain 4-wave form
     const char *e = getenv("SCULPT_L3_ATTN_PIPE");   // 0 / 1: never / always the pipelined form (A/B); read per call
-    const bool pipe = e ? atoi(e) != 0 : (long)cdiv(Tq, 256) * heads * 3 >= 2L * num_cus();
+    const bool pipe = e ? atoi(e) != 0 : (long)cdiv(Tq, 256) * heads * batch * 3 >= 2L * num_cus();
     if (!pipe)
-        hipLaunchKernelGGL(attention_l3_kernel, dim3(cdiv(Tq, 128), heads), dim3(256), 0, as_stream(stream), Q, ldq, K, ldk, Vt, ldvt, O,
-                           ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8);
+        hipLaunchKernelGGL(attention_l3_kernel, dim3(cdiv(Tq, 128), heads, batch), dim3(256), 0, as_stream(stream), Q, ldq, K, ldk, Vt,
+                           ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8, ab);
     else
-        hipLaunchKernelGGL(attention_l3_pipe_kernel<8>, dim3(cdiv(Tq, 256), heads), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk, Vt,
-                           ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8);
+        hipLaunchKernelGGL(attention_l3_pipe_kernel<8>, dim3(cdiv(Tq, 256), heads, batch), dim3(512), 0, as_stream(stream), Q, ldq, K, ldk,
+                           Vt, ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8, ab);
     SC_LAUNCH_CHECK();
     return 0;
 }
@@ -573,4 +587,17 @@ extern "C" int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const floa
                                              int o_row0, int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
     SC_REQUIRE(O_lt && o_cols % 32 == 0, "attention_f32_l3_limbs: null output or o_cols=%d not a multiple of 32", o_cols);
     return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, nullptr, 0, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream);
+}
+
+/* `batch` attentions of one shape in ONE launch (grid z): entry b reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (element strides,
+ * multiples of 4; vt_bs may be a column offset into one [heads*64][ldvt] array) and writes O + b*o_bs, or -- O_lt given, O null --
+ * rows o_row0 + b*o_row_bs .. of the limb-tiled output. */
+extern "C" int sculpt_attention_f32_l3_batched(const float *Q, int ldq, int64_t q_bs, const float *K, int ldk, int64_t k_bs,
+                                               const float *Vt, int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt,
+                                               int o_row0, int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch, float scale,
+                                               sculpt_stream_t stream) {
+    SC_REQUIRE((O != nullptr) != (O_lt != nullptr), "attention_f32_l3_batched: exactly one of O / O_lt");
+    SC_REQUIRE(!O_lt || o_cols % 32 == 0, "attention_f32_l3_batched: o_cols=%d not a multiple of 32", o_cols);
+    return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, O, ldo, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream, batch,
+                           AttnL3Batch{(long)q_bs, (long)k_bs, (long)vt_bs, (long)o_bs, o_row_bs});
 }

@@ -111,6 +111,8 @@ class KernelEngine:
             Tkp = ((Tk + 31) // 32) * 32 if self.l3 else ((Tk + 15) // 16) * 16
             assert (batch - 1) * vt_bs + Tkp <= Vt.shape[1], "V^T too narrow for the last batch entry (%d + %d > %d)" % (
                 (batch - 1) * vt_bs, Tkp, Vt.shape[1])
+        if fused and batch > 1:   # one launch over batch x heads (grid z), fp32 or limb output
+            return ops.attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
         for b in range(batch):
             q, k = Q[b * q_bs // Q.stride(0):] if b else Q, K[b * k_bs // K.stride(0):] if b else K
             vt = Vt[:, b * vt_bs:] if b else Vt

@@ -731,6 +731,18 @@ def softmax_rows_f32(x, rows, cols, pad_cols):
     check(lib.sculpt_softmax_rows_f32(_ptr(x), x.stride(0), rows, cols, pad_cols, _stream()))
 
 
+def attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs):
+    """`batch` fused three-limb attentions in one launch (sculpt_attention_f32_l3_batched); O an fp32 tensor (o_bs in elements) or a
+    Limbs (o_bs in elements of its logical [rows][cols] matrix: entry b starts at row b * o_bs / cols)."""
+    lt = isinstance(O, Limbs)
+    if lt:
+        assert o_bs % O.cols == 0
+    check(lib.sculpt_attention_f32_l3_batched(_ptr(Q), Q.stride(0), int(q_bs), _ptr(K), K.stride(0), int(k_bs), _ptr(Vt), Vt.stride(0),
+                                              int(vt_bs), None if lt else _ptr(O), 0 if lt else O.stride(0), 0 if lt else int(o_bs),
+                                              _ptr(O.data) if lt else None, 0, int(o_bs // O.cols) if lt else 0, O.cols if lt else 0,
+                                              Tq, Tk, heads, int(batch), float(scale), _stream()))
+
+
 def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False, o_row0=0):
     """softmax(Q K^T scale) V per head in fp32: two GEMMs and a row softmax per head.
     Q [Tq][*], K [Tk][*] with head h at columns 64h..; Vt [heads*64][>= round_up(Tk,32)] (zero padded).

@@ -120,3 +120,80 @@ def test_l3p_refuses_what_it_cannot_do():
         ops.gemm_l3p(small, big, 64, 128, 64, out=out)   # A holds 32 rows, the call needs 64
     with pytest.raises(AssertionError):
         ops.gemm_l3p(ops.Limbs(64, 32, _dev(), zero=True), big, 64, 128, 64, out=out)   # K mismatch
+
+
+def test_layernorm_and_attention_write_the_limbs_of_their_fp32_results():
+    import math
+
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    rows, cols = 1025, 768
+    x, gamma, beta = _rand((rows, cols), g, 3.0), _rand((cols,), g), _rand((cols,), g)
+    want = torch.empty(rows, cols, device=_dev())
+    ops.layernorm(x, gamma, beta, 1e-5, y_f32=want)
+    lt, also = ops.Limbs(rows, cols, _dev(), zero=True), torch.empty(rows, cols, device=_dev())
+    ops.layernorm(x, gamma, beta, 1e-5, y_lt=lt, y_f32=also)
+    assert torch.equal(lt.float(), want) and torch.equal(also, want)
+    # fused three-limb attention: both kernel forms (4-wave: the tokenizer's shape; pipelined 8-wave: the backbone's), with a row offset
+    for Tq, Tk, heads in ((1025, 1025, 12), (3072, 1025, 16)):
+        D = heads * 64
+        Q, K = _rand((Tq, D), g), _rand((Tk, D), g)
+        ldv = ((Tk + 63) // 64) * 64
+        Vt = torch.zeros(D, ldv, device=_dev()); Vt[:, :Tk] = _rand((D, Tk), g)
+        want = torch.empty(Tq, D, device=_dev())
+        ops.attention_f32(Q, K, Vt, want, Tq, Tk, heads, 1.0 / math.sqrt(64), None, l3=True)
+        row0 = 40
+        O = ops.Limbs(row0 + Tq, D, _dev(), zero=True)
+        ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, 1.0 / math.sqrt(64), None, l3=True, o_row0=row0)
+        got = O.float()
+        assert torch.equal(got[row0:], want) and float(got[:row0].abs().max()) == 0.0
+
+
+def test_limbs_once_forward_is_bit_identical_to_the_splitting_kernels(monkeypatch):
+    """TSR(precision="bf16l3") with the operands split once (default) against SCULPT_L3P=0 (every GEMM splits while staging): the
+    same products in the same order -> the same scene code, bit for bit; one image and a batch of two."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+    from sculptmate_amd.tsr.system import TSR
+
+    sd = synth.tsr_state(3, SMALL_CFG)
+    imgs = [torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=s, size=SMALL_CFG["cond_image_size"]))).to(_dev()) for s in (1, 2)]
+    codes = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SCULPT_L3P", flag)
+        m = TSR(SMALL_CFG, pos_embed_mode="size", precision="bf16l3")
+        m.load_state_dict(sd)
+        m.to(_dev())
+        assert m.l3p == (flag == "1")
+        m.max_batch = 2
+        with torch.no_grad():
+            codes[flag] = (m.forward(imgs[0]).clone(), m.forward(imgs).clone())
+    for a, b in zip(codes["1"], codes["0"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_batched_three_limb_attention_equals_the_per_entry_launches():
+    """sculpt_attention_f32_l3_batched (grid z = batch entry) against one launch per entry: token rows stacked, V^T side by side
+    in one array (a column offset per entry), fp32 and limb outputs; both kernel forms."""
+    import math
+
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    for T, Tk, heads, B in ((520, 520, 4, 3), (3072, 1032, 16, 2)):
+        D = heads * 64
+        Ts = ((Tk + 7) // 8) * 8
+        Q, K = _rand((B * T, D), g), _rand((B * Ts, D), g)
+        ldv = (B - 1) * Ts + ((Tk + 63) // 64) * 64
+        Vt = _rand((D, ldv), g)
+        scale = 1.0 / math.sqrt(64)
+        want = torch.empty(B * T, D, device=_dev())
+        for b in range(B):
+            ops.attention_f32(Q[b * T:], K[b * Ts:], Vt[:, b * Ts:], want[b * T:], T, Tk, heads, scale, None, l3=True)
+        got = torch.full((B * T, D), float("nan"), device=_dev())
+        ops.attention_f32_l3_batched(Q, K, Vt, got, T, Tk, heads, scale, B, T * D, Ts * D, Ts, T * D)
+        assert torch.equal(got, want)
+        O = ops.Limbs(B * T, D, _dev(), zero=True)
+        ops.attention_f32_l3_batched(Q, K, Vt, O, T, Tk, heads, scale, B, T * D, Ts * D, Ts, T * D)
+        assert torch.equal(O.float(), want)
