@@ -330,13 +330,16 @@ def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None
     ln = None
     if ln_stats is not None or stats_out is not None:
         # statistics arrays are slice-major: [K/64 or N/64][rows][2]
+        # (a view of a band of rows, [:, r0:r1], keeps the plane stride of the whole array: ld comes from the stride)
         ref = ln_stats if ln_stats is not None else stats_out
-        ld = ref.shape[1]
+        ld = ref.stride(0) // 2
         ln = _lib.LnFold(_ptr(ln_stats), K // LN_SLOT if ln_stats is not None else 0, _ptr(ln_colsum), float(ln_eps), _ptr(stats_out), ld)
         if ln_stats is not None:
-            assert ln_stats.dtype == torch.float32 and ln_stats.shape[0] >= K // LN_SLOT and ln_stats.shape[1] == ld and ln_colsum is not None
+            assert ln_stats.dtype == torch.float32 and ln_stats.shape[0] >= K // LN_SLOT and ln_stats.stride(0) == 2 * ld and ln_colsum is not None
+            assert ln_stats.shape[1] >= M and ln_stats.stride(1) == 2
         if stats_out is not None:
-            assert stats_out.dtype == torch.float32 and stats_out.shape[0] >= N // LN_SLOT and stats_out.shape[1] == ld
+            assert stats_out.dtype == torch.float32 and stats_out.shape[0] >= N // LN_SLOT and stats_out.stride(0) == 2 * ld
+            assert stats_out.shape[1] >= M and stats_out.stride(1) == 2
     check(lib.sculpt_gemm_bf16_ln(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual),
                                   residual.stride(0) if residual is not None else 0, _ptr(out_f32), _ptr(out_bf16),
                                   ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, int(n_split), 0, M, N, K,
