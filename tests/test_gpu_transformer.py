@@ -958,6 +958,19 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     meshl3 = ml3.extract_meshes(cl3, resolution=R, threshold=thr)[0]
     infol3 = assert_mesh_close(meshl3.vertices.cpu().numpy(), meshl3.faces.cpu().numpy(), rv, rf, tol=1e-4 * 1.74)
     print("image -> mesh at %d^3 in bf16l3 mode: %s" % (R, infol3))
+    # ... and at BASELINE's own grid, 256^3, through the product's default extraction (the two-pass filtered density grid +
+    # marching cubes) against the oracle's dense fp32 grid + its marching cubes on the host: the same 1e-4 and the same topology
+    R2 = 256
+    dref2 = capi.density_grid(ref32.numpy(), Ws, bs, R2)
+    thr2 = float(np.quantile(dref2, 0.97))
+    assert ml3.decoder_filter
+    mesh2 = ml3.extract_meshes(cl3, resolution=R2, threshold=thr2)[0]
+    assert ml3.filter_info["filtered"] >= 1 and ml3.filter_info["fallbacks"] == 0, ml3.filter_info
+    rv2, rf2 = capi.reference_isosurface(-(dref2 - np.float32(thr2)), R2)
+    rv2 = rv2 * np.float32(0.87 - (-0.87)) + np.float32(-0.87)
+    info2 = assert_mesh_close(mesh2.vertices.cpu().numpy(), mesh2.faces.cpu().numpy(), rv2, rf2, tol=1e-4 * 1.74)
+    print("image -> mesh at %d^3 in bf16l3 mode, filtered grid: %d vertices, %s" % (R2, mesh2.vertices.shape[0], info2))
+    del dref2, mesh2, rv2, rf2
     m32 = ml3   # the bf16-mode comparison below only needs a decoder
     # The DEFAULT mode (bf16 transformer, what bench.py times) against the same fp32 CPU mesh: the scene code is 0.8 % away
     # (bf16 weights and activations through 28 layers), so the iso-surface moves; how far is stated here and in bench.py's
