@@ -48,7 +48,8 @@ extern "C" {
  * 3: the two-pass dense density grid (sculpt_density_grid_filtered, sculpt_density_filter_workspace_bytes,
  *    sculpt_density_filter_stats); added without a version change (new symbols only): sculpt_limbs_bytes, sculpt_limbs_split,
  *    sculpt_gemm_l3p, sculpt_layernorm_limbs, sculpt_attention_f32_l3_limbs, sculpt_mc_count_launch, sculpt_mc_count_read,
- *    sculpt_mc_emit_capped, sculpt_attention_f32_l3_batched */
+ *    sculpt_mc_emit_capped, sculpt_attention_f32_l3_batched, sculpt_mc_count_launch_signed,
+ *    sculpt_density_filter_sign_offset */
 #define SCULPT_ABI_VERSION 3
 
 typedef void *sculpt_stream_t;
@@ -175,6 +176,8 @@ size_t sculpt_density_filter_workspace_bytes(int R, int nx);
 int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end, float density_bias,
                                  float out_add, float margin, const void *workspace, void *filter_workspace, float *out,
                                  unsigned flags, sculpt_stream_t stream);
+/* byte offset of the sign planes (uint32 [nx * R][ceil(R / 32)], bit = value > 0 of the final volume) inside the filter workspace */
+size_t sculpt_density_filter_sign_offset(int R, int nx);
 int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats8 /* host */, sculpt_stream_t stream);
 /* Step 2 for a decoder head with a 3-channel output (SF3D's MaterialMLP heads evaluated on the marching-tetrahedra lattice,
  * sf3d/system.py:141-168 + network.py:148-210): density_act (nullable) = exp(row 0 + density_bias) + out_add as above,
@@ -202,6 +205,10 @@ int sculpt_grid_decode(const void *mlp_packed, int n_hidden_64, int R, int x_beg
  * through the previous slab's top_plane_map (int32 [2][n1][n2], -1 = no vertex). */
 #define SCULPT_MC_SLAB 8u
 #define SCULPT_MC_SLAB_HALO_LOW 16u
+/* sculpt_mc_count_launch_signed / sculpt_mc_count_read after it: the count phase took its "value > level" bits from caller-supplied
+ * planes; no data range is collected -- an empty surface comes back as SCULPT_ERR_MC_EMPTY whether or not the level lies inside the
+ * range (call sculpt_mc_count to tell skimage's two errors apart), minmax is (+FLT_MAX, -FLT_MAX) */
+#define SCULPT_MC_SIGNED 32u
 #define SCULPT_ERR_MC_LEVEL 11
 #define SCULPT_ERR_MC_EMPTY 12
 #define SCULPT_ERR_MC_NAN 13 /* the volume contains NaN (e.g. a 16-bit split density mode left its range) */
@@ -225,6 +232,13 @@ int sculpt_mc_emit(const float *vol, int n0, int n1, int n2, double level, unsig
  * sculpt_mc_count == launch + read; sculpt_mc_emit == emit_capped with unbounded capacities. */
 int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
                            sculpt_stream_t stream);
+/* The count phase when the caller already holds the planes "vol > level" of the whole lattice -- sign_planes[(i0 * n1 + i1) *
+ * words_per_row + i2 / 32] bit i2 % 32, bits past n2 zero: what sculpt_density_grid_filtered leaves in its workspace
+ * (sculpt_density_filter_sign_offset) for level 0 -- : bricks of cells without a sign change never read the volume (most of it),
+ * the others read their rows as before.  Same records, counts, vertices and faces as sculpt_mc_count_launch; pass
+ * flags | SCULPT_MC_SIGNED to sculpt_mc_count_read.  Not for slab mode. */
+int sculpt_mc_count_launch_signed(const float *vol, const uint32_t *sign_planes, int words_per_row, int n0, int n1, int n2,
+                                  double level, unsigned flags, void *workspace, sculpt_stream_t stream);
 int sculpt_mc_count_read(int n0, int n1, int n2, double level, unsigned flags, const void *workspace, int64_t *n_verts_host,
                          int64_t *n_faces_host, float *minmax_host /* [2] or NULL */, sculpt_stream_t stream);
 int sculpt_mc_emit_capped(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace, float vert_div,

@@ -88,6 +88,8 @@ SIGNATURES = {
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "sculpt_mc_count_launch_signed": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.c_double, _u, _vp, _vp]),
+    "sculpt_density_filter_sign_offset": (_sz, [_i, _i]),
     "sculpt_mc_count_launch": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _vp]),
     "sculpt_mc_count_read": (_i, [_i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit_capped": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _i64, _vp, _i64, _vp, _vp]),
@@ -176,6 +178,7 @@ MC_REFERENCE_ORDER = 2
 MC_USE_CLASSIC = 4
 MC_SLAB = 8
 MC_SLAB_HALO_LOW = 16
+MC_SIGNED = 32
 ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
 ERR_MC_NAN = 13

@@ -488,6 +488,9 @@ __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
                 if (err < INFINITY) worst = fmaxf(worst, err);
             }
             out[idx] = exact;
+            // a NaN among the exact values fails the guard: the caller redoes the grid in full and marching cubes on the whole
+            // volume reports it (the classification from the sign planes looks at values near the surface only)
+            if (exact != exact) worst = INFINITY;
             if ((coarse > 0.0f) != (exact > 0.0f)) {
                 const int nzb = (R + 31) / 32;
                 atomicXor(&signbits[((long)ixl * R + iy) * nzb + (iz >> 5)], 1u << (iz & 31));
@@ -570,6 +573,14 @@ int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R,
         if (int rc = list_pass(1)) return rc;
     }
     return 0;
+}
+
+size_t sculpt_density_filter_sign_offset(int R, int nx) {
+    if (R < 2 || nx < 1) return 0;
+    FilterView v;
+    char base[1];
+    filter_layout(R, nx, base, &v);
+    return (size_t)(reinterpret_cast<char *>(v.sign) - base);
 }
 
 int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats8, sculpt_stream_t stream) {

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float
                                                                      int *__restrict__ block_counts,
                                                                      int *__restrict__ block_nact,
                                                                      float2 *__restrict__ block_minmax,
-                                                                     McHeader *__restrict__ hdr) {
+                                                                     McHeader *__restrict__ hdr,
+                                                                     const unsigned *__restrict__ signbits, int sign_ld) {
     constexpr int NSRC = (MC_TZ + 1) * (MC_TY + 1);
     constexpr int NCH = MC_BLOCK / 64;  // 64-value chunks of a row (= waves of the workgroup)
     // 38 KiB in all: four workgroups per CU
@@ -663,7 +664,12 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float
     // of a wave's 64 values IS its ballot, so the sign pass below works on 64-bit planes instead of on floats
     float mn = FLT_MAX, mx = -FLT_MAX;
     bool nan = false;
-    {
+    // SIGNED form (sculpt_mc_count_launch_signed): the caller already holds the planes "value > level" of the whole lattice (the
+    // filtered density grid's sign words, 32 values of the fastest axis per word): the masks come from 25 x 9 words instead of
+    // 25 x 257 floats, and a brick without an active cell -- most of the volume -- never touches the volume at all; bricks with
+    // active cells stage their rows as before (values for the Lewiner tests).  No data range is collected in this form.
+    const bool use_planes = signbits != nullptr;   // kernel-uniform
+    auto stage_rows = [&](bool masks) {
         float val[NSRC], edge = 0.f;
         const long sy = g.n2, sz = (long)g.n1 * g.n2;
         const float *base = vol + z0 * sz + y0 * sy + x0;
@@ -687,8 +693,10 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float
                 nan |= val[r] != val[r];
             }
             s_src[r * MC_SRC_LD + tid] = val[r];
-            const unsigned long long bal = __ballot(val[r] > levelf);  // == ((double)f - level > 0): levelf = largest float <= level
-            if (lane == 0) s_mask[r][wave] = bal;
+            if (masks) {
+                const unsigned long long bal = __ballot(val[r] > levelf);  // == ((double)f - level > 0): levelf = largest float <= level
+                if (lane == 0) s_mask[r][wave] = bal;
+            }
         }
         if (tid < NSRC) {
             const int dz = tid / (MC_TY + 1), dy = tid % (MC_TY + 1);
@@ -698,8 +706,22 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float
                 nan |= edge != edge;
             }
             s_src[tid * MC_SRC_LD + nx] = edge;  // nx == 256: the extra column; nx < 256: rewrites the same value
-            s_mask[tid][NCH] = (edge > levelf) ? 1ull : 0ull;
+            if (masks) s_mask[tid][NCH] = (edge > levelf) ? 1ull : 0ull;
         }
+    };
+    if (!use_planes) {
+        stage_rows(true);
+    } else if (tid < NSRC * (NCH + 1)) {
+        const int r = tid / (NCH + 1), c = tid % (NCH + 1);
+        const int dz = r / (MC_TY + 1), dy = r % (MC_TY + 1);
+        unsigned long long m = 0ull;
+        if (dz <= nz && dy <= ny) {
+            const unsigned *w = signbits + ((long)(z0 + dz) * g.n1 + (y0 + dy)) * sign_ld;
+            const int w0 = (x0 >> 5) + 2 * c;   // x0 is a multiple of MC_BLOCK = 256: word aligned; bits past the row are 0
+            const unsigned lo = w0 < sign_ld ? w[w0] : 0u, hi = w0 + 1 < sign_ld ? w[w0 + 1] : 0u;
+            m = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        }
+        s_mask[r][c] = c < NCH ? m : (m & 1ull);   // chunk NCH: the 257th value of a full segment
     }
     if (nan) hdr->nan_seen = 1u;  // fminf/fmaxf drop NaN silently; a plain racing store of 1 is enough
 #pragma unroll
@@ -742,6 +764,11 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float
 #pragma unroll
     for (int r = 0; r < MC_ROWS; ++r) pre[r + 1] = pre[r] + s_cnt[r];
     const int total_active = pre[MC_ROWS];
+    if (use_planes && total_active > 0) {   // workgroup-uniform: this brick needs its values after all
+        stage_rows(false);
+        if (nan) hdr->nan_seen = 1u;
+        __syncthreads();
+    }
     const TabLds T{s_lut};
     for (int p = tid; p < total_active; p += MC_BLOCK) {
         int lr = 0;
@@ -816,7 +843,7 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_classify_brick_kernel(const float
             block_counts[blk] = carry;
             block_nact[blk] = n;
             // the brick's min / max on its first row, neutral elements on the others (the scans only reduce them)
-            block_minmax[blk] = lr == 0 ? make_float2(bmn, bmx) : make_float2(FLT_MAX, -FLT_MAX);
+            block_minmax[blk] = (lr == 0 && !use_planes) ? make_float2(bmn, bmx) : make_float2(FLT_MAX, -FLT_MAX);
         }
     }
 }
@@ -1159,8 +1186,8 @@ size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2) {
     return ws_layout(g).total;
 }
 
-int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
-                           sculpt_stream_t stream) {
+static int mc_count_launch(const float *vol, const unsigned *signbits, int sign_ld, int n0, int n1, int n2, double level,
+                           unsigned flags, void *workspace, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     Grid g;
     if (int rc = make_grid(n0, n1, n2, &g)) return rc;
@@ -1180,7 +1207,7 @@ int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double leve
     float levelf = (float)level;
     if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
     static const int old_classify = [] { const char *e = getenv("SCULPT_MC_CLASSIFY_ROWS"); return e ? atoi(e) : 0; }();
-    if (old_classify) {
+    if (old_classify && !signbits) {
         hipLaunchKernelGGL(mc_classify_kernel, dim3(w.nblocks), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
                            reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
                            reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr);
@@ -1189,7 +1216,7 @@ int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double leve
         static const int dbg = [] { const char *e = getenv("SCULPT_MC_DBG"); return e ? atoi(e) : 0; }();  // timing ablations only
         hipLaunchKernelGGL(mc_classify_brick_kernel, dim3(bpr * nby * nbz), dim3(MC_BLOCK), 0, st, vol, g, levelf, level, classic,
                            nby, bpr, dbg, reinterpret_cast<CellRec *>(ws + w.off_recs), reinterpret_cast<int *>(ws + w.off_counts),
-                           reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr);
+                           reinterpret_cast<int *>(ws + w.off_nact), reinterpret_cast<float2 *>(ws + w.off_minmax), hdr, signbits, sign_ld);
     }
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(w.ngroups), dim3(1024), 0, st, reinterpret_cast<const int *>(ws + w.off_counts),
@@ -1204,6 +1231,20 @@ int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double leve
                        reinterpret_cast<unsigned *>(ws + w.off_gact));
     SC_LAUNCH_CHECK();
     return 0;
+}
+
+int sculpt_mc_count_launch(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace,
+                           sculpt_stream_t stream) {
+    SC_REQUIRE(!(flags & SCULPT_MC_SIGNED), "mc_count: SCULPT_MC_SIGNED belongs to sculpt_mc_count_launch_signed");
+    return mc_count_launch(vol, nullptr, 0, n0, n1, n2, level, flags, workspace, stream);
+}
+
+int sculpt_mc_count_launch_signed(const float *vol, const uint32_t *sign_planes, int words_per_row, int n0, int n1, int n2,
+                                  double level, unsigned flags, void *workspace, sculpt_stream_t stream) {
+    SC_REQUIRE(sign_planes && words_per_row >= (n2 + 31) / 32, "mc_count_signed: sign planes missing or rows too short (%d words for n2=%d)",
+               words_per_row, n2);
+    SC_REQUIRE(!(flags & (SCULPT_MC_SLAB | SCULPT_MC_SLAB_HALO_LOW)), "mc_count_signed: not in slab mode (no data range is collected)");
+    return mc_count_launch(vol, sign_planes, words_per_row, n0, n1, n2, level, flags, workspace, stream);
 }
 
 int sculpt_mc_count_read(int n0, int n1, int n2, double level, unsigned flags, const void *workspace, int64_t *n_verts_host,
@@ -1225,7 +1266,9 @@ int sculpt_mc_count_read(int n0, int n1, int n2, double level, unsigned flags, c
         return SCULPT_ERR_MC_NAN;
     }
     if (flags & SCULPT_MC_SLAB) return 0;  // a slab may be empty; the caller decides globally
-    if ((double)level < (double)mn || (double)level > (double)mx) {
+    // (SIGNED: no data range was collected; an empty result is reported as EMPTY and the caller asks the unsigned form which of
+    // skimage's two errors it is)
+    if (!(flags & SCULPT_MC_SIGNED) && ((double)level < (double)mn || (double)level > (double)mx)) {
         set_error("Surface level must be within volume data range.");
         return SCULPT_ERR_MC_LEVEL;
     }

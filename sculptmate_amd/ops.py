@@ -214,6 +214,20 @@ def density_grid_filtered(planes, mlp, resolution, margin, radius=0.87, density_
     return out, stats
 
 
+def filter_sign_planes(resolution, device, x_begin=0, x_end=None):
+    """The sign planes the LAST density_grid_filtered call of these arguments left in the filter workspace: int32
+    [nx * R][ceil(R / 32)], bit iz % 32 of word iz / 32 = (final volume value > 0) -- what marching_cubes(sign_planes=) takes for
+    level 0.  A view: valid until the next filtered call on this device."""
+    R = int(resolution)
+    nx = (R if x_end is None else int(x_end)) - int(x_begin)
+    fws = _ws_cache.get(("dgf", device))
+    need = lib.sculpt_density_filter_workspace_bytes(R, nx)
+    if fws is None or fws.numel() < need:
+        raise SculptError("filter_sign_planes: no filtered density grid of this size has run on %s" % device)
+    off, nzb = int(lib.sculpt_density_filter_sign_offset(R, nx)), (R + 31) // 32
+    return fws[off:off + nx * R * nzb * 4].view(torch.int32).view(nx * R, nzb)
+
+
 def filter_stats(stats):
     """int32[8] statistics of density_grid_filtered (host or device tensor; a device tensor is read back here) -> dict."""
     s = stats.cpu().numpy() if isinstance(stats, torch.Tensor) else np.asarray(stats)
@@ -235,7 +249,7 @@ def _axis_table(R, radius, device):
 # marching cubes
 # ----------------------------------------------------------------------------------------------
 def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul=1.0, vert_add=0.0,
-                   use_classic=False, slab=None):
+                   use_classic=False, slab=None, sign_planes=None):
     """skimage.measure.marching_cubes(vol, level) on the GPU.
 
     reference_order=False: (verts f32[nv,3] voxel units, faces i32[nf,3]) exactly as skimage returns.
@@ -244,6 +258,10 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     Raises ValueError / RuntimeError like skimage for an out-of-range level / empty surface.
     slab=dict(axis0_offset=int, halo_low=bool): slab mode for the axis-0 split (sculptmate_amd/slab.py);
         returns (verts, faces, top_plane_map int32[2,n1,n2], (min, max)) and never raises on an empty slab.
+    sign_planes (uint32 / int32 [n0*n1][words >= ceil(n2/32)], bit i2%32 of word i2/32 = vol > level, bits past n2 zero; not in
+        slab mode): the count phase takes the signs from them and reads the volume only where a cell is active
+        (sculpt_mc_count_launch_signed) -- what density_grid_filtered leaves behind for level 0.  Same mesh; an empty result is
+        re-run without the planes so that skimage's two errors stay apart.
     """
     vol = _req(vol, torch.float32, "vol")
     assert vol.dim() == 3
@@ -269,17 +287,30 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     key = (vol.device, n0, n1, n2, flags)
     cap = _MC_CAPACITY.get(key) if (slab is None and _MC_SPECULATE) else None
     verts = faces = None
+    rflags = flags
+    if sign_planes is not None:
+        assert slab is None and sign_planes.dim() == 2 and sign_planes.shape[0] == n0 * n1 and sign_planes.stride(1) == 1
+        assert sign_planes.element_size() == 4 and sign_planes.shape[1] >= (n2 + 31) // 32
+        rflags = flags | _lib.MC_SIGNED
+
+    def launch_count():
+        if sign_planes is not None:
+            check(lib.sculpt_mc_count_launch_signed(_ptr(vol), _ptr(sign_planes), sign_planes.stride(0), n0, n1, n2, float(level), flags,
+                                                    _ptr(ws), _stream()))
+        else:
+            check(lib.sculpt_mc_count_launch(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), _stream()))
+
+    launch_count()
     if cap is not None:
-        check(lib.sculpt_mc_count_launch(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), _stream()))
         verts = torch.empty((cap[0], 3), dtype=torch.float32, device=vol.device)
         faces = torch.empty((cap[1], 3), dtype=fdt, device=vol.device)
         check(lib.sculpt_mc_emit_capped(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), float(vert_div), float(vert_mul),
                                         float(vert_add), off, _ptr(verts), cap[0], _ptr(faces), cap[1], None, _stream()))
-        rc = lib.sculpt_mc_count_read(n0, n1, n2, float(level), flags, _ptr(ws), ctypes.byref(nv), ctypes.byref(nf),
-                                      ctypes.cast(mm, ctypes.c_void_p), _stream())
-    else:
-        rc = lib.sculpt_mc_count(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), ctypes.byref(nv),
-                                 ctypes.byref(nf), ctypes.cast(mm, ctypes.c_void_p), _stream())
+    rc = lib.sculpt_mc_count_read(n0, n1, n2, float(level), rflags, _ptr(ws), ctypes.byref(nv), ctypes.byref(nf),
+                                  ctypes.cast(mm, ctypes.c_void_p), _stream())
+    if sign_planes is not None and rc == _lib.ERR_MC_EMPTY:
+        # no surface: whether that is skimage's ValueError (level outside the data range) or its RuntimeError needs the range
+        return marching_cubes(vol, level, reference_order, vert_div, vert_mul, vert_add, use_classic, slab)
     if rc == _lib.ERR_MC_LEVEL:
         raise ValueError(_lib.last_error())
     if rc == _lib.ERR_MC_EMPTY:

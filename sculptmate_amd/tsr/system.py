@@ -129,6 +129,9 @@ class PendingMesh:
         return self._mesh
 
 
+_MC_SIGN_PLANES = os.environ.get("SCULPT_MC_SIGN_PLANES", "1") != "0"
+
+
 class PendingTokens:
     """The image tokens of one image, being computed on the tokenizer stream (TSR.tokens_async)."""
 
@@ -738,8 +741,11 @@ class TSR(KernelEngine):
         r = self.renderer.cfg.radius
         R = resolution
         out = []
-        mc = lambda v: ops.marching_cubes(v.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0,  # noqa: E731
-                                          vert_mul=r - (-r), vert_add=-r)
+        def mc(v, sign_planes=None):
+            return ops.marching_cubes(v.view(R, R, R), 0.0, reference_order=True, vert_div=R - 1.0, vert_mul=r - (-r), vert_add=-r,
+                                      sign_planes=sign_planes)
+
+        mc.takes_sign_planes = True
         for scene_code in scene_codes:
             planes = scene_code.contiguous()
             dkw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, out_add=-threshold)
@@ -810,8 +816,14 @@ class TSR(KernelEngine):
         vol, _ = ops.density_grid_filtered(planes, self.decoder, R, info["margin"], coarse=info["coarse"], events=density_events,
                                            stats_host=host, **dkw)
         err = None
+        # a whole grid (not a slab): marching cubes takes its cell signs from the grid's sign planes and reads the volume only
+        # where a cell is active; SCULPT_MC_SIGN_PLANES=0: the plain count phase over the whole volume (A/B)
+        signs = None
+        if x_begin == 0 and (x_end is None or x_end == R) and getattr(mc, "takes_sign_planes", False) and _MC_SIGN_PLANES:
+            signs = ops.filter_sign_planes(R, planes.device)
         try:
-            mesh = mc(vol)   # waits for the stream (sculpt_mc_count reads its counts back): the statistics have landed with it
+            # waits for the stream (sculpt_mc_count reads its counts back): the statistics have landed with it
+            mesh = mc(vol) if signs is None else mc(vol, signs)
         except Exception as e:  # an empty / out-of-range surface raises in both evaluations; checked below before it is believed
             mesh, err = None, e
         st = ops.filter_stats(host)

@@ -190,3 +190,62 @@ def test_speculative_emit_equals_the_two_phase_path(cuda, monkeypatch):
     # and a good call afterwards is still right
     gv, gf = ops.marching_cubes(vols[0], 0.0, reference_order=True, vert_div=51.0)
     assert torch.equal(gv, want[0][0]) and torch.equal(gf, want[0][1])
+
+
+def _planes_of(vol, level=0.0):
+    """uint32 words along the last axis, bit i % 32 of word i / 32 = vol > level (bits past the row are zero), as int32 [n0*n1][words]."""
+    n0, n1, n2 = vol.shape
+    words = (n2 + 31) // 32
+    bits = np.zeros((n0 * n1, words * 32), np.uint8)
+    bits[:, :n2] = (vol.reshape(n0 * n1, n2) > np.float32(level))
+    packed = np.packbits(bits.reshape(n0 * n1, words, 32), axis=-1, bitorder="little").view(np.uint32).reshape(n0 * n1, words)
+    return torch.from_numpy(packed.view(np.int32))
+
+
+@pytest.mark.parametrize("shape,seed", [((2, 2, 2), 0), ((17, 9, 33), 2), ((40, 41, 42), 3), ((64, 64, 64), 4), ((9, 10, 300), 5),
+                                         ((12, 7, 513), 6)])
+def test_count_phase_from_sign_planes_equals_the_plain_one(cuda, shape, seed, monkeypatch):
+    """sculpt_mc_count_launch_signed: the cell signs come from caller-supplied planes and the volume is read only in bricks with an
+    active cell -- same vertices, faces and order as the plain count phase (noise: every Lewiner case; rows longer than one
+    256-cell segment; sizes that are not multiples of 32 / 64), with and without the speculative emit."""
+    from sculptmate_amd import ops
+
+    rng = np.random.default_rng(seed)
+    vol = rng.standard_normal(shape).astype(np.float32)
+    if min(shape) > 4:
+        vol[2:4] = np.abs(vol[2:4]) + 1.0          # slabs without any sign change: bricks that never read the volume
+    volt, planes = torch.from_numpy(vol).to(cuda), _planes_of(vol).to(cuda)
+    for spec in (False, True, True):
+        monkeypatch.setattr(ops, "_MC_SPECULATE", spec)
+        v, f = ops.marching_cubes(volt, 0.0)
+        sv, sf = ops.marching_cubes(volt, 0.0, sign_planes=planes)
+        assert torch.equal(sv, v) and torch.equal(sf, f)
+    rv, rf = capi.marching_cubes(vol, 0.0)
+    _same(sv, sf, rv, rf)
+    # integer values with exact zeros (value == level is "not above")
+    ivol = rng.integers(-2, 3, shape).astype(np.float32)
+    if (ivol > 0).any() and (ivol <= 0).any():
+        it = torch.from_numpy(ivol).to(cuda)
+        v, f = ops.marching_cubes(it, 0.0, reference_order=True, vert_div=3.0)
+        sv, sf = ops.marching_cubes(it, 0.0, reference_order=True, vert_div=3.0, sign_planes=_planes_of(ivol).to(cuda))
+        assert torch.equal(sv, v) and torch.equal(sf, f)
+
+
+def test_sign_plane_count_keeps_the_error_semantics(cuda):
+    from sculptmate_amd import ops
+
+    shape = (20, 21, 70)
+    ones = torch.ones(shape, device=cuda)
+    with pytest.raises(ValueError):       # level below the data range: the planes say "no surface", the plain form names the error
+        ops.marching_cubes(ones, 0.0, sign_planes=_planes_of(ones.cpu().numpy()).to(cuda))
+    e = -torch.ones(shape, device=cuda)
+    e[1, 1, 1] = 0.0
+    with pytest.raises(RuntimeError):
+        ops.marching_cubes(e, 0.0, sign_planes=_planes_of(e.cpu().numpy()).to(cuda))
+    vol = np.random.default_rng(1).standard_normal(shape).astype(np.float32)
+    bad = vol.copy()
+    bad[5, 5, 5] = np.nan                 # inside the surface band of a noise volume: its brick is staged, the NaN is seen
+    with pytest.raises(ops.SculptError):
+        ops.marching_cubes(torch.from_numpy(bad).to(cuda), 0.0, sign_planes=_planes_of(bad).to(cuda))
+    with pytest.raises(AssertionError):   # not in slab mode
+        ops.marching_cubes(torch.from_numpy(vol).to(cuda), 0.0, slab=dict(axis0_offset=0), sign_planes=_planes_of(vol).to(cuda))
