@@ -197,3 +197,33 @@ def test_batched_three_limb_attention_equals_the_per_entry_launches():
         O = ops.Limbs(B * T, D, _dev(), zero=True)
         ops.attention_f32_l3_batched(Q, K, Vt, O, T, Tk, heads, scale, B, T * D, Ts * D, Ts, T * D)
         assert torch.equal(O.float(), want)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (33, 128, 32), (31, 256, 96), (129, 384, 160), (64, 128, 4096)])
+def test_l3p_smallest_and_ragged_shapes(M, N, K, monkeypatch):
+    """One row, one K-tile pair, a last row block with a single row, a tile whose row blocks run past the matrix (clamped reads,
+    unwritten rows), a long K: every tile form, all bit-identical to the splitting kernel; GEGLU at its smallest width."""
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A, W, bias, res = _rand((M, K), g), _rand((N, K), g, K ** -0.5), _rand((N,), g), _rand((M, N), g)
+    A_lt, W_lt = ops.Limbs.of(A), ops.Limbs.of(W)
+    want = res.clone()
+    ops.gemm_f32(A, W, bias=bias, residual=want, out=want, l3=True)
+    for bm64, nw8 in (("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("SCULPT_L3P_BM64", bm64)
+        monkeypatch.setenv("SCULPT_L3P_NW8", nw8)
+        got = res.clone()
+        ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, residual=got, out=got)
+        assert torch.equal(got, want), (bm64, nw8)
+        out_lt = ops.Limbs(M, N, _dev(), zero=True)
+        ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out_lt=out_lt, epilogue=_lib.EPI_GELU)
+        w2 = torch.empty(M, N, device=_dev())
+        ops.gemm_f32(A, W, bias=bias, out=w2, epilogue=_lib.EPI_GELU, l3=True)
+        assert torch.equal(out_lt.float(), w2), (bm64, nw8)
+    # GEGLU with 64 output columns (one tile)
+    Wg, bg = _rand((128, K), g, K ** -0.5), _rand((128,), g)
+    want = torch.empty(M, 64, device=_dev()); got = torch.empty(M, 64, device=_dev())
+    ops.gemm_f32(A, Wg, bias=bg, out=want, epilogue=_lib.EPI_GEGLU, l3=True)
+    ops.gemm_l3p(A_lt, ops.Limbs.of(ops.geglu_row_blocks(Wg)), M, 64, K, bias=bg, out=got, epilogue=_lib.EPI_GEGLU)
+    assert torch.equal(got, want)
