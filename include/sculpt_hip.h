@@ -328,38 +328,48 @@ int sculpt_gemm_f32_ex(const float *A, int lda, const float *W, int ldw, const f
  * 64 h ..; Vt [heads*64][ldvt] = V transposed, ldvt >= round_up(Tk, 64), columns >= Tk finite; O [Tq][ldo]. */
 int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, int Tq,
                             int Tk, int heads, float scale, sculpt_stream_t stream);
-/* "Limbs once" form of the SCULPT_F32_BF16L3 arithmetic (csrc/gemm_l3p.hip): the exact three-limb split x = x1 + x2 + x3 is done
+/* "Limbs once" form of the SCULPT_F32_BF16L3 arithmetic (csrc/gemm_l3p.hip): the split of an fp32 value into 16-bit limbs is done
  * ONCE -- weights at load time, activations by the kernel that produces them -- instead of by every column tile of every launch.
- * A limb-tiled matrix X [R][K] (K % 32 == 0) is ceil(R / 32) * K * 192 bytes (sculpt_limbs_bytes), 16-byte aligned:
- *     byte offset of limb l (0 = leading) of X[r][k] = (((r / 32) * (K / 8) + k / 8) * 3 + l) * 512 + (r % 32) * 16 + (k % 8) * 2
- * (32-row blocks x 8-k chunks x limb: one matrix-instruction fragment = 512 contiguous bytes, a 16-k step of a row block = 3 KiB that
+ * A limb-tiled matrix X [R][K] (K % 32 == 0) with NL limbs per element is ceil(R / 32) * K * 64 * NL bytes (sculpt_limbs_bytes),
+ * 16-byte aligned:
+ *     byte offset of limb l (0 = leading) of X[r][k] = (((r / 32) * (K / 8) + k / 8) * NL + l) * 512 + (r % 32) * 16 + (k % 8) * 2
+ * (32-row blocks x 8-k chunks x limb: one matrix-instruction fragment = 512 contiguous bytes, a 16-k step of a row block = NL KiB that
  * the GEMM copies into LDS by DMA).  Rows >= R of the last block: zeros from sculpt_limbs_split, unspecified from other producers
- * (they reach only outputs that are never stored).
- *   sculpt_limbs_split: fp32 [rows][K] (row stride ld, multiple of 4; src and dst 16-byte aligned) -> limb-tiled.
- *   sculpt_gemm_l3p:    out[m][n] = epi(A[m][:].W[n][:] + bias[n]) (+ residual) with A [M][K] and W [N][K] limb-tiled: the same
- *                       products in the same order as sculpt_gemm_f32_ex(SCULPT_F32_BF16L3) -- bit-identical results.  N % 128 == 0
- *                       (GEGLU: N % 64 == 0 and W stored as 32-row blocks in the order value n..n+31, gate n..n+31, value n+32..,
- *                       gate n+32.. per 64 output columns).  Outputs: out / out_t / n_split / residual as sculpt_gemm_f32, OR
- *                       out_lt: the result itself as a limb-tiled [M][N] matrix (what the next Linear reads; excludes the others).
+ * (they reach only outputs that are never stored).  Formats:
+ *   SCULPT_LIMBS_BF16X3  three bf16 limbs, x = x1 + x2 + x3 exactly (24 significant bits, fp32 exponent range); six limb products per
+ *                        multiply: the same products in the same order as sculpt_gemm_f32_ex(SCULPT_F32_BF16L3) -- bit-identical.
+ *   SCULPT_LIMBS_F16X2   two fp16 limbs: 22 significant bits for |x| >= 2^-3, an absolute error <= 2^-25 below, |x| < 65504 (larger
+ *                        values become inf and the result non-finite: the caller checks); three limb products per multiply, each
+ *                        exact in fp32 -- half the matrix work.  A weight is stored times a power of two `scale` that puts its largest
+ *                        magnitude in [2^14, 2^15) (sculpt_limbs_split's scale; exact) and the GEMM takes alpha = 1 / scale.
+ *   sculpt_limbs_split: scale * fp32 [rows][K] (row stride ld, multiple of 4; src and dst 16-byte aligned) -> limb-tiled.
+ *   sculpt_gemm_l3p:    out[m][n] = epi(alpha * A[m][:].W[n][:] + bias[n]) (+ residual), A [M][K] and W [N][K] limb-tiled in `format`.
+ *                       N % 128 == 0 (GEGLU: N % 64 == 0 and W stored as 32-row blocks in the order value n..n+31, gate n..n+31,
+ *                       value n+32.., gate n+32.. per 64 output columns).  Outputs: out / out_t / n_split / residual as
+ *                       sculpt_gemm_f32, OR out_lt: the result itself as a limb-tiled [M][N] matrix in out_format (what the next
+ *                       Linear reads; excludes the others).
  *   sculpt_layernorm_limbs:        sculpt_layernorm on fp32 rows with the normalised rows written limb-tiled ([rows][cols]; y_f32
  *                                  optional: the same rows in fp32 as well).
  *   sculpt_attention_f32_l3_limbs: sculpt_attention_f32_l3 with O written limb-tiled: query q of this call is row o_row0 + q of a
  *                                  limb-tiled matrix of o_cols (>= heads * 64, multiple of 32) columns, head h at columns 64 h .. */
-size_t sculpt_limbs_bytes(int rows, int K);
-int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const float *beta, float eps, void *y_lt, float *y_f32, int ldy,
-                           int rows, int cols, sculpt_stream_t stream);
-int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt, int o_row0,
-                                  int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream);
+#define SCULPT_LIMBS_BF16X3 0
+#define SCULPT_LIMBS_F16X2 1
+size_t sculpt_limbs_bytes(int rows, int K, int format);
+int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const float *beta, float eps, void *y_lt, int format,
+                           float *y_f32, int ldy, int rows, int cols, sculpt_stream_t stream);
+int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt, int format,
+                                  int o_row0, int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream);
 /* `batch` fused three-limb attentions of one shape in ONE launch (TSR.forward on a list of images in the tolerance mode): entry b
  * reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (element strides, multiples of 4; vt_bs may be a column offset into one
  * [heads*64][ldvt] array) and writes O + b*o_bs -- or, with O null and O_lt given, rows o_row0 + b*o_row_bs .. of the limb-tiled
- * output of o_cols columns. */
+ * output of o_cols columns in `format`. */
 int sculpt_attention_f32_l3_batched(const float *Q, int ldq, int64_t q_bs, const float *K, int ldk, int64_t k_bs, const float *Vt,
-                                    int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt, int o_row0, int o_row_bs,
-                                    int o_cols, int Tq, int Tk, int heads, int batch, float scale, sculpt_stream_t stream);
-int sculpt_limbs_split(const float *src, int ld, int rows, int K, void *dst, sculpt_stream_t stream);
-int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const float *residual, int ldr, float *out, int ldo,
-                    float *out_t, int ldt, int n_split, void *out_lt, int M, int N, int K, int epilogue, sculpt_stream_t stream);
+                                    int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt, int format, int o_row0,
+                                    int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch, float scale, sculpt_stream_t stream);
+int sculpt_limbs_split(const float *src, int ld, int rows, int K, float scale, int format, void *dst, sculpt_stream_t stream);
+int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha, const float *bias, const float *residual, int ldr,
+                    float *out, int ldo, float *out_t, int ldt, int n_split, void *out_lt, int out_format, int M, int N, int K,
+                    int epilogue, sculpt_stream_t stream);
 /* in-place softmax over the first `cols` columns of each row; columns [cols, pad_cols) are set to 0 */
 int sculpt_softmax_rows_f32(float *x, int ld, int rows, int cols, int pad_cols, sculpt_stream_t stream);
 

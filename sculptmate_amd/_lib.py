@@ -106,12 +106,12 @@ SIGNATURES = {
     "sculpt_fuse_sigmoid": (_i, [_vp, _i, _i64, _vp, _f, _vp, _vp]),
     "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_attention_f32_l3": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
-    "sculpt_limbs_bytes": (_sz, [_i, _i]),
-    "sculpt_attention_f32_l3_batched": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
-    "sculpt_layernorm_limbs": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
-    "sculpt_attention_f32_l3_limbs": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "sculpt_limbs_split": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "sculpt_gemm_l3p": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "sculpt_limbs_bytes": (_sz, [_i, _i, _i]),
+    "sculpt_attention_f32_l3_batched": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_layernorm_limbs": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "sculpt_attention_f32_l3_limbs": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_limbs_split": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp]),
+    "sculpt_gemm_l3p": (_i, [_vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_f32_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "sculpt_softmax_rows_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "sculpt_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -179,6 +179,7 @@ MC_USE_CLASSIC = 4
 MC_SLAB = 8
 MC_SLAB_HALO_LOW = 16
 MC_SIGNED = 32
+LIMBS_BF16X3, LIMBS_F16X2 = 0, 1
 ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
 ERR_MC_NAN = 13

@@ -64,7 +64,7 @@ __device__ __forceinline__ void al_split8(const float (&x)[8], abf16x8 &f1, abf1
 
 // blockIdx.z = batch entry (`batch` independent attentions of one shape in one launch): element strides of Q, K, Vt (a column
 // offset when the V^T of the entries sit side by side) and O; for a limb output the entry's first ROW
-struct AttnL3Batch { long q_bs, k_bs, vt_bs, o_bs; int o_row_bs; };
+struct AttnL3Batch { long q_bs, k_bs, vt_bs, o_bs; int o_row_bs; int o_fmt; };
 
 __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
                                                               const float *__restrict__ Vt, int ldvt, float *__restrict__ O, int ldo,
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__res
         for (int g4 = 0; g4 < 4; ++g4) {
             const float a[4] = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
             const float b[4] = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
-            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 8 * g4 + 4 * h, a);
-            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 32 + 8 * g4 + 4 * h, b);
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 8 * g4 + 4 * h, a, ab.o_fmt);
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 32 + 8 * g4 + 4 * h, b, ab.o_fmt);
         }
     } else if (q < Tq) {
         float *orow = O + (long)q * ldo + head * 64;
@@ -522,8 +522,8 @@ __global__ __launch_bounds__(NW * 64) void attention_l3_pipe_kernel(const float 
         for (int g4 = 0; g4 < 4; ++g4) {
             const float a[4] = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
             const float b[4] = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
-            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 8 * g4 + 4 * h, a);
-            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 32 + 8 * g4 + 4 * h, b);
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 8 * g4 + 4 * h, a, ab.o_fmt);
+            lt_store4(O_lt, o_k8, (long)o_row0 + q, head * 64 + 32 + 8 * g4 + 4 * h, b, ab.o_fmt);
         }
     } else if (q < Tq) {
         float *orow = O + (long)q * ldo + head * 64;
@@ -551,8 +551,9 @@ using namespace sculpt;
 
 static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, void *O_lt,
                            int o_row0, int o_k8, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream, int batch = 1,
-                           AttnL3Batch ab = AttnL3Batch{0, 0, 0, 0, 0}) {
+                           AttnL3Batch ab = AttnL3Batch{0, 0, 0, 0, 0, 0}) {
     SC_REQUIRE(batch >= 1 && batch <= 65535, "attention_f32_l3: bad batch %d", batch);
+    SC_REQUIRE(ab.o_fmt == LT_BF16X3 || ab.o_fmt == LT_F16X2, "attention_f32_l3: unknown limb format %d", ab.o_fmt);
     SC_REQUIRE(batch == 1 || (ab.q_bs % 4 == 0 && ab.k_bs % 4 == 0 && ab.vt_bs % 4 == 0 && ab.o_bs % 4 == 0 && ab.o_row_bs >= 0),
                "attention_f32_l3: batch strides must be multiples of 4 elements");
     SC_REQUIRE(Q && K && Vt && (O || O_lt), "attention_f32_l3: null argument");
@@ -584,9 +585,11 @@ extern "C" int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, 
 }
 
 extern "C" int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt,
-                                             int o_row0, int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream) {
+                                             int format, int o_row0, int o_cols, int Tq, int Tk, int heads, float scale,
+                                             sculpt_stream_t stream) {
     SC_REQUIRE(O_lt && o_cols % 32 == 0, "attention_f32_l3_limbs: null output or o_cols=%d not a multiple of 32", o_cols);
-    return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, nullptr, 0, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream);
+    return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, nullptr, 0, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream, 1,
+                           AttnL3Batch{0, 0, 0, 0, 0, format});
 }
 
 /* `batch` attentions of one shape in ONE launch (grid z): entry b reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (element strides,
@@ -594,10 +597,10 @@ extern "C" int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const floa
  * rows o_row0 + b*o_row_bs .. of the limb-tiled output. */
 extern "C" int sculpt_attention_f32_l3_batched(const float *Q, int ldq, int64_t q_bs, const float *K, int ldk, int64_t k_bs,
                                                const float *Vt, int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt,
-                                               int o_row0, int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch, float scale,
-                                               sculpt_stream_t stream) {
+                                               int format, int o_row0, int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch,
+                                               float scale, sculpt_stream_t stream) {
     SC_REQUIRE((O != nullptr) != (O_lt != nullptr), "attention_f32_l3_batched: exactly one of O / O_lt");
     SC_REQUIRE(!O_lt || o_cols % 32 == 0, "attention_f32_l3_batched: o_cols=%d not a multiple of 32", o_cols);
     return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, O, ldo, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream, batch,
-                           AttnL3Batch{(long)q_bs, (long)k_bs, (long)vt_bs, (long)o_bs, o_row_bs});
+                           AttnL3Batch{(long)q_bs, (long)k_bs, (long)vt_bs, (long)o_bs, o_row_bs, O_lt ? format : 0});
 }

@@ -27,6 +27,17 @@
 namespace sculpt {
 
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+
+// one limb product of a 32 x 32 x 16 step, operands as raw 16-byte fragments
+template <int FMT>
+__device__ __forceinline__ f32x16 l3p_mfma(pu32x4 w, pu32x4 x, f32x16 c) {
+    if constexpr (FMT == LT_F16X2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, w), __builtin_bit_cast(pf16x8, x), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pbf16x8, w), __builtin_bit_cast(pbf16x8, x), c, 0, 0, 0);
+}
 typedef __attribute__((address_space(3))) void *p_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *p_gbl_ptr_t;
 
@@ -37,6 +48,7 @@ struct GemmL3pArgs {
     unsigned char *out_lt;    // when set: the result leaves as limbs (limb-tiled [M][N or N/2 outputs]) instead of g.out
     int a_blocks;             // 32-row blocks allocated in A_lt
     int out_k8;               // 16-byte chunks per row of out_lt = output columns / 8
+    int out_fmt;              // limb format of out_lt (limbs.h)
     // XCD-aware tile order (common.h xcd_tile): the workgroups of one XCD (private L2) take a contiguous band of the tile grid -- a
     // band of activation rows with every weight tile, or (n_major = 1, W the larger operand) a band of weight rows with every
     // activation tile; -1 = the natural order (A/B)
@@ -67,7 +79,7 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
                     const float gt = acc[1][j][4 * q4 + r] * g.alpha + bgs[r];
                     o[r] = v * gelu_erf_exact(gt);
                 }
-                lt_store4(a.out_lt, a.out_k8, m, n, o);
+                lt_store4(a.out_lt, a.out_k8, m, n, o, a.out_fmt);
             } else {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -82,7 +94,7 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
                         if (EPI == SCULPT_EPI_RELU) v = fmaxf(v, 0.f);
                         o[r] = v;
                     }
-                    lt_store4(a.out_lt, a.out_k8, m, n, o);
+                    lt_store4(a.out_lt, a.out_k8, m, n, o, a.out_fmt);
                 }
             }
         }
@@ -95,14 +107,17 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
 // (One 128 x 96 tile per CU on 6 waves -- 256 tiles for the 3072 x 1024 outputs that 128 x 128 tiles spread over 192 CUs -- measured
 // no faster: o / q 49.3 against 47.6 us, FF2 164 against 157: these launches run at the clock the chip holds under the matrix load,
 // not at a rate the idle quarter of the CUs could add to.)
-template <int EPI, int BM, int NW>
+// FMT (limbs.h): LT_BF16X3 -- three limbs, the six products above; LT_F16X2 -- two fp16 limbs, W.x = W2x1 + W1x2 + W1x1 per 16 k
+// (W2x2 < 2^-22 |W||x| dropped): half the matrix work, the K-tile of a row block is 2 KiB.
+template <int EPI, int BM, int NW, int FMT>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(GemmL3pArgs a) {
     static_assert(((BM == 128 || BM == 64) && NW == 4) || (NW == 8 && BM == 128), "tile forms");
+    constexpr int NL = FMT == LT_F16X2 ? 2 : 3;
     constexpr int NWC = NW / 2;           // waves along the activation rows
     constexpr int JT = BM / 32 / NWC;     // 32-row activation sub-tiles per wave
     constexpr int ARB = BM / 32;          // activation row blocks per tile
     constexpr int NRB = 4 + ARB;          // row blocks per ring stage: [4 weight | ARB activation]
-    constexpr int RBK = 3072;             // bytes of one K-tile (16 k = 2 chunks x 3 limbs x 512 B) of one row block
+    constexpr int RBK = NL * 1024;        // bytes of one K-tile (16 k = 2 chunks x NL limbs x 512 B) of one row block
     constexpr int STG = NRB * RBK;
     constexpr int NST = 3;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STG];
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
         mt = a.n_major ? tile % gy : tile / gx;
     }
     const int n0 = nt * NOUT, m0 = mt * BM;
-    const long kblk = (long)g.K * 192;    // bytes of one 32-row block: K / 8 chunks x 3 limbs x 512
+    const long kblk = (long)g.K * (64 * NL);   // bytes of one 32-row block: K / 8 chunks x NL limbs x 512
     // staging: wave w copies row block w of the stage and (when there are more blocks than waves) row block w + NW; blocks 0..3 are
     // the tile's weight rows (a GEGLU weight is stored with its row blocks already in the tile's value / gate order: 4 blocks per
     // 64 output columns), blocks 4.. its activation rows
@@ -135,13 +150,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
     do {                                                                                                                    \
         unsigned char *sb = smem + (buf) * STG;                                                                             \
         const long ko = (long)(kt) * RBK;                                                                                   \
-        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko), (p_lds_ptr_t)(sb + dst0), 16, 0, 0);                     \
-        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko + 1024), (p_lds_ptr_t)(sb + dst0 + 1024), 16, 0, 0);      \
-        __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko + 2048), (p_lds_ptr_t)(sb + dst0 + 2048), 16, 0, 0);      \
+        _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_)                                                                   \
+            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko + q_ * 1024), (p_lds_ptr_t)(sb + dst0 + q_ * 1024), 16, 0, 0); \
         if (NRB > NW && two) {                                                                                              \
-            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko), (p_lds_ptr_t)(sb + dst1), 16, 0, 0);                 \
-            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko + 1024), (p_lds_ptr_t)(sb + dst1 + 1024), 16, 0, 0);  \
-            __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko + 2048), (p_lds_ptr_t)(sb + dst1 + 2048), 16, 0, 0);  \
+            _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_)                                                               \
+                __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko + q_ * 1024), (p_lds_ptr_t)(sb + dst1 + q_ * 1024), 16, 0, 0); \
         }                                                                                                                   \
     } while (0)
 
@@ -155,8 +168,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
 
     const int l31 = lane & 31, lh = lane >> 5;
     // fragment of limb l: + l * 512; lane (l31, lh): chunk lh of the K-tile, row l31
-    const int wfo = (wr * 2) * RBK + lh * 1536 + l31 * 16;
-    const int afo = (4 + wc * JT) * RBK + lh * 1536 + l31 * 16;
+    const int wfo = (wr * 2) * RBK + lh * (NL * 512) + l31 * 16;
+    const int afo = (4 + wc * JT) * RBK + lh * (NL * 512) + l31 * 16;
 
     const int nk = g.K >> 4;
     L3P_STAGE(0, 0);
@@ -164,8 +177,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
     for (int kt = 0; kt < nk; ++kt) {
         // wait until K-tile kt has landed; K-tile kt + 1 (if issued) stays in flight
         if (kt + 1 < nk) {
-            if (NRB > NW && two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (NRB > NW && two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -173,25 +186,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
         // every wave finished reading stage (kt - 1) % 3 == (kt + 2) % 3 before it passed the barrier
         if (kt + 2 < nk) L3P_STAGE((kt + 2) % NST, kt + 2);
         const unsigned char *sb = smem + (kt % NST) * STG;
-        pbf16x8 wf[2][3], af[JT][3];
+        pu32x4 wf[2][NL], af[JT][NL];
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
+        for (int l = 0; l < NL; ++l) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i][l] = *reinterpret_cast<const pbf16x8 *>(sb + wfo + i * RBK + l * 512);
+            for (int i = 0; i < 2; ++i) wf[i][l] = *reinterpret_cast<const pu32x4 *>(sb + wfo + i * RBK + l * 512);
 #pragma unroll
-            for (int j = 0; j < JT; ++j) af[j][l] = *reinterpret_cast<const pbf16x8 *>(sb + afo + j * RBK + l * 512);
+            for (int j = 0; j < JT; ++j) af[j][l] = *reinterpret_cast<const pu32x4 *>(sb + afo + j * RBK + l * 512);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                f32x16 c = acc[i][j];   // smallest terms first: the order of gemm_l3_kernel
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][2], af[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][1], af[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][1], af[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][0], af[j][0], c, 0, 0, 0);
+                f32x16 c = acc[i][j];   // smallest terms first
+                if constexpr (NL == 3) {   // the order of gemm_l3_kernel
+                    c = l3p_mfma<FMT>(wf[i][0], af[j][2], c);
+                    c = l3p_mfma<FMT>(wf[i][2], af[j][0], c);
+                    c = l3p_mfma<FMT>(wf[i][1], af[j][1], c);
+                    c = l3p_mfma<FMT>(wf[i][0], af[j][1], c);
+                    c = l3p_mfma<FMT>(wf[i][1], af[j][0], c);
+                    c = l3p_mfma<FMT>(wf[i][0], af[j][0], c);
+                } else {
+                    c = l3p_mfma<FMT>(wf[i][1], af[j][0], c);
+                    c = l3p_mfma<FMT>(wf[i][0], af[j][1], c);
+                    c = l3p_mfma<FMT>(wf[i][0], af[j][0], c);
+                }
                 acc[i][j] = c;
             }
     }
@@ -200,10 +219,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
     else f32_tile_epilogue<EPI, JT>(g, acc, n0, m0, wr, wc, l31, lh);
 }
 
-// fp32 [R][K] (row stride ld) -> limb-tiled; one thread per (row of a block, k chunk): the 32 threads of a block row group write
-// 512 contiguous bytes per limb.  Rows >= R of the last block are written as zeros.
-__global__ __launch_bounds__(256) void limbs_split_kernel(const float *__restrict__ src, long ld, int R, int K,
+// fp32 [R][K] (row stride ld) times `scale` (a power of two: exact) -> limb-tiled; one thread per (row of a block, k chunk): the 32
+// threads of a block row group write 512 contiguous bytes per limb.  Rows >= R of the last block are written as zeros.
+template <int FMT>
+__global__ __launch_bounds__(256) void limbs_split_kernel(const float *__restrict__ src, long ld, int R, int K, float scale,
                                                           unsigned char *__restrict__ dst) {
+    constexpr int NL = FMT == LT_F16X2 ? 2 : 3;
     const int k8 = K >> 3;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)((R + 31) >> 5) * k8 * 32;
@@ -217,16 +238,24 @@ __global__ __launch_bounds__(256) void limbs_split_kernel(const float *__restric
     if (row < R) {
         const float4 x0 = *reinterpret_cast<const float4 *>(src + row * ld + kc * 8);
         const float4 x1 = *reinterpret_cast<const float4 *>(src + row * ld + kc * 8 + 4);
-        lo[0] = x0.x; lo[1] = x0.y; lo[2] = x0.z; lo[3] = x0.w;
-        hi[0] = x1.x; hi[1] = x1.y; hi[2] = x1.z; hi[3] = x1.w;
+        lo[0] = x0.x * scale; lo[1] = x0.y * scale; lo[2] = x0.z * scale; lo[3] = x0.w * scale;
+        hi[0] = x1.x * scale; hi[1] = x1.y * scale; hi[2] = x1.z * scale; hi[3] = x1.w * scale;
     }
-    uint2 a1, a2, a3, b1, b2, b3;
-    lt_split4(lo, a1, a2, a3);
-    lt_split4(hi, b1, b2, b3);
-    unsigned char *d = dst + (bc * 3) * 512 + r32 * 16;
-    *reinterpret_cast<uint4 *>(d) = make_uint4(a1.x, a1.y, b1.x, b1.y);
-    *reinterpret_cast<uint4 *>(d + 512) = make_uint4(a2.x, a2.y, b2.x, b2.y);
-    *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+    unsigned char *d = dst + (bc * NL) * 512 + r32 * 16;
+    if constexpr (FMT == LT_F16X2) {
+        uint2 a1, a2, b1, b2;
+        lt_split4_h(lo, a1, a2);
+        lt_split4_h(hi, b1, b2);
+        *reinterpret_cast<uint4 *>(d) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        *reinterpret_cast<uint4 *>(d + 512) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    } else {
+        uint2 a1, a2, a3, b1, b2, b3;
+        lt_split4(lo, a1, a2, a3);
+        lt_split4(hi, b1, b2, b3);
+        *reinterpret_cast<uint4 *>(d) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        *reinterpret_cast<uint4 *>(d + 512) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        *reinterpret_cast<uint4 *>(d + 1024) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+    }
 }
 
 }  // namespace sculpt
@@ -235,23 +264,37 @@ using namespace sculpt;
 
 extern "C" {
 
-size_t sculpt_limbs_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * (size_t)K * 192; }
+static bool lt_fmt_ok(int f) { return f == LT_BF16X3 || f == LT_F16X2; }
 
-int sculpt_limbs_split(const float *src, int ld, int rows, int K, void *dst, sculpt_stream_t stream) {
+size_t sculpt_limbs_bytes(int rows, int K, int format) {
+    return (size_t)((rows + 31) / 32) * (size_t)K * (size_t)(64 * lt_limbs(format));
+}
+
+int sculpt_limbs_split(const float *src, int ld, int rows, int K, float scale, int format, void *dst, sculpt_stream_t stream) {
     SC_REQUIRE(src && dst, "limbs_split: null argument");
+    SC_REQUIRE(lt_fmt_ok(format), "limbs_split: unknown limb format %d", format);
     SC_REQUIRE(rows >= 1 && K >= 32 && K % 32 == 0 && ld >= K && ld % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
                "limbs_split: bad shape rows=%d K=%d ld=%d (K %% 32 == 0, ld %% 4 == 0, 16-byte aligned)", rows, K, ld);
+    SC_REQUIRE(scale > 0.f && scale == scale && scale < INFINITY, "limbs_split: scale must be a positive finite number (a power of two)");
     const long total = (long)((rows + 31) / 32) * (K / 8) * 32;
-    hipLaunchKernelGGL(limbs_split_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, as_stream(stream), src, (long)ld, rows, K,
-                       reinterpret_cast<unsigned char *>(dst));
+    unsigned char *d = reinterpret_cast<unsigned char *>(dst);
+    if (format == LT_F16X2)
+        hipLaunchKernelGGL(limbs_split_kernel<LT_F16X2>, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, as_stream(stream), src, (long)ld,
+                           rows, K, scale, d);
+    else
+        hipLaunchKernelGGL(limbs_split_kernel<LT_BF16X3>, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, as_stream(stream), src, (long)ld,
+                           rows, K, scale, d);
     SC_LAUNCH_CHECK();
     return 0;
 }
 
-int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const float *residual, int ldr, float *out, int ldo,
-                    float *out_t, int ldt, int n_split, void *out_lt, int M, int N, int K, int epilogue, sculpt_stream_t stream) {
+int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha, const float *bias, const float *residual, int ldr,
+                    float *out, int ldo, float *out_t, int ldt, int n_split, void *out_lt, int out_format, int M, int N, int K,
+                    int epilogue, sculpt_stream_t stream) {
     SC_REQUIRE(A_lt && W_lt && (out || out_t || out_lt), "gemm_l3p: null argument");
+    SC_REQUIRE(lt_fmt_ok(format) && (!out_lt || lt_fmt_ok(out_format)), "gemm_l3p: unknown limb format %d / %d", format, out_format);
     SC_REQUIRE(M >= 1 && K >= 32 && K % 32 == 0, "gemm_l3p: bad shape M=%d K=%d (K %% 32 == 0)", M, K);
+    SC_REQUIRE(alpha == alpha && alpha != 0.f && fabsf(alpha) < INFINITY, "gemm_l3p: alpha must be finite and non-zero");
     SC_REQUIRE(((uintptr_t)A_lt & 15) == 0 && ((uintptr_t)W_lt & 15) == 0 && ((uintptr_t)out_lt & 15) == 0, "gemm_l3p: limb arrays must be 16-byte aligned");
     const bool geglu = epilogue == SCULPT_EPI_GEGLU;
     if (geglu) SC_REQUIRE(N % 64 == 0 && (out || out_lt) && !residual && !out_t, "gemm_l3p(GEGLU): N %% 64 == 0, plain or limb output only");
@@ -268,19 +311,21 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const
     }
     SC_REQUIRE(((uintptr_t)bias & 15) == 0, "gemm_l3p: bias must be 16-byte aligned");
     GemmL3pArgs a;
-    a.g = GemmF32Args{nullptr, 0, nullptr, 0, bias, residual, ldr, out, ldo, out_t, ldt, M, N, K, n_split, N, 1.0f, 0, 0, 0};
+    a.g = GemmF32Args{nullptr, 0, nullptr, 0, bias, residual, ldr, out, ldo, out_t, ldt, M, N, K, n_split, N, alpha, 0, 0, 0};
     a.A_lt = reinterpret_cast<const unsigned char *>(A_lt);
     a.W_lt = reinterpret_cast<const unsigned char *>(W_lt);
     a.out_lt = reinterpret_cast<unsigned char *>(out_lt);
     a.a_blocks = (M + 31) / 32;
     a.out_k8 = N / 8;
+    a.out_fmt = out_format;
     hipStream_t st = as_stream(stream);
     const int gx = geglu ? N / 64 : N / 128;
     // XCD band order: measured equal to the natural order on every shape of the two transformers (tools/time_l3p.py; the operands
     // sit in the Infinity Cache): off unless SCULPT_L3P_ORDER=1
     const char *eo = getenv("SCULPT_L3P_ORDER");
     a.n_major = (eo && atoi(eo) == 1) ? ((geglu ? 2 * N : N) > M ? 1 : 0) : -1;
-    // Tile form by the number of 128 x 128 tiles (tools/time_l3p.py, one MI355X, us; 4 waves 128 / 4 waves 64 / 8 waves 128):
+    // Tile form by the number of 128 x 128 tiles (tools/time_l3p.py, one MI355X, three bf16 limbs, us; 4 waves 128 / 4 waves 64 /
+    // 8 waves 128):
     //   image tokenizer (1025 rows)  o    54 tiles  34.7 / 24.5 / 31.0     f2   54 tiles  115.8 / 82.6 / 108.6
     //                                qkv 162 tiles  36.8 / 36.6 / 33.4     f1  216 tiles   49.4 / 46.8 /  42.7
     //   backbone (3072 rows)         o / q 192      52.0 / 53.5 / 49.1     FF2 192        163.6 / 175.3 / 153.6
@@ -292,17 +337,23 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, const float *bias, const
     const long tiles128 = (long)gx * cdiv(M, 128);
     const bool bm64 = e64 ? atoi(e64) != 0 : 2 * tiles128 < num_cus();
     const bool nw8 = !bm64 && (e8 ? atoi(e8) != 0 : tiles128 <= 3L * num_cus());
-#define L3P_GO(E)                                                                                                      \
-    do {                                                                                                               \
-        if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64, 4>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);         \
-        else if (nw8) hipLaunchKernelGGL((gemm_l3p_kernel<E, 128, 8>), dim3(gx, cdiv(M, 128)), dim3(512), 0, st, a);   \
-        else hipLaunchKernelGGL((gemm_l3p_kernel<E, 128, 4>), dim3(gx, cdiv(M, 128)), dim3(256), 0, st, a);            \
+#define L3P_GO2(E, F)                                                                                                      \
+    do {                                                                                                                   \
+        if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64, 4, F>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);          \
+        else if (nw8) hipLaunchKernelGGL((gemm_l3p_kernel<E, 128, 8, F>), dim3(gx, cdiv(M, 128)), dim3(512), 0, st, a);    \
+        else hipLaunchKernelGGL((gemm_l3p_kernel<E, 128, 4, F>), dim3(gx, cdiv(M, 128)), dim3(256), 0, st, a);             \
+    } while (0)
+#define L3P_GO(E)                                   \
+    do {                                            \
+        if (format == LT_F16X2) L3P_GO2(E, LT_F16X2); \
+        else L3P_GO2(E, LT_BF16X3);                 \
     } while (0)
     if (geglu) L3P_GO(SCULPT_EPI_GEGLU);
     else if (epilogue == SCULPT_EPI_GELU) L3P_GO(SCULPT_EPI_GELU);
     else if (epilogue == SCULPT_EPI_RELU) L3P_GO(SCULPT_EPI_RELU);
     else L3P_GO(SCULPT_EPI_NONE);
 #undef L3P_GO
+#undef L3P_GO2
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -1,14 +1,25 @@
-// The limb-tiled three-limb form of an fp32 matrix (the operands of gemm_l3p.hip) and the exact split that produces it; shared by
-// the kernels that WRITE activations as limbs (gemm_l3p.hip epilogues, norms.hip LayerNorm, attention_l3.hip).
+// The limb-tiled form of an fp32 matrix (the operands of gemm_l3p.hip) and the splits that produce it; shared by the kernels that
+// WRITE activations as limbs (gemm_l3p.hip epilogues, norms.hip LayerNorm, attention_l3.hip).
 //
-// Limb-tiled X [R][K] (K % 32 == 0), rows in blocks of 32, k in chunks of 8:
-//     byte offset of limb l (0 = leading) of X[r][k] = (((r / 32) * (K / 8) + k / 8) * 3 + l) * 512 + (r % 32) * 16 + (k % 8) * 2
+// Limb-tiled X [R][K] (K % 32 == 0), rows in blocks of 32, k in chunks of 8, NL limbs per element:
+//     byte offset of limb l (0 = leading) of X[r][k] = (((r / 32) * (K / 8) + k / 8) * NL + l) * 512 + (r % 32) * 16 + (k % 8) * 2
+// Formats:
+//   LT_BF16X3  three bf16 limbs, x = x1 + x2 + x3 EXACTLY for every fp32 x (8 + 8 + 8 significant bits, the fp32 exponent range);
+//              six limb products per multiply (gemm_l3.hip's arithmetic);
+//   LT_F16X2   two fp16 limbs, x ~ h1 + h2: 22 significant bits while |x| >= 2^-3, an absolute error <= 2^-25 below that, and
+//              |x| < 65504 (an fp16 limb has 5 exponent bits: weights are stored pre-multiplied by a power of two that puts their
+//              largest magnitude in [2^14, 2^15), undone exactly by the GEMM's alpha; activations go in as they are); three limb
+//              products per multiply, each exact in fp32 (11 x 11 bits).
 #pragma once
 #include "common.h"
 
 namespace sculpt {
 
+static constexpr int LT_BF16X3 = 0, LT_F16X2 = 1;
+__host__ __device__ __forceinline__ int lt_limbs(int fmt) { return fmt == LT_F16X2 ? 2 : 3; }
+
 typedef __bf16 lt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lt_f16x2 __attribute__((ext_vector_type(2)));
 typedef float lt_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned lt_cvt_pk(float lo, float hi) {
@@ -31,8 +42,27 @@ __device__ __forceinline__ void lt_split4(const float (&x)[4], uint2 &p1, uint2 
     p3 = make_uint2(lt_cvt_pk(s0, s1), lt_cvt_pk(s2, s3));
 }
 
-// X[row][col .. col + 3] (col % 4 == 0) of a limb-tiled matrix with k8 = K / 8 chunks per row: split and store the three 8-byte pieces
-__device__ __forceinline__ void lt_store4(unsigned char *base, int k8, long row, int col, const float (&x)[4]) {
+// the same for two fp16 limbs: h1 = fp16(x) (round to nearest even; |x| >= 65520 -> inf), h2 = fp16(x - h1) -- the difference is exact
+__device__ __forceinline__ void lt_split4_h(const float (&x)[4], uint2 &p1, uint2 &p2) {
+#pragma clang fp contract(off)
+    const lt_f32x2 v0 = {x[0], x[1]}, v1 = {x[2], x[3]};
+    const lt_f16x2 a = __builtin_convertvector(v0, lt_f16x2), b = __builtin_convertvector(v1, lt_f16x2);   // v_cvt_pk_f16_f32
+    const lt_f32x2 r0 = {x[0] - (float)a[0], x[1] - (float)a[1]}, r1 = {x[2] - (float)b[0], x[3] - (float)b[1]};
+    const lt_f16x2 c = __builtin_convertvector(r0, lt_f16x2), d = __builtin_convertvector(r1, lt_f16x2);
+    p1 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    p2 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
+
+// X[row][col .. col + 3] (col % 4 == 0) of a limb-tiled matrix with k8 = K / 8 chunks per row: split and store the 8-byte pieces
+__device__ __forceinline__ void lt_store4(unsigned char *base, int k8, long row, int col, const float (&x)[4], int fmt = LT_BF16X3) {
+    if (fmt == LT_F16X2) {   // kernel-uniform
+        uint2 p1, p2;
+        lt_split4_h(x, p1, p2);
+        unsigned char *d = base + (((row >> 5) * k8 + (col >> 3)) * 2) * 512 + (row & 31) * 16 + ((col >> 2) & 1) * 8;
+        *reinterpret_cast<uint2 *>(d) = p1;
+        *reinterpret_cast<uint2 *>(d + 512) = p2;
+        return;
+    }
     uint2 p1, p2, p3;
     lt_split4(x, p1, p2, p3);
     unsigned char *d = base + (((row >> 5) * k8 + (col >> 3)) * 3) * 512 + (row & 31) * 16 + ((col >> 2) & 1) * 8;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                                                         int ldx, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float eps,
                                                         uint16_t *__restrict__ y, int ldy, float *__restrict__ yf,
-                                                        int rows, int cols, unsigned char *__restrict__ y_lt = nullptr) {
+                                                        int rows, int cols, unsigned char *__restrict__ y_lt = nullptr, int lt_fmt = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                 *reinterpret_cast<uint2 *>(y + (long)row * ldy + c) = pk;
             }
             if (yf) *reinterpret_cast<float4 *>(yf + (long)row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
-            if (y_lt) lt_store4(y_lt, cols >> 3, row, c, o);   // the normalised row as three bf16 limbs (the operand of gemm_l3p)
+            if (y_lt) lt_store4(y_lt, cols >> 3, row, c, o, lt_fmt);   // the normalised row as limbs (the operand of gemm_l3p)
         }
     }
 }
@@ -289,14 +289,15 @@ int sculpt_layernorm(const float *x_f32, const uint16_t *x_bf16, int ldx, const 
     return 0;
 }
 
-int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const float *beta, float eps, void *y_lt, float *y_f32, int ldy,
-                           int rows, int cols, sculpt_stream_t stream) {
+int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const float *beta, float eps, void *y_lt, int format,
+                           float *y_f32, int ldy, int rows, int cols, sculpt_stream_t stream) {
     SC_REQUIRE(x && gamma && beta && y_lt, "layernorm_limbs: null argument");
+    SC_REQUIRE(format == LT_BF16X3 || format == LT_F16X2, "layernorm_limbs: unknown limb format %d", format);
     SC_REQUIRE(cols % 256 == 0 && cols <= 2048 && ldx % 4 == 0 && ((uintptr_t)y_lt & 15) == 0 && (!y_f32 || ldy % 4 == 0),
                "layernorm_limbs: cols=%d must be a multiple of 256 and <= 2048, ldx / ldy multiples of 4, y_lt 16-byte aligned", cols);
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(layernorm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, (const uint16_t *)nullptr, ldx,
-                       gamma, beta, eps, (uint16_t *)nullptr, ldy, y_f32, rows, cols, reinterpret_cast<unsigned char *>(y_lt));
+                       gamma, beta, eps, (uint16_t *)nullptr, ldy, y_f32, rows, cols, reinterpret_cast<unsigned char *>(y_lt), format);
     SC_LAUNCH_CHECK();
     return 0;
 }

@@ -2,6 +2,10 @@
 
 bf16:   bf16 storage / fp32 accumulate on the MFMA kernels (what bench.py times).
 fp32:   every GEMM / attention / norm on the exact-fp32 parity kernels (the reference's own precision).
+fp16l2: "bf16l3" with the hot Linears (limbs once, below) on TWO fp16 limbs per operand: 22 significant bits, three products per
+        multiply instead of six; weights are stored pre-scaled into the fp16 range, activations must stay below 65504 in magnitude
+        (they are LayerNorm outputs, attention outputs, GELU / GEGLU products; a value beyond it makes the result non-finite, which
+        the model checks).  Attention products and the cold Linears stay on three bf16 limbs.
 bf16l3: fp32 storage and fp32 norms / softmax like "fp32", but every matrix product (Linears, QK^T, PV) on the bf16 matrix pipe
         through the exact three-limb split of both operands, fp32 accumulate (csrc/gemm_l3.hip): fp32-equivalent, ~6x faster.
         "Limbs once" (default in this mode, SCULPT_L3P=0 restores the form that splits inside every GEMM): a subclass that
@@ -52,10 +56,11 @@ class KernelEngine:
 
     def _lt(self, name, rows, cols):
         """A cached limb-tiled activation buffer (ops.Limbs), zero-initialised once (pad rows stay finite)."""
-        key = (name, "limbs", rows, cols)
+        fmt = getattr(self, "limb_format", "bf16x3")
+        key = (name, "limbs", rows, cols, fmt)
         t = self._buf.get(key)
         if t is None:
-            t = self._buf[key] = ops.Limbs(rows, cols, self.device, zero=True)
+            t = self._buf[key] = ops.Limbs(rows, cols, self.device, zero=True, fmt=fmt)
         return t
 
     # ------------------------------------------------------------------ precision dispatch
@@ -77,8 +82,9 @@ class KernelEngine:
 
     @property
     def l3(self):
-        """fp32 storage with the matrix products on the three-limb bf16 pipe."""
-        return self.precision == "bf16l3"
+        """fp32 storage with the matrix products on the 16-bit matrix pipe through limbs ("bf16l3": three bf16 limbs everywhere;
+        "fp16l2": the hot Linears on two fp16 limbs -- half the products --, everything else as "bf16l3")."""
+        return self.precision in ("bf16l3", "fp16l2")
 
     def _attn(self, Q, K, Vt, O, Tq, Tk, heads, scale, batch=1, q_bs=0, k_bs=0, vt_bs=0, o_bs=0):
         """batch > 1: `batch` independent attentions, entry b at Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (a column offset), O + b*o_bs

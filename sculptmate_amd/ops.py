@@ -420,7 +420,7 @@ def layernorm(x, gamma, beta, eps, y=None, y_f32=None, rows=None, y_lt=None):
     rows = x.shape[0] if rows is None else rows
     if y_lt is not None:
         assert x.dtype == torch.float32 and y is None and y_lt.cols == x.shape[1] and y_lt.rows >= rows
-        check(lib.sculpt_layernorm_limbs(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y_lt.data), _ptr(y_f32),
+        check(lib.sculpt_layernorm_limbs(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), float(eps), _ptr(y_lt.data), y_lt.code, _ptr(y_f32),
                                          y_f32.stride(0) if y_f32 is not None else 0, rows, x.shape[1], _stream()))
         return
     xf = x if x.dtype == torch.float32 else None
@@ -693,46 +693,64 @@ def gemm_f32(A, W, bias=None, residual=None, out=None, out_t=None, M=None, N=Non
                                  int(o_bs), _stream()))
 
 
-class Limbs:
-    """An fp32 matrix [rows][cols] held as three bf16 limbs per element in the limb-tiled layout of csrc/limbs.h: the operand form
-    of `gemm_l3p` (weights split once at load time, activations written this way by the kernel that produces them)."""
-    __slots__ = ("data", "rows", "cols")
+LIMB_FORMATS = {"bf16x3": _lib.LIMBS_BF16X3, "f16x2": _lib.LIMBS_F16X2}
 
-    def __init__(self, rows, cols, device=None, data=None, zero=False):
-        self.rows, self.cols = int(rows), int(cols)
-        self.data = data if data is not None else limbs_empty(rows, cols, device, zero=zero)
+
+class Limbs:
+    """An fp32 matrix [rows][cols] held as 16-bit limbs in the limb-tiled layout of csrc/limbs.h: the operand form of `gemm_l3p`
+    (weights split once at load time, activations written this way by the kernel that produces them).
+    fmt "bf16x3": three bf16 limbs, exact; "f16x2": two fp16 limbs (22 bits, |x| < 65504) -- a weight is then stored times the
+    power of two `scale` that puts its largest magnitude in [2^14, 2^15) and the GEMM multiplies by alpha = 1 / scale."""
+    __slots__ = ("data", "rows", "cols", "fmt", "scale")
+
+    def __init__(self, rows, cols, device=None, data=None, zero=False, fmt="bf16x3", scale=1.0):
+        self.rows, self.cols, self.fmt, self.scale = int(rows), int(cols), fmt, float(scale)
+        self.data = data if data is not None else limbs_empty(rows, cols, device, zero=zero, fmt=fmt)
 
     @staticmethod
-    def of(x):
-        return Limbs(x.shape[0], x.shape[1], data=limbs_split(x))
+    def of(x, fmt="bf16x3", weight=False):
+        """weight=True (f16x2 only): stored pre-scaled into the fp16 range (see the class)."""
+        scale = 1.0
+        if weight and fmt == "f16x2":
+            mx = float(x.abs().max())
+            if mx > 0.0 and np.isfinite(mx):
+                scale = 2.0 ** (14 - int(np.floor(np.log2(mx))))
+        return Limbs(x.shape[0], x.shape[1], data=limbs_split(x, fmt=fmt, scale=scale), fmt=fmt, scale=scale)
+
+    @property
+    def code(self):
+        return LIMB_FORMATS[self.fmt]
 
     def float(self):
-        return limbs_join(self.data, self.rows, self.cols)
+        return limbs_join(self.data, self.rows, self.cols, self.fmt) / self.scale
 
 
-def limbs_bytes(rows, K):
-    return int(lib.sculpt_limbs_bytes(int(rows), int(K)))
+def limbs_bytes(rows, K, fmt="bf16x3"):
+    return int(lib.sculpt_limbs_bytes(int(rows), int(K), LIMB_FORMATS[fmt]))
 
 
-def limbs_empty(rows, K, device, zero=False):
+def limbs_empty(rows, K, device, zero=False, fmt="bf16x3"):
     """An uninitialised limb-tiled [rows][K] matrix (sculpt_limbs_split's layout; a flat uint8 tensor)."""
-    return (torch.zeros if zero else torch.empty)(limbs_bytes(rows, K), dtype=torch.uint8, device=device)
+    return (torch.zeros if zero else torch.empty)(limbs_bytes(rows, K, fmt), dtype=torch.uint8, device=device)
 
 
-def limbs_split(x, out=None):
-    """fp32 [rows][K] -> the limb-tiled three-limb form the `gemm_l3p` operands take (exact: x = x1 + x2 + x3 in bf16 limbs)."""
+def limbs_split(x, out=None, fmt="bf16x3", scale=1.0):
+    """scale * fp32 [rows][K] -> the limb-tiled form the `gemm_l3p` operands take (bf16x3: exact; f16x2: 22 bits)."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     rows, K = x.shape
     if out is None:
-        out = limbs_empty(rows, K, x.device)
-    check(lib.sculpt_limbs_split(_ptr(x), x.stride(0), rows, K, _ptr(out), _stream()))
+        out = limbs_empty(rows, K, x.device, fmt=fmt)
+    check(lib.sculpt_limbs_split(_ptr(x), x.stride(0), rows, K, float(scale), LIMB_FORMATS[fmt], _ptr(out), _stream()))
     return out
 
 
-def limbs_join(lt, rows, K):
-    """The fp32 matrix a limb-tiled array stands for (tests): x1 + x2 + x3 per element."""
-    v = lt.view(torch.bfloat16).view(-1, K // 8, 3, 32, 8).to(torch.float32)       # [block][chunk][limb][row][k]
-    x = (v[:, :, 0] + v[:, :, 1]) + v[:, :, 2]                                     # exact: the limbs do not overlap
+def limbs_join(lt, rows, K, fmt="bf16x3"):
+    """The fp32 matrix a limb-tiled array stands for (tests): the sum of the limbs per element."""
+    nl = 2 if fmt == "f16x2" else 3
+    v = lt.view(torch.float16 if fmt == "f16x2" else torch.bfloat16).view(-1, K // 8, nl, 32, 8).to(torch.float32)   # [block][chunk][limb][row][k]
+    x = v[:, :, 0] + v[:, :, 1]
+    if nl == 3:
+        x = x + v[:, :, 2]                                                         # exact: the limbs do not overlap
     return x.permute(0, 2, 1, 3).reshape(-1, K)[:rows].contiguous()
 
 
@@ -745,20 +763,28 @@ def geglu_row_blocks(W):
     return W.index_select(0, order)
 
 
-def gemm_l3p(A_lt, W_lt, M, N, K, bias=None, residual=None, out=None, out_t=None, n_split=0, out_lt=None, epilogue=0):
-    """sculpt_gemm_l3p: the three-limb GEMM on operands split once (A_lt [M][K], W_lt [N or 2N][K] limb-tiled; Limbs or raw)."""
+def gemm_l3p(A_lt, W_lt, M, N, K, bias=None, residual=None, out=None, out_t=None, n_split=0, out_lt=None, epilogue=0, fmt=None,
+             alpha=None):
+    """sculpt_gemm_l3p: the limb GEMM on operands split once (A_lt [M][K], W_lt [N or 2N][K] limb-tiled; Limbs or raw tensors
+    with fmt / alpha given).  A Limbs weight brings its format and alpha = 1 / scale."""
+    if fmt is None:
+        fmt = W_lt.fmt if isinstance(W_lt, Limbs) else "bf16x3"
+    if alpha is None:
+        alpha = 1.0 / (W_lt.scale * (A_lt.scale if isinstance(A_lt, Limbs) else 1.0)) if isinstance(W_lt, Limbs) else 1.0
+    out_fmt = out_lt.fmt if isinstance(out_lt, Limbs) else fmt
     rows_w = 2 * N if epilogue == _lib.EPI_GEGLU else N
-    for t, r, c, what in ((A_lt, M, K, "A"), (W_lt, rows_w, K, "W"), (out_lt, M, N, "out")):
+    for t, r, c, what, f in ((A_lt, M, K, "A", fmt), (W_lt, rows_w, K, "W", fmt), (out_lt, M, N, "out", out_fmt)):
         if isinstance(t, Limbs):
-            assert t.cols == c and t.rows >= r, "gemm_l3p: %s is a limb-tiled [%d][%d], the call needs [>= %d][%d]" % (what, t.rows, t.cols, r, c)
+            assert t.cols == c and t.rows >= r and t.fmt == f, "gemm_l3p: %s is a limb-tiled %s [%d][%d], the call needs %s [>= %d][%d]" % (
+                what, t.fmt, t.rows, t.cols, f, r, c)
         elif t is not None:
-            assert t.numel() * t.element_size() >= limbs_bytes(r, c), "gemm_l3p: %s holds fewer bytes than a limb-tiled [%d][%d]" % (what, r, c)
+            assert t.numel() * t.element_size() >= limbs_bytes(r, c, f), "gemm_l3p: %s holds fewer bytes than a limb-tiled [%d][%d]" % (what, r, c)
     A_lt, W_lt = getattr(A_lt, "data", A_lt), getattr(W_lt, "data", W_lt)
     out_lt = getattr(out_lt, "data", out_lt)
-    check(lib.sculpt_gemm_l3p(_ptr(A_lt), _ptr(W_lt), _ptr(bias), _ptr(residual), residual.stride(0) if residual is not None else 0,
-                              _ptr(out), out.stride(0) if out is not None else 0, _ptr(out_t),
-                              out_t.stride(0) if out_t is not None else 0, int(n_split), _ptr(out_lt), int(M), int(N), int(K),
-                              int(epilogue), _stream()))
+    check(lib.sculpt_gemm_l3p(_ptr(A_lt), _ptr(W_lt), LIMB_FORMATS[fmt], float(alpha), _ptr(bias), _ptr(residual),
+                              residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0) if out is not None else 0,
+                              _ptr(out_t), out_t.stride(0) if out_t is not None else 0, int(n_split), _ptr(out_lt),
+                              LIMB_FORMATS[out_fmt], int(M), int(N), int(K), int(epilogue), _stream()))
 
 
 def softmax_rows_f32(x, rows, cols, pad_cols):
@@ -773,7 +799,8 @@ def attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_b
         assert o_bs % O.cols == 0
     check(lib.sculpt_attention_f32_l3_batched(_ptr(Q), Q.stride(0), int(q_bs), _ptr(K), K.stride(0), int(k_bs), _ptr(Vt), Vt.stride(0),
                                               int(vt_bs), None if lt else _ptr(O), 0 if lt else O.stride(0), 0 if lt else int(o_bs),
-                                              _ptr(O.data) if lt else None, 0, int(o_bs // O.cols) if lt else 0, O.cols if lt else 0,
+                                              _ptr(O.data) if lt else None, O.code if lt else 0, 0, int(o_bs // O.cols) if lt else 0,
+                                              O.cols if lt else 0,
                                               Tq, Tk, heads, int(batch), float(scale), _stream()))
 
 
@@ -790,7 +817,7 @@ def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False, o_row0=0)
         assert l3, "the exact-fp32 attention is a composition: it needs the scores scratch"
         if isinstance(O, Limbs):   # the output as limbs: row o_row0 + q of the limb-tiled matrix O
             check(lib.sculpt_attention_f32_l3_limbs(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O.data),
-                                                    int(o_row0), O.cols, Tq, Tk, heads, float(scale), _stream()))
+                                                    O.code, int(o_row0), O.cols, Tq, Tk, heads, float(scale), _stream()))
             return
         check(lib.sculpt_attention_f32_l3(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O), O.stride(0),
                                           Tq, Tk, heads, float(scale), _stream()))

@@ -202,7 +202,10 @@ class TSR(KernelEngine):
         """precision: "bf16" (BASELINE config 2: bf16 storage, fp32 accumulate -- what bench.py times),
         "fp32" (parity mode: the whole transformer on the exact-fp32 matrix pipe, like the fp32 reference), or
         "bf16l3" (the fast parity mode: fp32 storage, norms and softmax as in "fp32", every matrix product on the bf16 matrix pipe
-        with both operands split exactly into three bf16 limbs and fp32 accumulation -- fp32-equivalent, csrc/gemm_l3.hip).
+        with both operands split exactly into three bf16 limbs and fp32 accumulation -- fp32-equivalent, csrc/gemm_l3.hip), or
+        "fp16l2" ("bf16l3" with the Linears of the two transformers on TWO fp16 limbs per operand, 22 significant bits, three
+        products per multiply: fp32-equivalent on this model -- scene code 1e-6 from the fp32 reference like "fp32" itself -- at
+        two thirds of the time; activations beyond 65504 in magnitude make the scene code non-finite, which forward() refuses).
         decoder_precision: how the 64x64 hidden layers of the dense density query (extract_mesh's 256^3 grid) are evaluated.
           "bf16l3" (default): fp32-equivalent -- both operands split EXACTLY into three bf16 limbs (24 significant bits, fp32
                    exponent range), six exact products per weight on the bf16 matrix pipe, fp32 accumulation; no range
@@ -216,8 +219,8 @@ class TSR(KernelEngine):
           error reaches the calibrated margin (8 x the largest error measured on a 64^3 probe of the first scene code); every call is
           guarded by the largest coarse error seen at the re-evaluated points and redone in full when that exceeds a third of the
           margin (filter_info counts both).  False: every lattice point with the three-limb arithmetic."""
-        if precision not in ("bf16", "fp32", "bf16l3"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'bf16l3'")
+        if precision not in ("bf16", "fp32", "bf16l3", "fp16l2"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'bf16l3' or 'fp16l2'")
         if decoder_precision not in ("fp32", "bf16l3", "bf16x3", "fp16x3"):
             raise ValueError("decoder_precision must be 'bf16l3', 'fp32', 'fp16x3' or 'bf16x3'")
         self.decoder_precision = decoder_precision
@@ -295,10 +298,12 @@ class TSR(KernelEngine):
         wt = _bf if self.precision == "bf16" else _f32  # GEMM weight storage
         # "limbs once" (engine.py): in the three-limb mode the Linears of the two transformers keep their weights split
         # (the attention must be the fused kernel: the three-launch composition, SCULPT_L3_ATTN_FUSED=0, has no limb output)
-        self.l3p = (self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0"
-                    and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0")
-        wh = (lambda x, d, geglu=False: ops.Limbs.of(_f32(ops.geglu_row_blocks(torch.as_tensor(x)) if geglu else x, d))) if self.l3p \
-            else (lambda x, d, geglu=False: wt(x, d))
+        self.l3p = self.precision == "fp16l2" or (self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0"
+                                                  and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0")
+        self.limb_format = "f16x2" if self.precision == "fp16l2" else "bf16x3"
+        fmt = self.limb_format
+        wh = (lambda x, d, geglu=False: ops.Limbs.of(_f32(ops.geglu_row_blocks(torch.as_tensor(x)) if geglu else x, d), fmt=fmt,
+                                                     weight=True)) if self.l3p else (lambda x, d, geglu=False: wt(x, d))
         v, b = cfg["image_tokenizer"], cfg["backbone"]
         H = v["hidden_size"]
         w = {}
@@ -469,7 +474,7 @@ class TSR(KernelEngine):
         nh, hd = b["num_attention_heads"], b["attention_head_dim"]
         D = nh * hd
         if self.l3p and not isinstance(ctx, ops.Limbs):   # tokens handed over as a plain fp32 matrix (backbone_tokens): split here
-            ctx = ops.Limbs.of(ctx.to(torch.float32).contiguous())
+            ctx = ops.Limbs.of(ctx.to(torch.float32).contiguous(), fmt=self.limb_format)
         M, Mc = st["h"].shape[0], (ctx.rows if isinstance(ctx, ops.Limbs) else ctx.shape[0])
         T, Ts = M // batch, Mc // batch
         Tc = Ts if ctx_tokens is None else ctx_tokens
@@ -722,7 +727,13 @@ class TSR(KernelEngine):
             else:   # the reference's batched pass (system.py:82-115)
                 _, outb = self.encode_images(group)
                 codes.append(self.scene_code(outb, len(group)))
-        return torch.cat(codes, 0) if len(codes) > 1 else codes[0]
+        out = torch.cat(codes, 0) if len(codes) > 1 else codes[0]
+        if self.precision == "fp16l2" and not bool(torch.isfinite(out).all()):
+            # an fp16 limb overflowed (an activation of 65504 or more in magnitude) or the input was not finite: never hand on a
+            # silently wrong scene code -- "bf16l3" has the fp32 exponent range
+            raise _lib.SculptError('TSR(precision="fp16l2"): the scene code is not finite (an activation left the fp16 range); '
+                                   'use precision="bf16l3"')
+        return out
 
     __call__ = forward
 

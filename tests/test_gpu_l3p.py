@@ -227,3 +227,87 @@ def test_l3p_smallest_and_ragged_shapes(M, N, K, monkeypatch):
     ops.gemm_f32(A, Wg, bias=bg, out=want, epilogue=_lib.EPI_GEGLU, l3=True)
     ops.gemm_l3p(A_lt, ops.Limbs.of(ops.geglu_row_blocks(Wg)), M, 64, K, bias=bg, out=got, epilogue=_lib.EPI_GEGLU)
     assert torch.equal(got, want)
+
+
+def test_two_fp16_limbs_format():
+    """LIMBS_F16X2: the split keeps 22 bits (an absolute 2^-25 for small values), a weight travels pre-scaled into the fp16 range,
+    the GEMM's three products are fp32-equivalent on operands that already fit 22 bits and within 2^-21 of Sum |a||w| otherwise;
+    LayerNorm / attention / GELU epilogues write the same limbs as the stand-alone split of their fp32 results."""
+    import math
+
+    from sculptmate_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 300, 256, 160
+    A, W, bias = _rand((M, K), g), _rand((N, K), g, 0.03), _rand((N,), g)
+    A_lt, W_lt = ops.Limbs.of(A, fmt="f16x2"), ops.Limbs.of(W, fmt="f16x2", weight=True)
+    assert W_lt.scale >= 2.0 ** 14 and math.log2(W_lt.scale).is_integer()
+    ja, jw = A_lt.float(), W_lt.float()
+    assert float((ja - A).abs().max()) <= 2.0 ** -22 * float(A.abs().max()) and float(((ja - A).abs() / A.abs().clamp_min(0.125)).max()) <= 2.0 ** -22
+    assert float(((jw - W).abs() / W.abs().clamp_min(1e-30)).max()) <= 2.0 ** -21      # scaled: full precision down to tiny weights
+    assert ops.limbs_bytes(M, K, "f16x2") == 10 * K * 128 and A_lt.data.numel() == ops.limbs_bytes(M, K, "f16x2")
+    # the GEMM against fp64 on the SAME 22-bit operands: only the dropped h2.h2 term and fp32 accumulation remain
+    ref = (ja.double() @ jw.double().t() + bias.double())
+    for bm64, nw8 in (("0", "0"), ("1", "0"), ("0", "1")):
+        import os
+        os.environ["SCULPT_L3P_BM64"], os.environ["SCULPT_L3P_NW8"] = bm64, nw8
+        try:
+            got = torch.empty(M, N, device=_dev())
+            ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=got)
+        finally:
+            os.environ.pop("SCULPT_L3P_BM64"); os.environ.pop("SCULPT_L3P_NW8")
+        bound = (ja.abs().double() @ jw.abs().double().t())
+        assert float(((got.double() - ref).abs() / bound).max()) < 3e-7, (bm64, nw8)
+    # and against fp64 on the fp32 operands: 22-bit operand rounding
+    ref32 = A.double() @ W.double().t() + bias.double()
+    bound = A.abs().double() @ W.abs().double().t()
+    assert float(((got.double() - ref32).abs() / bound).max()) < 2.0 ** -20
+    # producers: GELU epilogue, LayerNorm, attention write split(fp32 result)
+    want = torch.empty(M, N, device=_dev())
+    ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=want, epilogue=_lib.EPI_GELU)
+    o_lt = ops.Limbs(M, N, _dev(), zero=True, fmt="f16x2")
+    ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out_lt=o_lt, epilogue=_lib.EPI_GELU)
+    assert torch.equal(o_lt.float(), ops.Limbs.of(want, fmt="f16x2").float())   # (pad rows of the last block differ: never read)
+    x, gamma, beta = _rand((77, 256), g, 3.0), _rand((256,), g), _rand((256,), g)
+    y = torch.empty(77, 256, device=_dev())
+    ops.layernorm(x, gamma, beta, 1e-5, y_f32=y)
+    y_lt = ops.Limbs(77, 256, _dev(), zero=True, fmt="f16x2")
+    ops.layernorm(x, gamma, beta, 1e-5, y_lt=y_lt)
+    assert torch.equal(y_lt.float(), ops.Limbs.of(y, fmt="f16x2").float())
+    Tq, Tk, heads = 200, 130, 4
+    D = heads * 64
+    Q, Kk = _rand((Tq, D), g), _rand((Tk, D), g)
+    Vt = torch.zeros(D, 192, device=_dev()); Vt[:, :Tk] = _rand((D, Tk), g)
+    o = torch.empty(Tq, D, device=_dev())
+    ops.attention_f32(Q, Kk, Vt, o, Tq, Tk, heads, 0.125, None, l3=True)
+    O = ops.Limbs(Tq, D, _dev(), zero=True, fmt="f16x2")
+    ops.attention_f32(Q, Kk, Vt, O, Tq, Tk, heads, 0.125, None, l3=True)
+    assert torch.equal(O.float(), ops.Limbs.of(o, fmt="f16x2").float())
+    # overflow is loud, not silent: a value beyond the fp16 range becomes inf
+    big = A.clone(); big[0, 0] = 1e5
+    assert not bool(torch.isfinite(ops.Limbs.of(big, fmt="f16x2").float()).all())
+
+
+def test_fp16l2_mode_is_fp32_equivalent_on_the_small_model(monkeypatch):
+    """TSR(precision="fp16l2") against the exact-fp32 mode and the three-limb mode: the scene code differs from fp32 by fp32
+    rounding noise (the bound the three-limb mode meets), one image and a batch."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+    from sculptmate_amd.tsr.system import TSR
+
+    sd = synth.tsr_state(3, SMALL_CFG)
+    imgs = [torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=s, size=SMALL_CFG["cond_image_size"]))).to(_dev()) for s in (1, 2)]
+    codes = {}
+    for prec in ("fp32", "bf16l3", "fp16l2"):
+        m = TSR(SMALL_CFG, pos_embed_mode="size", precision=prec)
+        m.load_state_dict(sd)
+        m.to(_dev())
+        m.max_batch = 2
+        with torch.no_grad():
+            codes[prec] = (m.forward(imgs[0]).clone(), m.forward(imgs).clone())
+        assert (m.limb_format == "f16x2") == (prec == "fp16l2")
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for i in range(2):
+        r3, r2 = rel(codes["bf16l3"][i], codes["fp32"][i]), rel(codes["fp16l2"][i], codes["fp32"][i])
+        print("scene code vs exact fp32: bf16l3 %.2e, fp16l2 %.2e" % (r3, r2))
+        assert r2 < 1e-5 and r2 < 4.0 * r3 + 1e-6

@@ -13,7 +13,7 @@ sd = synth.tsr_state(seed=0)
 img = torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=100))).to(dev)
 codes = {}
 # "bf16l3-split": the same mode with SCULPT_L3P=0, every GEMM splitting its operands while staging them (the form before "limbs once")
-modes = [sys.argv[sys.argv.index("--prof") + 1]] if "--prof" in sys.argv else ["bf16l3", "bf16l3-split", "fp32", "bf16"]
+modes = [sys.argv[sys.argv.index("--prof") + 1]] if "--prof" in sys.argv else ["fp16l2", "bf16l3", "bf16l3-split", "fp32", "bf16"]
 with torch.no_grad():
     for mode in modes:
         os.environ["SCULPT_L3P"] = "0" if mode.endswith("-split") else "1"
@@ -33,5 +33,7 @@ with torch.no_grad():
 rel = lambda a, b: float((a - b).norm() / b.norm())
 if "bf16l3" in codes and "bf16l3-split" in codes:
     print("scene code, limbs once vs split in every GEMM: identical %s" % torch.equal(codes["bf16l3"], codes["bf16l3-split"]))
+if "fp32" in codes and "fp16l2" in codes:
+    print("scene code: fp16l2 vs exact fp32 rel %.3e" % rel(codes["fp16l2"], codes["fp32"]))
 if "fp32" in codes and "bf16l3" in codes:
     print("scene code: bf16l3 vs exact fp32 rel %.3e; bf16 vs exact fp32 rel %.3e" % (rel(codes["bf16l3"], codes["fp32"]), rel(codes["bf16"], codes["fp32"])))
