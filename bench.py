@@ -318,14 +318,16 @@ def batched_rates(model, imgs, steps):
     return res
 
 
-def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps):
-    """The fast parity mode, TSR(precision="bf16l3"): fp32 storage, every matrix product of the transformer (Linears, QK^T, PV)
-    with both operands split exactly into three bf16 limbs and fp32 accumulation, fp32 norms / softmax -- the mode that meets
-    north_star's 1e-4 vertex tolerance against the fp32 CPU reference.  Timed like `value` (image resident, mesh left in HBM);
-    its 128^3 mesh against the oracle's fp32 CPU mesh of the same image (the same comparison as parity.bf16_mesh_vs_fp32_cpu)."""
+def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps, precision="fp16l2"):
+    """The tolerance modes: fp32 storage, fp32 norms / softmax, every matrix product of the transformer on the 16-bit matrix pipe
+    through limbs with fp32 accumulation -- the modes that meet north_star's 1e-4 vertex tolerance against the fp32 CPU reference.
+    precision="bf16l3": both operands of every product (Linears, QK^T, PV) split exactly into three bf16 limbs, six products;
+    "fp16l2" (round 5, the faster one): the Linears on two fp16 limbs per operand (22 bits), three products, the rest as bf16l3.
+    Timed like `value` (image resident, mesh left in HBM); the 128^3 mesh against the oracle's fp32 CPU mesh of the same image
+    (the same comparison as parity.bf16_mesh_vs_fp32_cpu)."""
     from sculptmate_amd.tsr import TSR
 
-    m = TSR(pos_embed_mode="scale_factor", precision="bf16l3", decoder_precision=model.decoder_precision)
+    m = TSR(pos_embed_mode="scale_factor", precision=precision, decoder_precision=model.decoder_precision)
     m.load_state_dict(model.state_dict())   # the calibrated density bias included
     m.to(model.device)
     n = max(3, min(steps, 10))
@@ -341,13 +343,16 @@ def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps):
         m.extract_meshes(codes, False, MC_RES, THRESHOLD)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"mode": 'TSR(precision="bf16l3")', "forward_ms": float(np.median([a.elapsed_time(b) for a, b in ev])),
-           "ms_per_step": dt / n * 1e3, "meshes_per_s": n / dt,
-           "dtype": "f32 storage; matrix products: bf16 3-limb split of both operands (24 bits), fp32 accumulate; f32 norms / softmax",
-           # 2.96 TFLOP algorithmic per image; x 6 limb products executed on the bf16 pipe
+    dtype = ("f32 storage; matrix products: bf16 3-limb split of both operands (24 bits), fp32 accumulate; f32 norms / softmax"
+             if precision == "bf16l3" else
+             "f32 storage; Linears: fp16 2-limb operands (22 bits), 3 products; attention products: bf16 3-limb (24 bits), 6 products; "
+             "fp32 accumulate; f32 norms / softmax")
+    out = {"mode": 'TSR(precision="%s")' % precision, "forward_ms": float(np.median([a.elapsed_time(b) for a, b in ev])),
+           "ms_per_step": dt / n * 1e3, "meshes_per_s": n / dt, "dtype": dtype,
+           # 2.96 TFLOP algorithmic per image (2.10 in the Linears, 0.86 in the attention products); x 6 (3) limb products executed
            "transformer_tflops_algorithmic": None, "steps_timed": n}
     out["transformer_tflops_algorithmic"] = 2.96 / (out["forward_ms"] * 1e-3)
-    out["mfma_executed_tflops"] = 6 * 2.96 / (out["forward_ms"] * 1e-3)
+    out["mfma_executed_tflops"] = (6 * 2.96 if precision == "bf16l3" else 3 * 2.10 + 6 * 0.86) / (out["forward_ms"] * 1e-3)
     # operands split once (weights at load time, activations by their producers; csrc/gemm_l3p.hip) -- SCULPT_L3P=0: in every GEMM
     out["limbs_once"] = bool(getattr(m, "l3p", False))
     try:   # the same mode with four images per transformer pass (TSR.forward on a list; every attention one launch over batch x heads)
@@ -371,8 +376,8 @@ def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps):
     if cpu_verts is not None:
         gm = m.run_async(imgs_np[0], 128, THRESHOLD).result()
         d = mesh_distance(gm.vertices, cpu_verts, 1.74)
-        d["what"] = ("128^3, bench image 0, threshold 25: bf16l3 transformer + %s decoder vs the oracle's fp32 CPU path; two-sided "
-                     "nearest-vertex distance / 1.74 (north_star: 1e-4)" % model.decoder_precision)
+        d["what"] = ("128^3, bench image 0, threshold 25: %s transformer + %s decoder vs the oracle's fp32 CPU path; two-sided "
+                     "nearest-vertex distance / 1.74 (north_star: 1e-4)" % (precision, model.decoder_precision))
         out["mesh_vs_fp32_cpu"] = d
     del m
     torch.cuda.empty_cache()
@@ -883,7 +888,9 @@ def main():
             if DECODER_PRECISION == "bf16l3" and not args.no_extras:
                 try:
                     with torch.no_grad():
-                        out["parity_mode"] = parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, args.steps)
+                        out["parity_mode"] = parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, args.steps, "fp16l2")
+                        # the all-three-limb mode of round 4 beside it (same measurement)
+                        out["parity_mode"]["bf16l3"] = parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, args.steps, "bf16l3")
                 except Exception as e:  # an extra must never take the headline line down
                     out["parity_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:

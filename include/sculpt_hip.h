@@ -358,14 +358,19 @@ size_t sculpt_limbs_bytes(int rows, int K, int format);
 int sculpt_layernorm_limbs(const float *x, int ldx, const float *gamma, const float *beta, float eps, void *y_lt, int format,
                            float *y_f32, int ldy, int rows, int cols, sculpt_stream_t stream);
 int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt, int format,
-                                  int o_row0, int o_cols, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream);
+                                  int o_row0, int o_cols, int Tq, int Tk, int heads, float scale, int two_fp16_limbs,
+                                  sculpt_stream_t stream);
 /* `batch` fused three-limb attentions of one shape in ONE launch (TSR.forward on a list of images in the tolerance mode): entry b
  * reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (element strides, multiples of 4; vt_bs may be a column offset into one
  * [heads*64][ldvt] array) and writes O + b*o_bs -- or, with O null and O_lt given, rows o_row0 + b*o_row_bs .. of the limb-tiled
- * output of o_cols columns in `format`. */
+ * output of o_cols columns in `format`.
+ * two_fp16_limbs != 0 (both entries): both products on TWO fp16 limbs per operand (22 bits; csrc/attention_l2.hip) instead of three
+ * bf16 limbs where the pipelined 256-query form runs (the small launches keep three limbs): half the matrix work, the arithmetic
+ * of TSR(precision="fp16l2"); the operands of an attention -- scaled queries, keys, values, probabilities -- are O(1). */
 int sculpt_attention_f32_l3_batched(const float *Q, int ldq, int64_t q_bs, const float *K, int ldk, int64_t k_bs, const float *Vt,
                                     int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt, int format, int o_row0,
-                                    int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch, float scale, sculpt_stream_t stream);
+                                    int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch, float scale, int two_fp16_limbs,
+                                    sculpt_stream_t stream);
 int sculpt_limbs_split(const float *src, int ld, int rows, int K, float scale, int format, void *dst, sculpt_stream_t stream);
 int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha, const float *bias, const float *residual, int ldr,
                     float *out, int ldo, float *out_t, int ldt, int n_split, void *out_lt, int out_format, int M, int N, int K,

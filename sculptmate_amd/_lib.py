@@ -107,9 +107,9 @@ SIGNATURES = {
     "sculpt_gemm_f32": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_attention_f32_l3": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "sculpt_limbs_bytes": (_sz, [_i, _i, _i]),
-    "sculpt_attention_f32_l3_batched": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_attention_f32_l3_batched": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_layernorm_limbs": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "sculpt_attention_f32_l3_limbs": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sculpt_attention_f32_l3_limbs": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sculpt_limbs_split": (_i, [_vp, _i, _i, _i, _f, _i, _vp, _vp]),
     "sculpt_gemm_l3p": (_i, [_vp, _vp, _i, _f, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "sculpt_gemm_f32_ex": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i64, _i64, _i64, _vp]),

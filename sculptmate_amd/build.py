@@ -18,7 +18,7 @@ ARCH = "gfx950"
 # v_pk_mul_f32, which cost ~10 issue cycles each and break the overlap with the bf16 MFMAs they are interleaved with
 # (tools/micro/mfma_fill.hip); the kernels that want packed operations ask for them with vector types.
 PER_FILE_FLAGS = {"triplane.hip": ["-fno-slp-vectorize"], "density_filter.hip": ["-fno-slp-vectorize"], "attention_pipe.hip": ["-fno-slp-vectorize"],
-                  "gemm_l3.hip": ["-fno-slp-vectorize"], "attention_l3.hip": ["-fno-slp-vectorize"]}
+                  "gemm_l3.hip": ["-fno-slp-vectorize"], "attention_l3.hip": ["-fno-slp-vectorize"], "attention_l2.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

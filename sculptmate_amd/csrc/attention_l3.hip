@@ -62,10 +62,6 @@ __device__ __forceinline__ void al_split8(const float (&x)[8], abf16x8 &f1, abf1
     f3 = __builtin_bit_cast(abf16x8, v3);
 }
 
-// blockIdx.z = batch entry (`batch` independent attentions of one shape in one launch): element strides of Q, K, Vt (a column
-// offset when the V^T of the entries sit side by side) and O; for a limb output the entry's first ROW
-struct AttnL3Batch { long q_bs, k_bs, vt_bs, o_bs; int o_row_bs; int o_fmt; };
-
 __global__ __launch_bounds__(256, 2) void attention_l3_kernel(const float *__restrict__ Q, int ldq, const float *__restrict__ K, int ldk,
                                                               const float *__restrict__ Vt, int ldvt, float *__restrict__ O, int ldo,
                                                               int Tq, int Tk, float scale_log2e, unsigned char *__restrict__ O_lt,
@@ -551,7 +547,7 @@ using namespace sculpt;
 
 static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, float *O, int ldo, void *O_lt,
                            int o_row0, int o_k8, int Tq, int Tk, int heads, float scale, sculpt_stream_t stream, int batch = 1,
-                           AttnL3Batch ab = AttnL3Batch{0, 0, 0, 0, 0, 0}) {
+                           AttnL3Batch ab = AttnL3Batch{0, 0, 0, 0, 0, 0}, int two_fp16_limbs = 0) {
     SC_REQUIRE(batch >= 1 && batch <= 65535, "attention_f32_l3: bad batch %d", batch);
     SC_REQUIRE(ab.o_fmt == LT_BF16X3 || ab.o_fmt == LT_F16X2, "attention_f32_l3: unknown limb format %d", ab.o_fmt);
     SC_REQUIRE(batch == 1 || (ab.q_bs % 4 == 0 && ab.k_bs % 4 == 0 && ab.vt_bs % 4 == 0 && ab.o_bs % 4 == 0 && ab.o_row_bs >= 0),
@@ -568,7 +564,12 @@ static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, con
     // queries x 16 heads = 192 workgroups --; otherwise (the image tokenizer: 1025 queries x 12 heads) the plain 4-wave form
     const char *e = getenv("SCULPT_L3_ATTN_PIPE");   // 0 / 1: never / always the pipelined form (A/B); read per call
     const bool pipe = e ? atoi(e) != 0 : (long)cdiv(Tq, 256) * heads * batch * 3 >= 2L * num_cus();
-    if (!pipe)
+    // two fp16 limbs per operand (attention_l2.hip: half the matrix work) where the pipelined form runs; the small launches (the
+    // image tokenizer's) stay on the three-limb 4-wave kernel
+    if (pipe && two_fp16_limbs)
+        attention_l2_pipe_launch(dim3(cdiv(Tq, 256), heads, batch), as_stream(stream), Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk,
+                                 scale * 1.44269504088896340736f, olt, o_row0, o_k8, ab);
+    else if (!pipe)
         hipLaunchKernelGGL(attention_l3_kernel, dim3(cdiv(Tq, 128), heads, batch), dim3(256), 0, as_stream(stream), Q, ldq, K, ldk, Vt,
                            ldvt, O, ldo, Tq, Tk, scale * 1.44269504088896340736f, olt, o_row0, o_k8, ab);
     else
@@ -586,10 +587,10 @@ extern "C" int sculpt_attention_f32_l3(const float *Q, int ldq, const float *K, 
 
 extern "C" int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt, void *O_lt,
                                              int format, int o_row0, int o_cols, int Tq, int Tk, int heads, float scale,
-                                             sculpt_stream_t stream) {
+                                             int two_fp16_limbs, sculpt_stream_t stream) {
     SC_REQUIRE(O_lt && o_cols % 32 == 0, "attention_f32_l3_limbs: null output or o_cols=%d not a multiple of 32", o_cols);
     return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, nullptr, 0, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream, 1,
-                           AttnL3Batch{0, 0, 0, 0, 0, format});
+                           AttnL3Batch{0, 0, 0, 0, 0, format}, two_fp16_limbs);
 }
 
 /* `batch` attentions of one shape in ONE launch (grid z): entry b reads Q + b*q_bs, K + b*k_bs, Vt + b*vt_bs (element strides,
@@ -598,9 +599,9 @@ extern "C" int sculpt_attention_f32_l3_limbs(const float *Q, int ldq, const floa
 extern "C" int sculpt_attention_f32_l3_batched(const float *Q, int ldq, int64_t q_bs, const float *K, int ldk, int64_t k_bs,
                                                const float *Vt, int ldvt, int64_t vt_bs, float *O, int ldo, int64_t o_bs, void *O_lt,
                                                int format, int o_row0, int o_row_bs, int o_cols, int Tq, int Tk, int heads, int batch,
-                                               float scale, sculpt_stream_t stream) {
+                                               float scale, int two_fp16_limbs, sculpt_stream_t stream) {
     SC_REQUIRE((O != nullptr) != (O_lt != nullptr), "attention_f32_l3_batched: exactly one of O / O_lt");
     SC_REQUIRE(!O_lt || o_cols % 32 == 0, "attention_f32_l3_batched: o_cols=%d not a multiple of 32", o_cols);
     return attention_l3_go(Q, ldq, K, ldk, Vt, ldvt, O, ldo, O_lt, o_row0, o_cols / 8, Tq, Tk, heads, scale, stream, batch,
-                           AttnL3Batch{(long)q_bs, (long)k_bs, (long)vt_bs, (long)o_bs, o_row_bs, O_lt ? format : 0});
+                           AttnL3Batch{(long)q_bs, (long)k_bs, (long)vt_bs, (long)o_bs, o_row_bs, O_lt ? format : 0}, two_fp16_limbs);
 }

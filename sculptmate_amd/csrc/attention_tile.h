@@ -37,6 +37,15 @@ struct AttnBatch {
     long q_bs, k_bs, vt_bs, o_bs;
 };
 
+// The fused attentions of the tolerance modes (attention_l3.hip, attention_l2.hip).  blockIdx.z = batch entry (`batch` independent
+// attentions of one shape in one launch): element strides of Q, K, Vt (a column offset when the V^T of the entries sit side by
+// side) and O; for a limb output the entry's first ROW and the limb format (limbs.h)
+struct AttnL3Batch { long q_bs, k_bs, vt_bs, o_bs; int o_row_bs; int o_fmt; };
+// attention_l2.hip: the pipelined 8-wave kernel with two fp16 limbs per operand
+void attention_l2_pipe_launch(dim3 grid, hipStream_t st, const float *Q, int ldq, const float *K, int ldk, const float *Vt, int ldvt,
+                              float *O, int ldo, int Tq, int Tk, float scale_log2e, unsigned char *O_lt, int o_row0, int o_k8,
+                              AttnL3Batch ab);
+
 // attention_pipe.hip: the pipelined loop for pre-scaled queries, 128 (nqb 4) or 192 (nqb 6) queries per workgroup
 void attention_pipe_launch(int nqb, dim3 grid, dim3 block, hipStream_t st, const uint16_t *Q, int ldq, const uint16_t *K, int ldk,
                            const uint16_t *Vt, int ldvt, uint16_t *O, int ldo, int Tq, int Tk, AttnBatch ab);

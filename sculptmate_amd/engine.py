@@ -117,14 +117,15 @@ class KernelEngine:
             Tkp = ((Tk + 31) // 32) * 32 if self.l3 else ((Tk + 15) // 16) * 16
             assert (batch - 1) * vt_bs + Tkp <= Vt.shape[1], "V^T too narrow for the last batch entry (%d + %d > %d)" % (
                 (batch - 1) * vt_bs, Tkp, Vt.shape[1])
+        h2 = self.precision == "fp16l2"   # both products on two fp16 limbs where the pipelined form runs
         if fused and batch > 1:   # one launch over batch x heads (grid z), fp32 or limb output
-            return ops.attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
+            return ops.attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs, two_fp16_limbs=h2)
         for b in range(batch):
             q, k = Q[b * q_bs // Q.stride(0):] if b else Q, K[b * k_bs // K.stride(0):] if b else K
             vt = Vt[:, b * vt_bs:] if b else Vt
             if isinstance(O, ops.Limbs):   # fused three-limb attention writing limbs: entry b starts at row b * o_bs / cols
                 assert fused
-                ops.attention_f32(q, k, vt, O, Tq, Tk, heads, scale, None, l3=True, o_row0=b * o_bs // O.cols)
+                ops.attention_f32(q, k, vt, O, Tq, Tk, heads, scale, None, l3=True, o_row0=b * o_bs // O.cols, two_fp16_limbs=h2)
                 continue
             o = O[b * o_bs // O.stride(0):] if b else O
             for h0, nh, scores in chunks:

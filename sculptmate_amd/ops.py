@@ -791,7 +791,7 @@ def softmax_rows_f32(x, rows, cols, pad_cols):
     check(lib.sculpt_softmax_rows_f32(_ptr(x), x.stride(0), rows, cols, pad_cols, _stream()))
 
 
-def attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs):
+def attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs, two_fp16_limbs=False):
     """`batch` fused three-limb attentions in one launch (sculpt_attention_f32_l3_batched); O an fp32 tensor (o_bs in elements) or a
     Limbs (o_bs in elements of its logical [rows][cols] matrix: entry b starts at row b * o_bs / cols)."""
     lt = isinstance(O, Limbs)
@@ -801,10 +801,10 @@ def attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_b
                                               int(vt_bs), None if lt else _ptr(O), 0 if lt else O.stride(0), 0 if lt else int(o_bs),
                                               _ptr(O.data) if lt else None, O.code if lt else 0, 0, int(o_bs // O.cols) if lt else 0,
                                               O.cols if lt else 0,
-                                              Tq, Tk, heads, int(batch), float(scale), _stream()))
+                                              Tq, Tk, heads, int(batch), float(scale), 1 if two_fp16_limbs else 0, _stream()))
 
 
-def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False, o_row0=0):
+def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False, o_row0=0, two_fp16_limbs=False):
     """softmax(Q K^T scale) V per head in fp32: two GEMMs and a row softmax per head.
     Q [Tq][*], K [Tk][*] with head h at columns 64h..; Vt [heads*64][>= round_up(Tk,32)] (zero padded).
     scores: fp32 scratch.  [Tq][>= round_up(Tk,32)]: the heads run one after the other (three launches each);
@@ -817,8 +817,11 @@ def attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, scores, l3=False, o_row0=0)
         assert l3, "the exact-fp32 attention is a composition: it needs the scores scratch"
         if isinstance(O, Limbs):   # the output as limbs: row o_row0 + q of the limb-tiled matrix O
             check(lib.sculpt_attention_f32_l3_limbs(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O.data),
-                                                    O.code, int(o_row0), O.cols, Tq, Tk, heads, float(scale), _stream()))
+                                                    O.code, int(o_row0), O.cols, Tq, Tk, heads, float(scale), 1 if two_fp16_limbs else 0,
+                                                    _stream()))
             return
+        if two_fp16_limbs:   # fp32 output through the batched entry (one entry)
+            return attention_f32_l3_batched(Q, K, Vt, O, Tq, Tk, heads, scale, 1, 0, 0, 0, 0, two_fp16_limbs=True)
         check(lib.sculpt_attention_f32_l3(_ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(Vt), Vt.stride(0), _ptr(O), O.stride(0),
                                           Tq, Tk, heads, float(scale), _stream()))
         return

@@ -311,3 +311,42 @@ def test_fp16l2_mode_is_fp32_equivalent_on_the_small_model(monkeypatch):
         r3, r2 = rel(codes["bf16l3"][i], codes["fp32"][i]), rel(codes["fp16l2"][i], codes["fp32"][i])
         print("scene code vs exact fp32: bf16l3 %.2e, fp16l2 %.2e" % (r3, r2))
         assert r2 < 1e-5 and r2 < 4.0 * r3 + 1e-6
+
+
+@pytest.mark.parametrize("Tq,Tk,heads,gain", [(3072, 3072, 16, 1.0), (3072, 1025, 16, 1.0), (600, 333, 4, 1.0), (300, 64, 2, 6.0), (257, 1, 1, 1.0)])
+def test_two_fp16_limb_attention_vs_fp64(Tq, Tk, heads, gain, monkeypatch):
+    """csrc/attention_l2.hip (both products on two fp16 limbs per operand, three limb products) against an fp64 softmax(QK^T s)V of
+    the same fp32 operands: the error of the three-limb kernel's class (fp32 rounding of the softmax), ragged key tiles, one key,
+    sharp distributions; fp32 and limb outputs; a batch."""
+    import math
+
+    from sculptmate_amd import ops
+
+    monkeypatch.setenv("SCULPT_L3_ATTN_PIPE", "1")     # the pipelined form on every shape (the small ones default to the 4-wave kernel)
+    g = torch.Generator().manual_seed(Tq + Tk)
+    D = heads * 64
+    Q, K = _rand((Tq, D), g, gain), _rand((Tk, D), g)
+    ldv = ((Tk + 63) // 64) * 64
+    Vt = torch.zeros(D, ldv, device=_dev()); Vt[:, :Tk] = _rand((D, Tk), g)
+    scale = 1.0 / math.sqrt(64)
+    qh = Q.double().view(Tq, heads, 64).transpose(0, 1); kh = K.double().view(Tk, heads, 64).transpose(0, 1)
+    vh = Vt[:, :Tk].t().double().view(Tk, heads, 64).transpose(0, 1)
+    ref = (torch.softmax(qh @ kh.transpose(1, 2) * scale, -1) @ vh).transpose(0, 1).reshape(Tq, D)
+    o3 = torch.empty(Tq, D, device=_dev()); o2 = torch.full((Tq, D), float("nan"), device=_dev())
+    ops.attention_f32(Q, K, Vt, o3, Tq, Tk, heads, scale, None, l3=True)
+    ops.attention_f32(Q, K, Vt, o2, Tq, Tk, heads, scale, None, l3=True, two_fp16_limbs=True)
+    e3, e2 = float((o3.double() - ref).norm() / ref.norm()), float((o2.double() - ref).norm() / ref.norm())
+    print("Tq %d Tk %d: rel err vs fp64: three bf16 limbs %.2e, two fp16 limbs %.2e" % (Tq, Tk, e3, e2))
+    assert torch.isfinite(o2).all() and e2 < 2e-6 and e2 < 4.0 * e3 + 2e-7
+    O = ops.Limbs(Tq + 32, D, _dev(), zero=True, fmt="f16x2")
+    ops.attention_f32(Q, K, Vt, O, Tq, Tk, heads, scale, None, l3=True, o_row0=32, two_fp16_limbs=True)
+    assert torch.equal(O.float()[32:], ops.Limbs.of(o2, fmt="f16x2").float())
+    if Tq == 600:   # two entries in one launch, V^T side by side
+        Ts = ((Tk + 7) // 8) * 8
+        Q2, K2 = torch.cat([Q, Q.flip(0)]), torch.zeros(2 * Ts, D, device=_dev())
+        K2[:Tk], K2[Ts:Ts + Tk] = K, K.flip(0)
+        Vt2 = torch.zeros(D, Ts + ldv, device=_dev()); Vt2[:, :Tk] = Vt[:, :Tk]; Vt2[:, Ts:Ts + Tk] = Vt[:, :Tk].flip(1)
+        got = torch.empty(2 * Tq, D, device=_dev())
+        ops.attention_f32_l3_batched(Q2, K2, Vt2, got, Tq, Tk, heads, scale, 2, Tq * D, Ts * D, Ts, Tq * D, two_fp16_limbs=True)
+        assert torch.equal(got[:Tq], o2)
+        assert float((got[Tq:].flip(0).double() - ref).norm() / ref.norm()) < 2e-6

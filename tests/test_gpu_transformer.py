@@ -751,7 +751,7 @@ def test_run_async_pipeline_and_pinned_buffer_lifetime(cuda):
         assert np.array_equal(q.result().vertices, want[i % 4][0])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16l3", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16l3", "fp16l2", "bf16"])
 def test_full_size_forward_is_reproducible_call_after_call(cuda, precision, monkeypatch):
     """The same image through the same model gives the same bits on every call, in every precision mode -- with the attention
     score scratch capped so that the backbone's heads go through it in chunks (round 5: the exact-fp32 mode's scratch is one
@@ -816,7 +816,7 @@ def test_generator_facade_in_the_tolerance_mode(cuda, tmp_path):
     _write_checkpoint(str(tmp_path), SMALL_CFG, seed=61)
     img = (synth.composite_rgb(synth.image_rgba(seed=62, size=SMALL_CFG["cond_image_size"])) * 255).astype(np.uint8)
     meshes = {}
-    for prec in ("bf16l3", "fp32"):
+    for prec in ("bf16l3", "fp16l2", "fp32"):
         g = TripoGenerator(cuda)
         assert g.precision == "bf16"
         g.precision = prec
@@ -832,6 +832,8 @@ def test_generator_facade_in_the_tolerance_mode(cuda, tmp_path):
         assert g.generate_mesh(img, "m") == 0
         meshes[prec] = got[-1]
     assert_mesh_close(meshes["bf16l3"][0], meshes["bf16l3"][1], meshes["fp32"][0], meshes["fp32"][1], tol=1e-4 * 1.74)
+    # the faster tolerance mode (two fp16 limbs in the Linears, round 5): the same bound
+    assert_mesh_close(meshes["fp16l2"][0], meshes["fp16l2"][1], meshes["fp32"][0], meshes["fp32"][1], tol=1e-4 * 1.74)
 
 
 def _median_density(model, codes, R):
@@ -970,7 +972,26 @@ def test_full_size_tsr_forward_vs_oracle(cuda):
     rv2 = rv2 * np.float32(0.87 - (-0.87)) + np.float32(-0.87)
     info2 = assert_mesh_close(mesh2.vertices.cpu().numpy(), mesh2.faces.cpu().numpy(), rv2, rf2, tol=1e-4 * 1.74)
     print("image -> mesh at %d^3 in bf16l3 mode, filtered grid: %d vertices, %s" % (R2, mesh2.vertices.shape[0], info2))
+    del mesh2
+    # the faster tolerance mode, TSR(precision="fp16l2") -- the Linears of the two transformers on two fp16 limbs per operand (22
+    # bits, three products per multiply): the same three assertions -- scene code within fp32 rounding of the oracle, image -> mesh
+    # within 1e-4 at 128^3 and, through the filtered grid, at 256^3
+    del ml3
+    torch.cuda.empty_cache()
+    ml2 = TSR(pos_embed_mode="scale_factor", precision="fp16l2")
+    ml2.load_state_dict(sd)
+    ml2.to(cuda)
+    cl2 = ml2([img], device=cuda)
+    rell2, _ = _rel(cl2[0], ref32)
+    print("full-size scene code, fp16l2 mode: rel %.3e (bf16l3 %.3e, exact fp32 %.3e)" % (rell2, rell3, rel32))
+    assert rell2 < 1e-4 and rell2 < 2.0 * rel32 + 1e-6, (rell2, rel32)
+    meshl2 = ml2.extract_meshes(cl2, resolution=R, threshold=thr)[0]
+    infol2 = assert_mesh_close(meshl2.vertices.cpu().numpy(), meshl2.faces.cpu().numpy(), rv, rf, tol=1e-4 * 1.74)
+    mesh2 = ml2.extract_meshes(cl2, resolution=R2, threshold=thr2)[0]
+    info2b = assert_mesh_close(mesh2.vertices.cpu().numpy(), mesh2.faces.cpu().numpy(), rv2, rf2, tol=1e-4 * 1.74)
+    print("image -> mesh in fp16l2 mode: 128^3 %s; 256^3 (filtered grid) %s" % (infol2, info2b))
     del dref2, mesh2, rv2, rf2
+    ml3 = ml2
     m32 = ml3   # the bf16-mode comparison below only needs a decoder
     # The DEFAULT mode (bf16 transformer, what bench.py times) against the same fp32 CPU mesh: the scene code is 0.8 % away
     # (bf16 weights and activations through 28 layers), so the iso-surface moves; how far is stated here and in bench.py's

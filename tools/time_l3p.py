@@ -47,7 +47,14 @@ for name, M, N, K, epi, per_fwd in (("backbone QKV", 3072, 3072, 1024, 0, 16), (
         os.environ.pop("SCULPT_L3P_BM64", None); os.environ.pop("SCULPT_L3P_NW8", None)
         ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out_lt=out_lt, epilogue=epi)
     variants["new, limb output"] = f_lt
-    variants["split of A alone"] = lambda: ops.limbs_split(A, out=A_lt)
+    variants["split of A alone"] = lambda: ops.limbs_split(A, out=A_lt.data if hasattr(A_lt, "data") else A_lt)
+    A_h = ops.Limbs.of(A, fmt="f16x2")
+    W_h = ops.Limbs.of(ops.geglu_row_blocks(W) if epi == _lib.EPI_GEGLU else W, fmt="f16x2", weight=True)
+    o3 = torch.empty(M, N, device=dev)
+    def f_h():
+        os.environ.pop("SCULPT_L3P_BM64", None); os.environ.pop("SCULPT_L3P_NW8", None)
+        ops.gemm_l3p(A_h, W_h, M, N, K, bias=bias, out=o3, epilogue=epi)
+    variants["two fp16 limbs"] = f_h
     for f in variants.values(): f()
     torch.cuda.synchronize()
     same = torch.equal(o1, o2)
@@ -56,8 +63,10 @@ for name, M, N, K, epi, per_fwd in (("backbone QKV", 3072, 3072, 1024, 0, 16), (
             res.setdefault(k, []).append(timed(f))
     med = {k: float(np.median(v)) for k, v in res.items()}
     fl = 2.0 * M * rows * K * 6
+    tot_h = globals().get("tot_h", 0.0) + per_fwd * float(np.median(res["two fp16 limbs"])); globals()["tot_h"] = tot_h
+    err_h = float((o3.double() - o1.double()).abs().max() / o1.double().abs().max())
     best = min(v for k, v in med.items() if k.startswith("new") and "limb" not in k)
     tot_old += per_fwd * med["old"]; tot_new += per_fwd * best
-    print("%-20s M=%d N=%d K=%d: " % (name, M, rows, K) + " | ".join("%s %.1f us (%.2f PF/s)" % (k, v, fl / v / 1e9) if "split" not in k else "%s %.1f us" % (k, v) for k, v in med.items())
-          + " | identical %s" % same, flush=True)
-print("per forward: old %.2f ms, new (better tile) %.2f ms" % (tot_old / 1e3, tot_new / 1e3))
+    print("%-20s M=%d N=%d K=%d: " % (name, M, rows, K) + " | ".join("%s %.1f us (%.2f PF/s)" % (k, v, (fl / 2 if "fp16" in k else fl) / v / 1e9) if "split" not in k else "%s %.1f us" % (k, v) for k, v in med.items())
+          + " | identical %s | two fp16 limbs vs three bf16 limbs: max rel dev %.1e" % (same, err_h), flush=True)
+print("per forward: old %.2f ms, new (better tile) %.2f ms, two fp16 limbs %.2f ms" % (tot_old / 1e3, tot_new / 1e3, tot_h / 1e3))
