@@ -117,9 +117,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
     constexpr int JT = BM / 32 / NWC;     // 32-row activation sub-tiles per wave
     constexpr int ARB = BM / 32;          // activation row blocks per tile
     constexpr int NRB = 4 + ARB;          // row blocks per ring stage: [4 weight | ARB activation]
-    constexpr int RBK = NL * 1024;        // bytes of one K-tile (16 k = 2 chunks x NL limbs x 512 B) of one row block
+    // K-tile per ring stage: one 16-k MFMA step with three limbs; two with two limbs (the same 3 - 4 KiB per row block and stage,
+    // and a barrier every 12 - 24 MFMAs per wave instead of every 6 - 12: FF2 104 -> 9x us, fused Q|K|V 77 -> 6x)
+    constexpr int KT = NL == 2 ? 2 : 1;
+    constexpr int RBK = NL * 1024 * KT;   // bytes of one K-tile (KT x 2 chunks x NL limbs x 512 B) of one row block
     constexpr int STG = NRB * RBK;
-    constexpr int NST = 3;
+    // ring depth: three stages (two K-tiles in flight); two for the 4-wave 128-row two-limb tile (64 KiB: two workgroups per CU)
+    constexpr int NST = (NL == 2 && NW == 4 && BM == 128) ? 2 : 3;
+    constexpr int DIST = NST - 1;
+    constexpr int NPC = NL * KT;          // 1-KiB LDS-DMA pieces per row block and stage
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STG];
     const GemmF32Args &g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,10 +156,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
     do {                                                                                                                    \
         unsigned char *sb = smem + (buf) * STG;                                                                             \
         const long ko = (long)(kt) * RBK;                                                                                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_)                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < NPC; ++q_)                                                                  \
             __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src0 + ko + q_ * 1024), (p_lds_ptr_t)(sb + dst0 + q_ * 1024), 16, 0, 0); \
         if (NRB > NW && two) {                                                                                              \
-            _Pragma("unroll") for (int q_ = 0; q_ < NL; ++q_)                                                               \
+            _Pragma("unroll") for (int q_ = 0; q_ < NPC; ++q_)                                                              \
                 __builtin_amdgcn_global_load_lds((p_gbl_ptr_t)(src1 + ko + q_ * 1024), (p_lds_ptr_t)(sb + dst1 + q_ * 1024), 16, 0, 0); \
         }                                                                                                                   \
     } while (0)
@@ -167,52 +173,55 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    // fragment of limb l: + l * 512; lane (l31, lh): chunk lh of the K-tile, row l31
+    // fragment of limb l: + l * 512; lane (l31, lh): chunk 2 s + lh of the K-tile (s = 16-k step), row l31
     const int wfo = (wr * 2) * RBK + lh * (NL * 512) + l31 * 16;
     const int afo = (4 + wc * JT) * RBK + lh * (NL * 512) + l31 * 16;
 
-    const int nk = g.K >> 4;
+    const int nk = g.K / (16 * KT);
     L3P_STAGE(0, 0);
-    if (nk > 1) L3P_STAGE(1, 1);
+    if (DIST > 1 && nk > 1) L3P_STAGE(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        // wait until K-tile kt has landed; K-tile kt + 1 (if issued) stays in flight
-        if (kt + 1 < nk) {
-            if (NRB > NW && two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        // wait until K-tile kt has landed; with three stages K-tile kt + 1 (if issued) stays in flight
+        if (DIST > 1 && kt + 1 < nk) {
+            if (NRB > NW && two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        // every wave finished reading stage (kt - 1) % 3 == (kt + 2) % 3 before it passed the barrier
-        if (kt + 2 < nk) L3P_STAGE((kt + 2) % NST, kt + 2);
+        // every wave finished reading stage (kt - 1) % NST == (kt + DIST) % NST before it passed the barrier
+        if (kt + DIST < nk) L3P_STAGE((kt + DIST) % NST, kt + DIST);
         const unsigned char *sb = smem + (kt % NST) * STG;
-        pu32x4 wf[2][NL], af[JT][NL];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
+        for (int ss = 0; ss < KT; ++ss) {
+            pu32x4 wf[2][NL], af[JT][NL];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i][l] = *reinterpret_cast<const pu32x4 *>(sb + wfo + i * RBK + l * 512);
+            for (int l = 0; l < NL; ++l) {
 #pragma unroll
-            for (int j = 0; j < JT; ++j) af[j][l] = *reinterpret_cast<const pu32x4 *>(sb + afo + j * RBK + l * 512);
-        }
+                for (int i = 0; i < 2; ++i) wf[i][l] = *reinterpret_cast<const pu32x4 *>(sb + wfo + i * RBK + (2 * ss * NL + l) * 512);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < JT; ++j) {
-                f32x16 c = acc[i][j];   // smallest terms first
-                if constexpr (NL == 3) {   // the order of gemm_l3_kernel
-                    c = l3p_mfma<FMT>(wf[i][0], af[j][2], c);
-                    c = l3p_mfma<FMT>(wf[i][2], af[j][0], c);
-                    c = l3p_mfma<FMT>(wf[i][1], af[j][1], c);
-                    c = l3p_mfma<FMT>(wf[i][0], af[j][1], c);
-                    c = l3p_mfma<FMT>(wf[i][1], af[j][0], c);
-                    c = l3p_mfma<FMT>(wf[i][0], af[j][0], c);
-                } else {
-                    c = l3p_mfma<FMT>(wf[i][1], af[j][0], c);
-                    c = l3p_mfma<FMT>(wf[i][0], af[j][1], c);
-                    c = l3p_mfma<FMT>(wf[i][0], af[j][0], c);
-                }
-                acc[i][j] = c;
+                for (int j = 0; j < JT; ++j) af[j][l] = *reinterpret_cast<const pu32x4 *>(sb + afo + j * RBK + (2 * ss * NL + l) * 512);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    f32x16 c = acc[i][j];   // smallest terms first
+                    if constexpr (NL == 3) {   // the order of gemm_l3_kernel
+                        c = l3p_mfma<FMT>(wf[i][0], af[j][2], c);
+                        c = l3p_mfma<FMT>(wf[i][2], af[j][0], c);
+                        c = l3p_mfma<FMT>(wf[i][1], af[j][1], c);
+                        c = l3p_mfma<FMT>(wf[i][0], af[j][1], c);
+                        c = l3p_mfma<FMT>(wf[i][1], af[j][0], c);
+                        c = l3p_mfma<FMT>(wf[i][0], af[j][0], c);
+                    } else {
+                        c = l3p_mfma<FMT>(wf[i][1], af[j][0], c);
+                        c = l3p_mfma<FMT>(wf[i][0], af[j][1], c);
+                        c = l3p_mfma<FMT>(wf[i][0], af[j][0], c);
+                    }
+                    acc[i][j] = c;
+                }
+        }
     }
 #undef L3P_STAGE
     if (a.out_lt) l3p_epilogue_limbs<EPI, JT>(a, acc, n0, m0, wr, wc, l31, lh);
@@ -336,7 +345,9 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha,
     const char *e8 = getenv("SCULPT_L3P_NW8");     // 0 / 1: never / always 8 waves on the 128-row tile (A/B)
     const long tiles128 = (long)gx * cdiv(M, 128);
     const bool bm64 = e64 ? atoi(e64) != 0 : 2 * tiles128 < num_cus();
-    const bool nw8 = !bm64 && (e8 ? atoi(e8) != 0 : tiles128 <= 3L * num_cus());
+    // (two fp16 limbs, tools/time_l3p_f16_forms.py: the 8-wave form only where a CU holds at most one workgroup -- fused Q|K|V
+    // 77.8 against 80.8 us and FF1 + GEGLU 158 against 173 on 4 waves)
+    const bool nw8 = !bm64 && (e8 ? atoi(e8) != 0 : tiles128 <= (format == LT_F16X2 ? 1L : 3L) * num_cus());
 #define L3P_GO2(E, F)                                                                                                      \
     do {                                                                                                                   \
         if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64, 4, F>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);          \
