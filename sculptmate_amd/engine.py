@@ -5,7 +5,7 @@ fp32:   every GEMM / attention / norm on the exact-fp32 parity kernels (the refe
 fp16l2: "bf16l3" with the hot Linears (limbs once, below) on TWO fp16 limbs per operand: 22 significant bits, three products per
         multiply instead of six; weights are stored pre-scaled into the fp16 range, activations must stay below 65504 in magnitude
         (they are LayerNorm outputs, attention outputs, GELU / GEGLU products; a value beyond it makes the result non-finite, which
-        the model checks).  Attention products and the cold Linears stay on three bf16 limbs.
+        the model checks for and answers with its three-limb twin).  Attention products and the cold Linears stay on three bf16 limbs.
 bf16l3: fp32 storage and fp32 norms / softmax like "fp32", but every matrix product (Linears, QK^T, PV) on the bf16 matrix pipe
         through the exact three-limb split of both operands, fp32 accumulate (csrc/gemm_l3.hip): fp32-equivalent, ~6x faster.
         "Limbs once" (default in this mode, SCULPT_L3P=0 restores the form that splits inside every GEMM): a subclass that

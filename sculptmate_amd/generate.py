@@ -18,7 +18,7 @@ class TripoGenerator(GeneratorFacade):
                the fp32 reference, i.e. the mesh is within 1e-4 of it only GIVEN the same scene code;
       "fp16l2" the faster of the two modes that meet the 1e-4 vertex tolerance against the reference's fp32 CPU path end to end:
                fp32 storage, the Linears and the backbone's attention with two fp16 limbs per operand (22 bits), fp32 accumulate
-               (~2.4x the forward time); refuses a scene code that is not finite (an activation beyond the fp16 range);
+               (~2.4x the forward time); an image whose activations leave the fp16 range is redone on three bf16 limbs;
       "bf16l3" the same tolerance with the fp32 exponent range: every matrix product with both operands split exactly into three
                bf16 limbs, fp32 accumulate (~3.6x the forward time);
       "fp32"   the exact-fp32 matrix instruction (slowest; the parity yard-stick).

@@ -205,7 +205,8 @@ class TSR(KernelEngine):
         with both operands split exactly into three bf16 limbs and fp32 accumulation -- fp32-equivalent, csrc/gemm_l3.hip), or
         "fp16l2" ("bf16l3" with the Linears of the two transformers on TWO fp16 limbs per operand, 22 significant bits, three
         products per multiply: fp32-equivalent on this model -- scene code 1e-6 from the fp32 reference like "fp32" itself -- at
-        two thirds of the time; activations beyond 65504 in magnitude make the scene code non-finite, which forward() refuses).
+        two thirds of the time; an activation beyond 65504 in magnitude makes the scene code non-finite: forward() then repeats the
+        call on a "bf16l3" twin of the model and counts it in range_fallbacks).
         decoder_precision: how the 64x64 hidden layers of the dense density query (extract_mesh's 256^3 grid) are evaluated.
           "bf16l3" (default): fp32-equivalent -- both operands split EXACTLY into three bf16 limbs (24 significant bits, fp32
                    exponent range), six exact products per weight on the bf16 matrix pipe, fp32 accumulation; no range
@@ -232,6 +233,7 @@ class TSR(KernelEngine):
         self.pos_embed_mode = pos_embed_mode
         self.precision = precision
         self.l3p = False   # set by _prepare: the three-limb mode with operands split once (engine.py)
+        self.range_fallbacks = 0   # fp16l2: forward() calls redone on three bf16 limbs because an activation left the fp16 range
         self.adt = BF16 if precision == "bf16" else torch.float32  # activation / weight storage type
         self._spec = param_spec(self.cfg)
         self._sd = None
@@ -730,9 +732,17 @@ class TSR(KernelEngine):
         out = torch.cat(codes, 0) if len(codes) > 1 else codes[0]
         if self.precision == "fp16l2" and not bool(torch.isfinite(out).all()):
             # an fp16 limb overflowed (an activation of 65504 or more in magnitude) or the input was not finite: never hand on a
-            # silently wrong scene code -- "bf16l3" has the fp32 exponent range
-            raise _lib.SculptError('TSR(precision="fp16l2"): the scene code is not finite (an activation left the fp16 range); '
-                                   'use precision="bf16l3"')
+            # silently wrong scene code -- the same images go through a three-limb twin of this model ("bf16l3": the fp32 exponent
+            # range), built on first need; range_fallbacks counts the calls that needed it
+            self.range_fallbacks += 1
+            twin = getattr(self, "_range_twin", None)
+            if twin is None:
+                twin = self._range_twin = TSR(self.cfg, self.pos_embed_mode, precision="bf16l3", decoder_precision=self.decoder_precision,
+                                              decoder_filter=self.decoder_filter)
+                twin.load_state_dict(self._sd)
+                twin.to(self.device)
+            twin.max_batch = self.max_batch
+            return twin.forward(image)
         return out
 
     __call__ = forward

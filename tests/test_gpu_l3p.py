@@ -350,3 +350,28 @@ def test_two_fp16_limb_attention_vs_fp64(Tq, Tk, heads, gain, monkeypatch):
         ops.attention_f32_l3_batched(Q2, K2, Vt2, got, Tq, Tk, heads, scale, 2, Tq * D, Ts * D, Ts, Tq * D, two_fp16_limbs=True)
         assert torch.equal(got[:Tq], o2)
         assert float((got[Tq:].flip(0).double() - ref).norm() / ref.norm()) < 2e-6
+
+
+def test_fp16l2_range_fallback():
+    """An activation beyond the fp16 range (here: a LayerNorm gain of 3e5 in one block) makes the two-limb result non-finite;
+    forward() answers with the three-limb twin's scene code -- bit for bit what TSR(precision="bf16l3") gives -- and counts it."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+    from sculptmate_amd.tsr.system import TSR
+
+    sd = dict(synth.tsr_state(5, SMALL_CFG))
+    key = "backbone.transformer_blocks.1.norm3.weight"
+    sd[key] = sd[key] * 3e5
+    img = torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=4, size=SMALL_CFG["cond_image_size"]))).to(_dev())
+    got = {}
+    for prec in ("fp16l2", "bf16l3"):
+        m = TSR(SMALL_CFG, pos_embed_mode="size", precision=prec)
+        m.load_state_dict(sd)
+        m.to(_dev())
+        with torch.no_grad():
+            got[prec] = m.forward(img).clone()
+            if prec == "fp16l2":
+                assert m.range_fallbacks == 1
+                again = m.forward(img)
+                assert m.range_fallbacks == 2 and torch.equal(again, got[prec])
+    assert torch.isfinite(got["bf16l3"]).all() and torch.equal(got["fp16l2"], got["bf16l3"])

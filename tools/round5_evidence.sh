@@ -24,5 +24,7 @@ python3 tools/time_batched.py > $OUT/batched_forward.txt 2>&1
 tools/pmc_batched.sh > $OUT/pmc_batched.txt 2>&1
 python3 tools/time_parity_modes.py > $OUT/parity_modes.txt 2>&1
 python3 tools/time_l3p.py > $OUT/l3p_gemm.txt 2>&1
+python3 tools/time_l3p_f16_forms.py > $OUT/l3p_f16_forms.txt 2>&1
+python3 tools/time_l2_attention.py > $OUT/l2_attention.txt 2>&1
 find $OUT -name "*.csv" -size +8M -delete
 ls -la $OUT
