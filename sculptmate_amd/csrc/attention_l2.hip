@@ -11,9 +11,9 @@
 // registers hold 8 contiguous keys = one B fragment of the second product) and software pipeline as attention_l3_pipe_kernel<8>:
 //   QK phase   8 groups of 3 MFMAs (k-step ks, key row tile rt); group g < 4 carries the two-limb split of one float4 of the NEXT
 //              tile's rows (K rows, then V^T rows) in its shadows -- 6 / 4 / 2 vector instructions behind the three MFMAs;
-//   softmax    exposed (it needs all scores of the tile);
-//   PV phase   4 k-steps of 2 x 3 MFMAs; the split of k-step + 1's eight probabilities (four pairs of 6 instructions) rides behind
-//              four of the six.
+//   softmax    only the row maximum, the rescale of O and the first k-step's eight probabilities are exposed;
+//   PV phase   4 k-steps of 2 x 3 MFMAs; the exponentials, row sums and the split of k-step + 1's eight probabilities (four pairs
+//              of ~12 instructions) ride behind four of the six (self-attention 164 -> 156 us against the whole softmax up front).
 // One 33-KiB LDS buffer (two limbs x two operands), two barriers per tile, 8 waves = 256 queries per workgroup.
 #include <stdlib.h>
 
@@ -226,23 +226,21 @@ __global__ __launch_bounds__(NW * 64) void attention_l2_pipe_kernel(const float 
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float ps = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-            ps += s0[r] + s1[r];
-        }
-        l_run = l_run * alpha + ps;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // only the first k-step's eight probabilities are made here; the exponentials, row sums and splits of k-step + 1 ride in
+        // the shadows of k-step's MFMAs (the whole softmax up front left the matrix pipe idle for ~30 % of a tile)
+        float psa = 0.f, psb = 0.f;
 
-        // ---- PV phase: O^T += V^T . P^T; the split of k-step + 1's probabilities in the shadows of k-step's MFMAs
+        // ---- PV phase: O^T += V^T . P^T
         ahf16x8 p[2], v0[2], v1[2];
         {
             float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = s0[j];
+            for (int j = 0; j < 8; ++j) {
+                x[j] = __builtin_amdgcn_exp2f(s0[j] - m_new);
+                if (j & 1) psb += x[j]; else psa += x[j];
+            }
             ah_split8(x, p[0], p[1]);
         }
 #pragma unroll
@@ -258,11 +256,13 @@ __global__ __launch_bounds__(NW * 64) void attention_l2_pipe_kernel(const float 
 #define AHP_PAIR(i_)                                                                                    \
     do {                                                                                                \
         if (more) {                                                                                     \
-            float ya = y[2 * (i_)], yb = y[2 * (i_) + 1];                                                \
+            float ya = y[2 * (i_)] - m_new, yb = y[2 * (i_) + 1] - m_new;                                \
             AHP_PIN2(ya, yb);                                                                            \
+            ya = __builtin_amdgcn_exp2f(ya); yb = __builtin_amdgcn_exp2f(yb);                            \
+            psa += ya; psb += yb;                                                                        \
             unsigned c1, c2;                                                                             \
             ah_split2(ya, yb, c1, c2);                                                                   \
-            asm volatile("" : "+v"(c1), "+v"(c2));                                                       \
+            asm volatile("" : "+v"(c1), "+v"(c2), "+v"(psa), "+v"(psb));                                 \
             n1[i_] = c1; n2[i_] = c2;                                                                    \
         }                                                                                               \
     } while (0)
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(NW * 64) void attention_l2_pipe_kernel(const float 
             }
 #undef AHP_PAIR
         }
+        l_run = l_run * alpha + (psa + psb);
         if (t + 1 < nt) {
             __syncthreads();   // every wave has read this tile's fragments
             write_all();
