@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/b4 -- python3 tools
 cp $(find $OUT/b4 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_b4.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/l3 -- python3 tools/time_parity_modes.py --prof bf16l3 > $OUT/l3.log 2>&1
 cp $(find $OUT/l3 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_l3.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/h2 -- python3 tools/time_parity_modes.py --prof fp16l2 > $OUT/h2.log 2>&1
+cp $(find $OUT/h2 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_fp16l2.csv
 python3 tools/time_batched.py > $OUT/batched_forward.txt 2>&1
 tools/pmc_batched.sh > $OUT/pmc_batched.txt 2>&1
 python3 tools/time_parity_modes.py > $OUT/parity_modes.txt 2>&1
