@@ -135,10 +135,10 @@ _MC_SIGN_PLANES = os.environ.get("SCULPT_MC_SIGN_PLANES", "1") != "0"
 class PendingTokens:
     """The image tokens of one image, being computed on the tokenizer stream (TSR.tokens_async)."""
 
-    __slots__ = ("ctx", "ready", "_slot")
+    __slots__ = ("ctx", "ready", "_slot", "image")
 
-    def __init__(self, ctx, ready, slot):
-        self.ctx, self.ready, self._slot = ctx, ready, slot
+    def __init__(self, ctx, ready, slot, image=None):
+        self.ctx, self.ready, self._slot, self.image = ctx, ready, slot, image
 
 
 class MarchingCubeHelper:
@@ -645,8 +645,8 @@ class TSR(KernelEngine):
                 tok.wait_event(slot["consumed"])
             ctx, _ = self.image_tokens(self._preprocess(image))
             if isinstance(ctx, ops.Limbs):   # three-limb mode, limbs once: the tokens travel as limbs
-                if not isinstance(slot["ctx"], ops.Limbs) or (slot["ctx"].rows, slot["ctx"].cols) != (ctx.rows, ctx.cols):
-                    slot["ctx"] = ops.Limbs(ctx.rows, ctx.cols, data=torch.empty_like(ctx.data))
+                if not isinstance(slot["ctx"], ops.Limbs) or (slot["ctx"].rows, slot["ctx"].cols, slot["ctx"].fmt) != (ctx.rows, ctx.cols, ctx.fmt):
+                    slot["ctx"] = ops.Limbs(ctx.rows, ctx.cols, data=torch.empty_like(ctx.data), fmt=ctx.fmt)
                 slot["ctx"].data.copy_(ctx.data)
             else:
                 if not isinstance(slot["ctx"], torch.Tensor) or slot["ctx"].shape != ctx.shape or slot["ctx"].dtype != ctx.dtype:
@@ -655,7 +655,7 @@ class TSR(KernelEngine):
             ready = torch.cuda.Event()
             ready.record(tok)
         self._tok_last = ready
-        return PendingTokens(slot["ctx"], ready, slot)
+        return PendingTokens(slot["ctx"], ready, slot, image)
 
     def forward_tokens(self, tokens: PendingTokens) -> torch.Tensor:
         """The rest of forward() for one image whose tokens come from tokens_async: backbone + upsampler on the current stream
@@ -667,7 +667,10 @@ class TSR(KernelEngine):
         consumed.record(main)
         tokens._slot["consumed"] = consumed
         _, outb = self._backbone_tail(st)
-        return self.scene_code(outb)[None]
+        out = self.scene_code(outb)[None]
+        if self.precision == "fp16l2" and tokens.image is not None and not bool(torch.isfinite(out).all()):
+            return self.forward([tokens.image], self.device)   # forward()'s range fallback: the three-limb twin
+        return out
 
     def scene_code(self, tokens_bf16: torch.Tensor, batch: int = 1):
         """detokenize + TriplaneUpsampleNetwork: tokens [batch*3*S*S, C] -> planes fp32 [3, Co, 2S, 2S] ([batch, 3, ...] for batch > 1)."""

@@ -1,5 +1,6 @@
 """The "limbs once" GEMM of the tolerance mode (csrc/gemm_l3p.hip) against the kernel that splits while staging (gemm_l3.hip):
 same products in the same order, so every comparison here is BIT for bit."""
+import numpy as np
 import pytest
 import torch
 
@@ -375,3 +376,33 @@ def test_fp16l2_range_fallback():
                 again = m.forward(img)
                 assert m.range_fallbacks == 2 and torch.equal(again, got[prec])
     assert torch.isfinite(got["bf16l3"]).all() and torch.equal(got["fp16l2"], got["bf16l3"])
+
+
+def test_fp16l2_through_the_pipelined_entry(monkeypatch):
+    """TSR.run on a list of host images (tokens of image i + 1 on a second stream; the tokens travel as limbs) in the fp16l2 mode:
+    the same meshes as forward + extract_meshes one image at a time, and the range fallback works there as well."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+    from sculptmate_amd.tsr.system import TSR
+
+    sd = dict(synth.tsr_state(7, SMALL_CFG))
+    imgs = [synth.composite_rgb(synth.image_rgba(seed=s, size=SMALL_CFG["cond_image_size"])) for s in (11, 12, 13)]
+    m = TSR(SMALL_CFG, pos_embed_mode="size", precision="fp16l2")
+    m.load_state_dict(sd)
+    m.to(_dev())
+    with torch.no_grad():
+        thr = float(torch.median(__import__("sculptmate_amd").ops.density_grid(m([imgs[0]], device=_dev())[0].contiguous(), m.decoder, 32)))
+        one = [m.extract_meshes(m([im], device=_dev()), False, 32, thr)[0] for im in imgs]
+        many = m.run(imgs, mc_resolution=32, threshold=thr)
+    for a, b in zip(one, many):
+        assert np.array_equal(np.asarray(a.vertices.cpu()), np.asarray(b.vertices)) and np.array_equal(np.asarray(a.faces.cpu()), np.asarray(b.faces))
+    assert m.range_fallbacks == 0
+    key = "backbone.transformer_blocks.1.norm3.weight"
+    sd[key] = sd[key] * 3e5
+    m2 = TSR(SMALL_CFG, pos_embed_mode="size", precision="fp16l2"); m2.load_state_dict(sd); m2.to(_dev())
+    m3 = TSR(SMALL_CFG, pos_embed_mode="size", precision="bf16l3"); m3.load_state_dict(sd); m3.to(_dev())
+    with torch.no_grad():
+        tok = m2.tokens_async(imgs[0])
+        got = m2.forward_tokens(tok)
+        want = m3([imgs[0]], device=_dev())
+    assert m2.range_fallbacks == 1 and torch.equal(got, want)
