@@ -174,8 +174,10 @@ def filter_identity_check(model, img_dev, rounds=5):
     info = model.calibrate_decoder_filter(planes)
     res = {"usable": bool(info["usable"]), "coarse_operands": info["coarse"], "margin_log_density": info["margin"],
            "probe_max_err_log_density": info.get("probe_max_err"),
-           "margin_rule": "%g x the largest |log d~ - log d| on a %d^3 probe of the scene code; a call whose re-evaluated points show "
-                          "more than %.2f x margin is redone in full" % (model.FILTER_SAFETY, model.FILTER_PROBE, model.FILTER_GUARD)}
+           "margin_rule": "%g x the largest |log d~ - log d| on a %d^3 probe of the scene code; a call is redone in full when ANY "
+                          "re-evaluated point or any point of the audit sample (~0.5 %% of the otherwise untouched lattice) shows "
+                          "more than %.2f x margin, or an unmarked point's exact sign differs from the coarse one"
+                          % (model.FILTER_SAFETY, model.FILTER_PROBE, model.FILTER_GUARD)}
     if not info["usable"]:
         return res
     R = MC_RES
@@ -209,7 +211,10 @@ def filter_identity_check(model, img_dev, rounds=5):
                 "active_cells": stt["n_cells"], "nonfinite_coarse_values": stt["n_nonfinite"],
                 "passes": "A = one fp16 product per layer at every point; B = the marked points exactly (every sign certain after it); "
                           "C = the values marching cubes reads (end points of sign-changing edges, corners of ambiguous cells)",
-                "guard_max_err_log_density": stt["max_err"], "guard_over_margin": stt["max_err"] / info["margin"],
+                "guard_max_err_log_density": stt["max_err"], "guard_over_margin": ops.filter_guard_error(stt) / info["margin"],
+                "audit": {"points": stt["n_audit"], "fraction_of_lattice": stt["n_audit"] / stt["n_points"],
+                          "max_err_log_density": stt["audit_err"], "unmarked_sign_mismatches": stt["n_mismatch"],
+                          "marked_signs_corrected_by_pass_b": stt["n_sign_fixed"]},
                 "sign_mismatches_vs_full": mism, "mesh_identical": bool(same),
                 "mesh": {"vertices": int(mcb[0].shape[0]), "faces": int(mcb[1].shape[0])},
                 "checked_on": "256^3 volume of bench image 0, before the timed region"})

@@ -49,8 +49,10 @@ extern "C" {
  *    sculpt_density_filter_stats); added without a version change (new symbols only): sculpt_limbs_bytes, sculpt_limbs_split,
  *    sculpt_gemm_l3p, sculpt_layernorm_limbs, sculpt_attention_f32_l3_limbs, sculpt_mc_count_launch, sculpt_mc_count_read,
  *    sculpt_mc_emit_capped, sculpt_attention_f32_l3_batched, sculpt_mc_count_launch_signed,
- *    sculpt_density_filter_sign_offset */
-#define SCULPT_ABI_VERSION 3
+ *    sculpt_density_filter_sign_offset
+ * 4: the two-pass grid's guard: 12 statistics words instead of 8 (sculpt_density_filter_stats fills SCULPT_FILTER_STATS_WORDS),
+ *    word 1 covers every re-evaluated point, the audit sample and the sign mismatches are new */
+#define SCULPT_ABI_VERSION 4
 
 typedef void *sculpt_stream_t;
 
@@ -160,12 +162,20 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
  * out then holds the exact value wherever marching cubes reads one and a value of the right sign elsewhere, i.e. marching cubes
  * gives the mesh of the full evaluation bit for bit, PROVIDED no coarse error |log d~ - log d| reaches `margin`.  The caller
  * calibrates the margin: SCULPT_FILTER_MARK_ALL marks every point (margin and level unused), so that stats[1] is the largest
- * coarse error over the lattice; at run time stats[1] is the largest coarse error over the re-evaluated points within 2 margins
- * of the level (the guard).  flags must contain SCULPT_DENSITY_BF16L3; n_hidden_64 >= 1; R <= 1024.
- * filter_workspace: sculpt_density_filter_workspace_bytes(R, x_end - x_begin) bytes; its first 8 words are the statistics
+ * coarse error over the lattice.  At run time the call reports what it saw of the coarse error (the guard; the caller decides):
+ * stats[1] the largest over ALL re-evaluated points, +inf when an UNMARKED point came out on the other side of the level than
+ * the coarse pass had it (stats[10] counts those: each proves an error >= margin) or an exact value is a NaN; stats[8] the
+ * largest over an audit sample of ~0.5 % of the points nothing else re-evaluates (unmarked, value not read by marching cubes;
+ * pseudo-random, fixed per (R, x_begin, x_end)), appended to pass C.  A wrong sign that no mismatch reveals needs a whole
+ * 6-connected component of the true inside or outside mis-signed at every one of its points (csrc/density_filter.hip).
+ * flags must contain SCULPT_DENSITY_BF16L3; n_hidden_64 >= 1; R <= 1024.
+ * filter_workspace: sculpt_density_filter_workspace_bytes(R, x_end - x_begin) bytes; its first SCULPT_FILTER_STATS_WORDS words are
  *   [0] points re-evaluated  [1] float bits of the largest coarse error seen (see above)  [2] points marked in pass A
  *   [3] non-finite coarse values (all marked)  [4] active cells  [5] lattice points  [6] list entries of pass B  [7] of pass C
+ *   [8] float bits of the largest coarse error over the audit sample (+inf: an audited sign was wrong)  [9] audit points
+ *   [10] unmarked points whose coarse sign was wrong  [11] marked points whose coarse sign pass B corrected
  * valid once the stream has passed this call (sculpt_density_filter_stats copies them to the host and waits). */
+#define SCULPT_FILTER_STATS_WORDS 12
 #define SCULPT_FILTER_COARSE_FP16 8u
 #define SCULPT_FILTER_MARK_ALL 16u
 /* run only the named passes (timing the passes one by one: A, then B, then C on the same filter_workspace); none = all three */
@@ -178,7 +188,7 @@ int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R,
                                  unsigned flags, sculpt_stream_t stream);
 /* byte offset of the sign planes (uint32 [nx * R][ceil(R / 32)], bit = value > 0 of the final volume) inside the filter workspace */
 size_t sculpt_density_filter_sign_offset(int R, int nx);
-int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats8 /* host */, sculpt_stream_t stream);
+int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats /* host, SCULPT_FILTER_STATS_WORDS */, sculpt_stream_t stream);
 /* Step 2 for a decoder head with a 3-channel output (SF3D's MaterialMLP heads evaluated on the marching-tetrahedra lattice,
  * sf3d/system.py:141-168 + network.py:148-210): density_act (nullable) = exp(row 0 + density_bias) + out_add as above,
  * features (nullable) f32 [(x_end-x_begin)*R*R][3] = rows 1..3 of the last layer, raw.  Exact-fp32 kernel only. */

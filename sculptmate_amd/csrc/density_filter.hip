@@ -26,8 +26,18 @@
 // re-evaluated in pass B: every sign is then the full evaluation's, pass C lists exactly the values marching cubes reads for those
 // signs, and every one of them carries the full evaluation's bits -- the mesh is bit-identical to it.  The margin is calibrated by
 // the caller (8 x the largest coarse error measured with SCULPT_FILTER_MARK_ALL on a probe lattice of the same scene code) and
-// guarded at run time: the list kernel knows both values at every re-evaluated point near the level and records the largest
-// |d~ - d| it sees (FilterHeader::max_err).
+// guarded at run time, by three observations of the list kernel (which knows both values at every point it re-evaluates):
+//   max_err       the largest |d~ - d| over ALL re-evaluated points (passes B and C), wherever the exact value lies;
+//   n_mismatch    UNMARKED points whose exact sign differs from the coarse one -- each is a proof of a coarse error >= margin, and
+//                 the sign planes pass C's lists were built from were wrong there: the call is void (max_err = inf);
+//   audit_err     the largest |d~ - d| over a pseudo-random AUDIT sample of the points nothing else looks at (unmarked, value not
+//                 read by marching cubes: ~0.5 % of the lattice, one candidate per 16 % of the z words, appended to pass C's list;
+//                 pass A keeps the candidate's d~ in the audit plane so that the comparison is exact however far from the level).
+// What a wrong sign needs to escape the second observation: let W be the points whose sign is still wrong after pass B.  A lattice
+// edge from p in W to a neighbour q outside W has different signs in the planes iff p and q have the SAME true sign; then both
+// end points are listed by pass C, p is re-evaluated and counted in n_mismatch.  So the call passes only if every edge leaving W
+// crosses the true surface, i.e. W is a union of whole 6-connected components of the true inside or outside, every point of which
+// carries a coarse error >= margin and >= its own distance from the level.  The audit sample covers that case statistically.
 #include <math.h>
 #include <stdlib.h>
 
@@ -39,23 +49,42 @@
 namespace sculpt {
 
 struct FilterHeader {        // first 64 bytes of the filter workspace; zeroed by every call
-    int32_t n_refined;       // points re-evaluated exactly (passes B + C)
-    uint32_t max_err_bits;   // bits of max |log coarse - log exact| over the refined points within 2 margins of the level
+    int32_t n_refined;       // points re-evaluated exactly (passes B + C, audit sample included)
+    uint32_t max_err_bits;   // bits of max |log coarse - log exact| over the refined points; inf: a sign mismatch or a NaN
     int32_t n_marked;        // points within the margin of the level in pass A, non-finite ones included
     int32_t n_nonfinite;     // non-finite coarse values (all marked, all re-evaluated)
     int32_t n_cells;         // active cells (corner signs differ) once every sign is certain
     int32_t n_points;        // nx * R * R
     int32_t n_first;         // list entries of pass B: the marked points
-    int32_t n_second;        // list entries of pass C: the values marching cubes reads, marked points excluded
-    int32_t pad[8];
+    int32_t n_second;        // list entries of pass C: the values marching cubes reads, marked points excluded, + the audit sample
+    uint32_t audit_err_bits; // bits of max |d~ - d| over the audit sample (log units; inf: an audited sign is wrong)
+    int32_t n_audit;         // audit points (unmarked, not read by marching cubes) in pass C's list
+    int32_t n_mismatch;      // unmarked points whose exact sign differs from the coarse one (audit points included)
+    int32_t n_sign_fixed;    // marked points whose coarse sign pass B corrected
+    uint32_t audit_seed;     // selects the audit candidates (pass A writes it)
+    int32_t pad[3];
 };
 static_assert(sizeof(FilterHeader) == 64, "header is 16 words");
 
 struct FilterView {
     FilterHeader *hd;
     uint32_t *sign, *mark, *cell;        // [nx*R rows][nw words]
-    uint32_t *list;                      // [nx*R*R] packed (ix << 20 | iy << 10 | iz)
+    float *audit;                        // [nx*R rows][nw words]: d~ + bias of the word's audit candidate (point audit_bit(word))
+    uint32_t *list;                      // [nx*R*R] packed (ix << 20 | iy << 10 | iz): pass B's entries, then pass C's, upwards
+                                         // from 0; the audit sample downwards from the end (n_points - 1 - k)
 };
+
+// Audit candidates: word i (32 points along z) of the planes offers point z = 32 w + (hash & 31), and is a candidate with
+// probability AUDIT_Q / 256.  The same function in pass A (which keeps the candidate's coarse log density) and in pass C's list.
+#ifndef SCULPT_AUDIT_Q
+#define SCULPT_AUDIT_Q 41
+#endif
+constexpr uint32_t AUDIT_Q = SCULPT_AUDIT_Q;   // 41 / 256 / 32 = 0.50 % of the lattice
+__host__ __device__ __forceinline__ uint32_t audit_hash(uint32_t word, uint32_t seed) {
+    uint32_t h = word * 0x9E3779B1u ^ seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
 
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -66,11 +95,13 @@ static size_t filter_layout(int R, int nx, void *base, FilterView *v) {
     auto take = [&](size_t bytes) { char *q = p ? p + o : nullptr; o += align256(bytes); return q; };
     char *hd = take(sizeof(FilterHeader));
     char *sign = take(words * 4), *mark = take(words * 4), *cell = take(words * 4);
+    char *audit = take(words * 4);
     char *list = take(rows * (size_t)R * 4);
     if (v) {
         v->hd = reinterpret_cast<FilterHeader *>(hd);
         v->sign = reinterpret_cast<uint32_t *>(sign); v->mark = reinterpret_cast<uint32_t *>(mark);
         v->cell = reinterpret_cast<uint32_t *>(cell);
+        v->audit = reinterpret_cast<float *>(audit);
         v->list = reinterpret_cast<uint32_t *>(list);
     }
     return o;
@@ -178,10 +209,11 @@ __global__ __launch_bounds__(1024) void density_coarse_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
     const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float level_log, float margin,
     int mark_all, float *__restrict__ out, uint32_t *__restrict__ signbits, uint32_t *__restrict__ markbits,
-    FilterHeader *__restrict__ hdr) {
+    float *__restrict__ audit, uint32_t audit_seed, FilterHeader *__restrict__ hdr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;  // >= 1
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->audit_seed = audit_seed;
     {
         // the leading 16-bit part of every hidden weight: the first half of each layer's [part][T][s4][lane][8] image
         const float *src = blob + (__is_same(V8, tf16x8) ? hd.off_x3h : hd.off_x3);
@@ -263,10 +295,12 @@ __global__ __launch_bounds__(1024) void density_coarse_kernel(
         n_marked += __popc(mb);
         n_nonfinite += __popc((uint32_t)__ballot(live && !finite));
         const long row = (long)ixl * R + iy;
+        const long word = row * nzb + zb;
         if (lane == 0) {
-            signbits[row * nzb + zb] = sb;
-            markbits[row * nzb + zb] = mb;
+            signbits[word] = sb;
+            markbits[word] = mb;
         }
+        if (lane == (int)(audit_hash((uint32_t)word, audit_seed) & 31u)) audit[word] = d;   // the word's audit candidate
         if (h == 0 && live) out[row * R + iz] = c;
     }
     if (lane == 0) {
@@ -348,18 +382,20 @@ __global__ __launch_bounds__(1024) void filter_cells_kernel(const uint32_t *__re
 //   STAGE 0 (pass B): the MARKED points -> list[0 .. n_first).
 //   STAGE 1 (pass C): the points whose value marching cubes reads -- point (x, y, z) is a corner of the cells (x-1..x, y-1..y,
 //           z-1..z): all corners of an ambiguous cell; and an end point of the six lattice edges to its neighbours: the edges
-//           whose signs differ -- minus the marked ones (exact already) -> list[n_first .. n_first + n_second).
+//           whose signs differ -- minus the marked ones (exact already) -> list[n_first .. n_first + n_second); and the word's
+//           audit candidate when it is none of those -> list[n_points - 1 - k], k < n_audit (a segment of its own: its points
+//           are scattered over the lattice, and tiles that mix them with the surface's points lose the locality of those).
 template <int STAGE>
 __global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__restrict__ cell, const uint32_t *__restrict__ sign,
                                                              const uint32_t *__restrict__ mark, int R, int nx,
                                                              uint32_t *__restrict__ list, FilterHeader *__restrict__ hdr) {
-    __shared__ int wsum[16];
-    __shared__ int base_s;
+    __shared__ int wsum[16], asum[16];
+    __shared__ int base_s, abase_s;
     const int nw = (R + 31) / 32;
     const long words = (long)nx * R * nw;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t r = 0, entry = 0;
+    uint32_t r = 0, entry = 0, aud = 0;
     if (i < words) {
         const int w = (int)(i % nw);
         const long row = i / nw;
@@ -394,23 +430,33 @@ __global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__r
             if (x + 1 < nx) e |= S ^ sign[i + (long)R * nw];
             if (x > 0) e |= S ^ sign[i - (long)R * nw];
             r = (r | e) & ~mark[i] & pvalid;
+            const uint32_t hsh = audit_hash((uint32_t)i, hdr->audit_seed);
+            if (((hsh >> 8) & 255u) < AUDIT_Q) aud = (1u << (hsh & 31u)) & ~r & ~mark[i] & pvalid;
         }
         entry = ((uint32_t)x << 20) | ((uint32_t)y << 10) | (uint32_t)(32 * w);
     }
     const int n = __popc(r);
-    int incl = n;  // inclusive scan inside the wave
+    int incl = n, aincl = aud ? 1 : 0;  // inclusive scans inside the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
+        if (STAGE == 1) {
+            const int a = __shfl_up(aincl, o, 64);
+            if (lane >= o) aincl += a;
+        }
     }
-    if (lane == 63) wsum[wv] = incl;
+    if (lane == 63) { wsum[wv] = incl; asum[wv] = aincl; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t = 0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { const int v = wsum[k]; wsum[k] = t; t += v; }
+        int t = 0, ta = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+            const int v = wsum[k]; wsum[k] = t; t += v;
+            const int a = asum[k]; asum[k] = ta; ta += a;
+        }
         // (stage 1 starts behind stage 0's entries: n_first is final, pass B's list kernel has run)
         base_s = (t ? atomicAdd(STAGE == 0 ? &hdr->n_first : &hdr->n_second, t) : 0) + (STAGE == 0 ? 0 : hdr->n_first);
+        if (STAGE == 1) abase_s = ta ? atomicAdd(&hdr->n_audit, ta) : 0;
         if (STAGE == 0 && blockIdx.x == 0) hdr->n_points = nx * R * R;
     }
     __syncthreads();
@@ -420,6 +466,8 @@ __global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__r
         r &= r - 1;
         list[o++] = entry + (uint32_t)z;
     }
+    if (STAGE == 1 && aud)   // a point is in at most one segment, so the two ends never meet
+        list[(long)nx * R * R - 1 - (abase_s + asum[wv] + aincl - 1)] = entry + (uint32_t)(__ffs(aud) - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -428,32 +476,43 @@ __global__ __launch_bounds__(1024) void filter_points_kernel(const uint32_t *__r
 template <int NT>
 __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
     const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, float density_bias, float out_add, float level_log, float guard_band,
+    const float *__restrict__ FC, int R, float density_bias, float out_add,
     const uint32_t *__restrict__ list_all, FilterHeader *__restrict__ hdr, float *__restrict__ out, int stage,
-    uint32_t *__restrict__ signbits) {
+    uint32_t *__restrict__ signbits, const float *__restrict__ audit, long n_points) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [W1 | W2: NH*4096][bacc][wlast][blast]
     const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
     const int NH = hd.NH;
     // stage 0 (pass B): the marked points, whose coarse sign may be wrong -- a sign that comes out different is corrected in the
     // sign plane (rare: one atomic per such point), so that every sign is certain when pass C's bit kernels read the planes;
-    // stage 1 (pass C): the second part of the list
-    const int n = stage ? hdr->n_second : hdr->n_first;
-    const uint32_t *list = list_all + (stage ? hdr->n_first : 0);
-    if (stage && blockIdx.x == 0 && threadIdx.x == 0) hdr->n_refined = hdr->n_first + hdr->n_second;
-    if (n <= 0) return;
+    // stage 1 (pass C): the second part of the list.
+    // stage 0 / 1: list[0 .. n_first) / list[n_first .. n_first + n_second); stage 1 then takes the audit segment (read
+    // backwards from the end of the list) as a second round of the same loop
+    const int n_main = stage ? hdr->n_second : hdr->n_first;
+    const int n_aud = stage ? hdr->n_audit : 0;
+    if (stage && blockIdx.x == 0 && threadIdx.x == 0) hdr->n_refined = hdr->n_first + hdr->n_second + hdr->n_audit;
+    if (n_main + n_aud <= 0) return;
     l3_load_lds(smem, blob, hd);
     const LdsView L = lds_view(smem, NH);
     const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = lane & 31, h = lane >> 5;
-    const long ntiles = ((long)n + 31) / 32;
     const long nw_total = (long)gridDim.x * nwave;
+    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;
+    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;
+    float worst = 0.f, worst_audit = 0.f;
+    const int main_base = stage ? hdr->n_first : 0;
     // Tile order.  The list follows the lattice (x slowest) inside a filter_points workgroup, and every re-evaluated point gathers
     // its own FC row (iy, iz) -- 256 B per point, 714 MB per launch on the bench field if none is reused.  Neighbouring x planes cut
     // the surface at nearly the same (iy, iz), so: the workgroups of one XCD (blockIdx % 8, one private L2) take one contiguous
-    // eighth of the list, and inside it the tiles are dealt ROUND-ROBIN to the XCD's waves -- at any time the XCD works on ~512
+    // eighth of a segment, and inside it the tiles are dealt ROUND-ROBIN to the XCD's waves -- at any time the XCD works on ~512
     // consecutive tiles (one or two x planes) whose FC rows fit its L2 and are still there when the next plane comes by.  (A
     // contiguous range per wave put 32 different planes into an XCD's L2 at once: FETCH_SIZE 373 MB raw per launch.)
+    // seg 0: this stage's entries; seg 1 (stage 1 only): the audit sample, dealt the same way.
+    for (int seg = 0; seg < (n_aud > 0 ? 2 : 1); ++seg) {
+    const bool is_audit = seg;
+    const int n = seg ? n_aud : n_main;
+    if (n <= 0) continue;
+    const long ntiles = ((long)n + 31) / 32;
     long t_begin, t_end, t_step;
     if (gridDim.x % 8 == 0) {
         const long nxw = (long)(gridDim.x >> 3) * nwave, xcd = blockIdx.x & 7;
@@ -466,40 +525,52 @@ __global__ __launch_bounds__(NT) void density_list_l3k_kernel(
         t_end = ntiles;
         t_step = nw_total;
     }
-    const tbf16x8 *A = reinterpret_cast<const tbf16x8 *>(smem) + lane;
-    const tbf16x8 *A3 = reinterpret_cast<const tbf16x8 *>(blob + hd.off_w3) + lane;
-    float worst = 0.f;
     for (long t = t_begin; t < t_end; t += t_step) {
         const long j = t * 32 + p;
         const bool valid = j < n;
-        const uint32_t e = list[valid ? j : n - 1];
+        const long jj = valid ? j : n - 1;
+        const uint32_t e = seg ? list_all[n_points - 1 - jj] : list_all[main_base + jj];
         const int ixl = (int)(e >> 20), iy = (int)((e >> 10) & 1023u), iz = (int)(e & 1023u);
         f32x16 x0, x1;
         l3_table_sum(FA, FB, FC, R, ixl, iy, iz, h, x0, x1);
         l3k_hidden(L, NH, A, A3, h, x0, x1);
         const float d = last_dot(L, 0, h, x0, x1);
         if (h == 0 && valid) {
-            const long idx = ((long)ixl * R + iy) * R + iz;
+            const int nzb = (R + 31) / 32;
+            const long row = (long)ixl * R + iy, idx = row * R + iz, word = row * nzb + (iz >> 5);
             const float dl = d + density_bias;
             const float coarse = out[idx], exact = exp_f(dl) + out_add;
-            if (fabsf(dl - level_log) < guard_band) {
-                // the coarse value was exp(d~ + bias) + out_add: near the level the subtraction below is exact to an ulp of the level
-                const float err = fabsf(__logf(coarse - out_add) - dl);
-                if (err < INFINITY) worst = fmaxf(worst, err);
-            }
+            // The guard.  The coarse value was exp(d~ + bias) + out_add: log(coarse - out_add) gives d~ + bias back to an ulp of
+            // the level over the density, i.e. exactly enough unless the coarse density is a thousand times below the level
+            // (no error is recorded there: only the sign is compared); an audit point has its d~ + bias in the audit plane.
+            float err = 0.f;
+            if (is_audit) err = fabsf(audit[word] - dl);
+            else if (coarse - out_add > -1e-3f * out_add) err = fabsf(__logf(coarse - out_add) - dl);
+            // a non-finite coarse value (err not finite) was marked and is replaced here: n_nonfinite counts those
+            if (err < INFINITY) { if (is_audit) worst_audit = fmaxf(worst_audit, err); else worst = fmaxf(worst, err); }
             out[idx] = exact;
             // a NaN among the exact values fails the guard: the caller redoes the grid in full and marching cubes on the whole
             // volume reports it (the classification from the sign planes looks at values near the surface only)
             if (exact != exact) worst = INFINITY;
             if ((coarse > 0.0f) != (exact > 0.0f)) {
-                const int nzb = (R + 31) / 32;
-                atomicXor(&signbits[((long)ixl * R + iy) * nzb + (iz >> 5)], 1u << (iz & 31));
+                atomicXor(&signbits[word], 1u << (iz & 31));
+                // stage 0: a marked point, the correction pass B is there for.  stage 1: an unmarked point -- the coarse error
+                // reached the margin, and pass C's lists were built from a wrong sign: the call is void.  (Rare: one atomic each.)
+                if (stage) { if (is_audit) worst_audit = INFINITY; else worst = INFINITY; }
+                atomicAdd(stage ? &hdr->n_mismatch : &hdr->n_sign_fixed, 1);
             }
         }
     }
+    }
 #pragma unroll
-    for (int o = 32; o; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o, 64));
-    if (lane == 0 && worst > 0.f) atomicMax(&hdr->max_err_bits, __float_as_uint(worst));
+    for (int o = 32; o; o >>= 1) {
+        worst = fmaxf(worst, __shfl_xor(worst, o, 64));
+        worst_audit = fmaxf(worst_audit, __shfl_xor(worst_audit, o, 64));
+    }
+    if (lane == 0) {
+        if (worst > 0.f) atomicMax(&hdr->max_err_bits, __float_as_uint(worst));
+        if (worst_audit > 0.f) atomicMax(&hdr->audit_err_bits, __float_as_uint(worst_audit));
+    }
 }
 
 }  // namespace sculpt
@@ -548,15 +619,16 @@ int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R,
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_c, st, blob, FA, FB, FC, R, nx, density_bias, out_add, level_log,
-                           margin, mark_all ? 1 : 0, out, v.sign, v.mark, v.hd);
+                           margin, mark_all ? 1 : 0, out, v.sign, v.mark, v.audit,
+                           audit_hash((uint32_t)R * 2654435761u + (uint32_t)x_begin, (uint32_t)nx), v.hd);
         SC_LAUNCH_CHECK();
     }
     auto list_pass = [&](int stage) -> int {
         auto kern = density_list_l3k_kernel<1024>;
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_x, st, blob, FA, FB, FC, R, density_bias, out_add, level_log,
-                           mark_all ? INFINITY : 2.0f * margin, v.list, v.hd, out, stage, v.sign);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_x, st, blob, FA, FB, FC, R, density_bias, out_add,
+                           v.list, v.hd, out, stage, v.sign, v.audit, (long)nx * R * R);
         SC_LAUNCH_CHECK();
         return 0;
     };
@@ -583,10 +655,10 @@ size_t sculpt_density_filter_sign_offset(int R, int nx) {
     return (size_t)(reinterpret_cast<char *>(v.sign) - base);
 }
 
-int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats8, sculpt_stream_t stream) {
+int sculpt_density_filter_stats(const void *filter_workspace, int32_t *stats12, sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
-    SC_REQUIRE(filter_workspace && stats8, "density_filter_stats: null argument");
-    SC_HIP(hipMemcpyAsync(stats8, filter_workspace, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SC_REQUIRE(filter_workspace && stats12, "density_filter_stats: null argument");
+    SC_HIP(hipMemcpyAsync(stats12, filter_workspace, SCULPT_FILTER_STATS_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     SC_HIP(hipStreamSynchronize(st));
     return 0;
 }

@@ -179,8 +179,9 @@ def density_grid_filtered(planes, mlp, resolution, margin, radius=0.87, density_
     within `margin` (natural-log units of density_act) of the level -out_add (pass B: every sign certain) and at the values
     marching cubes reads -- end points of sign-changing lattice edges, all corners of ambiguous cells (pass C).  Returns (volume,
     stats): the volume holds the bits of the full evaluation wherever marching cubes reads a value and a value of the right sign
-    elsewhere as long as no coarse error reaches the margin; stats = device int32[8] view of the call's statistics
-    (include/sculpt_hip.h), valid once the stream has passed the call -- stats_host (a pinned int32[8] tensor) receives an
+    elsewhere as long as no coarse error reaches the margin; stats = device int32[FILTER_STATS_WORDS] view of the call's
+    statistics (include/sculpt_hip.h; filter_stats() decodes them, filter_guard_error() is the figure to hold against the
+    margin), valid once the stream has passed the call -- stats_host (a pinned int32[FILTER_STATS_WORDS] tensor) receives an
     asynchronous copy.  mark_all=True re-evaluates every point and stats[1] is the largest coarse error (calibration).
     passes / tables: timing aids -- run only the named passes ("A", "B", "C" one after the other on the same workspace give what
     "ABC" gives), skip the plane tables when an earlier call with the same arguments has left them in the workspace."""
@@ -208,31 +209,66 @@ def density_grid_filtered(planes, mlp, resolution, margin, radius=0.87, density_
                                            float(out_add), float(margin), _ptr(ws), _ptr(fws), _ptr(out), flags, _stream()))
     if events is not None:
         events[1].record()
-    stats = fws[:32].view(torch.int32)
+    # whose sign planes the workspace now holds (filter_sign_planes / marching_cubes check it: a probe or a slab call in between
+    # rewrites them)
+    gen = _filter_last.get(planes.device, (0,))[0] + 1
+    _filter_last[planes.device] = (gen, R, int(x_begin), x_end, "C" in passes and not mark_all)
+    stats = fws[:4 * FILTER_STATS_WORDS].view(torch.int32)
     if stats_host is not None:
         stats_host.copy_(stats, non_blocking=True)
     return out, stats
 
 
+_filter_last = {}   # device -> (generation, R, x_begin, x_end, complete) of the last density_grid_filtered call
+
+
 def filter_sign_planes(resolution, device, x_begin=0, x_end=None):
-    """The sign planes the LAST density_grid_filtered call of these arguments left in the filter workspace: int32
-    [nx * R][ceil(R / 32)], bit iz % 32 of word iz / 32 = (final volume value > 0) -- what marching_cubes(sign_planes=) takes for
-    level 0.  A view: valid until the next filtered call on this device."""
+    """The sign planes the LAST density_grid_filtered call on this device left in the filter workspace -- which must be a call
+    of these arguments: int32 [nx * R][ceil(R / 32)], bit iz % 32 of word iz / 32 = (final volume value > 0), what
+    marching_cubes(sign_planes=) takes for level 0.  A view, stamped with the call's generation: marching_cubes refuses it once
+    another filtered call (a calibration probe, a slab) has rewritten the workspace."""
     R = int(resolution)
-    nx = (R if x_end is None else int(x_end)) - int(x_begin)
+    x_end = R if x_end is None else int(x_end)
+    nx = x_end - int(x_begin)
     fws = _ws_cache.get(("dgf", device))
-    need = lib.sculpt_density_filter_workspace_bytes(R, nx)
-    if fws is None or fws.numel() < need:
-        raise SculptError("filter_sign_planes: no filtered density grid of this size has run on %s" % device)
+    last = _filter_last.get(device)
+    if fws is None or last is None or last[1:] != (R, int(x_begin), x_end, True):
+        raise SculptError("filter_sign_planes: the last filtered density grid on %s was not a complete call of R=%d, x in [%d, %d)"
+                          % (device, R, int(x_begin), x_end))
     off, nzb = int(lib.sculpt_density_filter_sign_offset(R, nx)), (R + 31) // 32
-    return fws[off:off + nx * R * nzb * 4].view(torch.int32).view(nx * R, nzb)
+    view = fws[off:off + nx * R * nzb * 4].view(torch.int32).view(nx * R, nzb)
+    view._sculpt_filter_generation = last[0]
+    return view
+
+
+def _check_sign_planes_current(sign_planes):
+    gen = getattr(sign_planes, "_sculpt_filter_generation", None)
+    if gen is not None and _filter_last.get(sign_planes.device, (None,))[0] != gen:
+        raise SculptError("marching_cubes: these sign planes are a view of the filter workspace, and a later "
+                          "density_grid_filtered call on %s has rewritten it" % sign_planes.device)
+
+
+FILTER_STATS_WORDS = 12   # SCULPT_FILTER_STATS_WORDS
 
 
 def filter_stats(stats):
-    """int32[8] statistics of density_grid_filtered (host or device tensor; a device tensor is read back here) -> dict."""
+    """int32[FILTER_STATS_WORDS] statistics of density_grid_filtered (host or device tensor; a device tensor is read back
+    here) -> dict.  max_err: largest coarse error over every re-evaluated point (inf: an unmarked point's sign was wrong, or a
+    NaN); audit_err: the same over the audit sample of otherwise untouched points; n_mismatch: unmarked points with a wrong
+    coarse sign; n_sign_fixed: marked points whose sign pass B corrected (what the margin is for)."""
     s = stats.cpu().numpy() if isinstance(stats, torch.Tensor) else np.asarray(stats)
     return {"n_refined": int(s[0]), "max_err": float(s[1:2].view(np.float32)[0]), "n_marked": int(s[2]),
-            "n_nonfinite": int(s[3]), "n_cells": int(s[4]), "n_points": int(s[5]), "n_first": int(s[6]), "n_second": int(s[7])}
+            "n_nonfinite": int(s[3]), "n_cells": int(s[4]), "n_points": int(s[5]), "n_first": int(s[6]), "n_second": int(s[7]),
+            "audit_err": float(s[8:9].view(np.float32)[0]), "n_audit": int(s[9]), "n_mismatch": int(s[10]),
+            "n_sign_fixed": int(s[11])}
+
+
+def filter_guard_error(st):
+    """The one figure of a filter_stats dict the run-time guard holds against the margin: the largest coarse error the call saw
+    anywhere -- re-evaluated points and audit sample -- and inf when any unmarked sign was wrong."""
+    if st["n_mismatch"]:
+        return float("inf")
+    return max(st["max_err"], st["audit_err"])
 
 
 _axis_cache = {}
@@ -291,6 +327,7 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     if sign_planes is not None:
         assert slab is None and sign_planes.dim() == 2 and sign_planes.shape[0] == n0 * n1 and sign_planes.stride(1) == 1
         assert sign_planes.element_size() == 4 and sign_planes.shape[1] >= (n2 + 31) // 32
+        _check_sign_planes_current(sign_planes)
         rflags = flags | _lib.MC_SIGNED
 
     def launch_count():

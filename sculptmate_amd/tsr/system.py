@@ -234,6 +234,7 @@ class TSR(KernelEngine):
         self.precision = precision
         self.l3p = False   # set by _prepare: the three-limb mode with operands split once (engine.py)
         self.range_fallbacks = 0   # fp16l2: forward() calls redone on three bf16 limbs because an activation left the fp16 range
+        self._range_twin = None    # the "bf16l3" model those calls run on (built on first need from the current weights)
         self.adt = BF16 if precision == "bf16" else torch.float32  # activation / weight storage type
         self._spec = param_spec(self.cfg)
         self._sd = None
@@ -281,6 +282,9 @@ class TSR(KernelEngine):
             if k in sd and tuple(sd[k].shape) != tuple(shp):
                 raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), shp))
         self._sd = {k: sd[k].detach().to(torch.float32) for k in self._spec if k in sd}
+        # state derived from the previous weights: the fp16l2 range twin, the two-pass grid's calibration
+        self._range_twin = None
+        self.filter_info.update(margin=None, usable=True, last=None)
         if self.device is not None:
             self._prepare(self.device)
         return self
@@ -300,8 +304,24 @@ class TSR(KernelEngine):
         wt = _bf if self.precision == "bf16" else _f32  # GEMM weight storage
         # "limbs once" (engine.py): in the three-limb mode the Linears of the two transformers keep their weights split
         # (the attention must be the fused kernel: the three-launch composition, SCULPT_L3_ATTN_FUSED=0, has no limb output)
-        self.l3p = self.precision == "fp16l2" or (self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0"
-                                                  and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0")
+        fused_attn = os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0"
+        self.l3p = self.precision == "fp16l2" or (self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0" and fused_attn)
+        if self.l3p:
+            # sculpt_gemm_l3p's tiles: N % 128 == 0 (N % 64 per GEGLU half), K % 32 == 0 for every Linear kept as limbs.  A model
+            # with other widths runs "bf16l3" on the splitting GEMM (csrc/gemm_l3.hip: N % 4), as it did before limbs-once.
+            vv, bb = cfg["image_tokenizer"], cfg["backbone"]
+            Hh, Ii = vv["hidden_size"], vv["intermediate_size"]
+            Dd = bb["num_attention_heads"] * bb["attention_head_dim"]
+            bad = [n for n, ok in (("image_tokenizer.hidden_size", Hh % 128 == 0), ("image_tokenizer.intermediate_size", Ii % 128 == 0),
+                                   ("backbone width", Dd % 128 == 0), ("backbone.cross_attention_dim", bb["cross_attention_dim"] % 32 == 0))
+                   if not ok]
+            if self.precision == "fp16l2":
+                if bad or not fused_attn:
+                    raise ValueError("precision='fp16l2' needs Linear widths the limb GEMM tiles (multiples of 128; cross-attention "
+                                     "width a multiple of 32) and the fused limb attention (SCULPT_L3_ATTN_FUSED unset): "
+                                     + (", ".join(bad) or "SCULPT_L3_ATTN_FUSED=0"))
+            elif bad:
+                self.l3p = False
         self.limb_format = "f16x2" if self.precision == "fp16l2" else "bf16x3"
         fmt = self.limb_format
         wh = (lambda x, d, geglu=False: ops.Limbs.of(_f32(ops.geglu_row_blocks(torch.as_tensor(x)) if geglu else x, d), fmt=fmt,
@@ -669,7 +689,7 @@ class TSR(KernelEngine):
         _, outb = self._backbone_tail(st)
         out = self.scene_code(outb)[None]
         if self.precision == "fp16l2" and tokens.image is not None and not bool(torch.isfinite(out).all()):
-            return self.forward([tokens.image], self.device)   # forward()'s range fallback: the three-limb twin
+            return self._range_fallback([tokens.image])   # forward()'s range fallback: straight to the three-limb twin
         return out
 
     def scene_code(self, tokens_bf16: torch.Tensor, batch: int = 1):
@@ -737,16 +757,21 @@ class TSR(KernelEngine):
             # an fp16 limb overflowed (an activation of 65504 or more in magnitude) or the input was not finite: never hand on a
             # silently wrong scene code -- the same images go through a three-limb twin of this model ("bf16l3": the fp32 exponent
             # range), built on first need; range_fallbacks counts the calls that needed it
-            self.range_fallbacks += 1
-            twin = getattr(self, "_range_twin", None)
-            if twin is None:
-                twin = self._range_twin = TSR(self.cfg, self.pos_embed_mode, precision="bf16l3", decoder_precision=self.decoder_precision,
-                                              decoder_filter=self.decoder_filter)
-                twin.load_state_dict(self._sd)
-                twin.to(self.device)
-            twin.max_batch = self.max_batch
-            return twin.forward(image)
+            return self._range_fallback(image)
         return out
+
+    def _range_fallback(self, image):
+        """fp16l2: the images of a call whose scene code came out non-finite, through the "bf16l3" twin of this model (built from the
+        CURRENT weights on first need; load_state_dict drops it)."""
+        self.range_fallbacks += 1
+        twin = self._range_twin
+        if twin is None:
+            twin = self._range_twin = TSR(self.cfg, self.pos_embed_mode, precision="bf16l3", decoder_precision=self.decoder_precision,
+                                          decoder_filter=self.decoder_filter)
+            twin.load_state_dict(self._sd)
+            twin.to(self.device)
+        twin.max_batch = self.max_batch
+        return twin.forward(image)
 
     __call__ = forward
 
@@ -836,7 +861,7 @@ class TSR(KernelEngine):
                 return mc(ops.density_grid(planes, self.decoder, R, precision="bf16l3", events=density_events, **dkw))
         host = getattr(self, "_filter_stats_host", None)
         if host is None:
-            host = self._filter_stats_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+            host = self._filter_stats_host = torch.zeros(ops.FILTER_STATS_WORDS, dtype=torch.int32).pin_memory()
         vol, _ = ops.density_grid_filtered(planes, self.decoder, R, info["margin"], coarse=info["coarse"], events=density_events,
                                            stats_host=host, **dkw)
         err = None
@@ -852,7 +877,8 @@ class TSR(KernelEngine):
             mesh, err = None, e
         st = ops.filter_stats(host)
         info["last"] = st
-        if st["max_err"] <= self.FILTER_GUARD * info["margin"]:
+        seen = ops.filter_guard_error(st)
+        if seen <= self.FILTER_GUARD * info["margin"]:
             info["filtered"] += 1
             if err is not None:
                 raise err
@@ -863,8 +889,8 @@ class TSR(KernelEngine):
         vol = ops.density_grid(planes, self.decoder, R, precision="bf16l3", out=vol, **dkw)
         mesh = mc(vol)
         self.calibrate_decoder_filter(planes)
-        if info["usable"] and info["margin"] is not None:
-            info["margin"] = min(max(info["margin"], self.FILTER_SAFETY * st["max_err"]), self.FILTER_MAX_MARGIN)
+        if info["usable"] and info["margin"] is not None and np.isfinite(seen):
+            info["margin"] = min(max(info["margin"], self.FILTER_SAFETY * seen), self.FILTER_MAX_MARGIN)
         return mesh
 
     def extract_mesh_sharded(self, scene_code, resolution: int = 512, threshold: float = 25.0, enable_texture=False):

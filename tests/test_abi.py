@@ -35,7 +35,7 @@ def test_version_and_error_string():
 
     hdr = open(os.path.join(ROOT, "include", "sculpt_hip.h")).read()
     want = int(re.search(r"#define\s+SCULPT_ABI_VERSION\s+(\d+)", hdr).group(1))
-    assert want == 3 and _lib.lib.sculpt_version() == want   # 3: the two-pass dense density grid (round 5)
+    assert want == 4 and _lib.lib.sculpt_version() == want   # 4: the two-pass grid reports 12 statistics words (round 6)
     assert isinstance(_lib.last_error(), str)
     assert _lib.lib.sculpt_device_count() >= 0
 

@@ -68,8 +68,9 @@ def test_filtered_grid_gives_marching_cubes_the_full_evaluations_bits(cuda, R, c
     s = ops.filter_stats(st)
     need = _assert_same_for_marching_cubes(vol, full, R)
     assert s["n_points"] == R ** 3 and int(need.sum()) <= s["n_refined"] < R ** 3
-    assert s["n_marked"] == s["n_first"] <= s["n_refined"] == s["n_first"] + s["n_second"] and s["n_nonfinite"] == 0
-    assert s["max_err"] <= margin / 3.0, (s, margin)   # the run-time guard TSR applies
+    assert s["n_marked"] == s["n_first"] <= s["n_refined"] == s["n_first"] + s["n_second"] + s["n_audit"] and s["n_nonfinite"] == 0
+    assert ops.filter_guard_error(s) <= margin / 3.0, (s, margin)   # the run-time guard TSR applies
+    assert s["n_mismatch"] == 0 and 0 < s["n_audit"] < 0.0055 * R ** 3
     assert _same_mesh(ops.marching_cubes(vol.view(R, R, R), 0.0), ops.marching_cubes(full.view(R, R, R), 0.0))
 
 
@@ -85,7 +86,7 @@ def test_mark_all_reproduces_the_full_volume_bit_for_bit(cuda, R):
     coarse_only = coarse_only.clone()
     vol, st = ops.density_grid_filtered(tri, mlp, R, 0.0, coarse="fp16", mark_all=True)
     s = ops.filter_stats(st)
-    assert s["n_refined"] == R ** 3 == s["n_marked"] == s["n_first"] and s["n_second"] == 0
+    assert s["n_refined"] == R ** 3 == s["n_marked"] == s["n_first"] and s["n_second"] == 0 == s["n_audit"]
     assert torch.equal(vol.view(torch.int32), full.view(torch.int32))
     err = (torch.log(coarse_only.double()) - torch.log(full.double())).abs().max().item()
     assert abs(err - s["max_err"]) <= 1e-5 + 1e-3 * err, (err, s)
@@ -107,10 +108,14 @@ def test_refined_set_from_signs_alone_matches_a_host_restatement(cuda):
     vol, st = ops.density_grid_filtered(tri, mlp, R, 1e-30, out_add=-THR, coarse="bf16")
     s = ops.filter_stats(st)
     need, n_active = _needed(coarse, R)
-    assert s["n_marked"] == 0 == s["n_first"] and s["n_cells"] == n_active and s["n_refined"] == s["n_second"] == int(need.sum())
-    # ... and pass C rewrote exactly those points
+    assert s["n_marked"] == 0 == s["n_first"] and s["n_cells"] == n_active
+    assert s["n_second"] == int(need.sum()) and s["n_refined"] == s["n_second"] + s["n_audit"]
+    # ... and pass C rewrote exactly those points, plus its audit sample of the others
     assert torch.equal(vol.view(torch.int32)[need], full.view(torch.int32)[need])
-    assert torch.equal(vol.view(torch.int32)[~need], coarse.view(torch.int32)[~need])
+    touched = (vol.view(torch.int32) != coarse.view(torch.int32)) & ~need
+    assert int(touched.sum()) <= s["n_audit"] and torch.equal(vol.view(torch.int32)[touched], full.view(torch.int32)[touched])
+    # (an audit point whose coarse and exact bits agree is not counted by `touched`; there are few of those)
+    assert int(touched.sum()) >= 0.9 * s["n_audit"]
 
 
 def test_passes_one_by_one_equal_the_single_call(cuda):
@@ -157,7 +162,9 @@ def test_filtered_grid_at_full_size_over_thresholds(cuda):
         vol, st = ops.density_grid_filtered(tri, mlp, R, margin, out_add=-thr, out=out)
         s = ops.filter_stats(st)
         _assert_same_for_marching_cubes(vol, full, R)
-        assert s["max_err"] <= margin / 3.0 and s["max_err"] <= 3.0 * probe_err, (s, margin, probe_err)
+        assert ops.filter_guard_error(s) <= margin / 3.0 and s["max_err"] <= 3.0 * probe_err, (s, margin, probe_err)
+        # the audit sample: ~0.5 % of the lattice (one candidate in 16 % of the z words), minus the candidates that are refined anyway
+        assert 0.003 * R ** 3 < s["n_audit"] < 0.0052 * R ** 3 and s["n_mismatch"] == 0
         assert s["n_refined"] < 0.5 * R ** 3
         assert _same_mesh(ops.marching_cubes(vol.view(R, R, R), 0.0), ops.marching_cubes(full.view(R, R, R), 0.0))
 
@@ -173,7 +180,8 @@ def test_statistics_through_the_c_entry_point(cuda):
     _, st = ops.density_grid_filtered(tri, mlp, 40, margin, out_add=-THR)
     want = st.cpu().numpy()
     fws = ops._ws_cache[("dgf", tri.device)]
-    got = np.zeros(8, np.int32)
+    got = np.zeros(ops.FILTER_STATS_WORDS, np.int32)
+    assert want.shape == got.shape == (12,)
     _lib.check(_lib.lib.sculpt_density_filter_stats(ctypes.c_void_p(fws.data_ptr()), ctypes.c_void_p(got.ctypes.data),
                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert np.array_equal(got, want) and got[5] == 40 ** 3 and 0 < got[0] < 40 ** 3
@@ -194,6 +202,177 @@ def test_bad_arguments_are_refused(cuda):
     _, mlp0, _, _ = _field(cuda, 21, inside=0.1, n_hidden_layers=1)     # no 64x64 hidden layer: nothing to do coarsely
     with pytest.raises(_lib.SculptError):
         ops.density_grid_filtered(tri, mlp0, 32, 0.1, out_add=-THR)
+
+
+
+# ------------------------------------------------------------------------------------------------- the run-time guard
+def _planted(cuda, seed, A_of, inside=0.15, deep=0.03, R=48):
+    """A decoder whose density is d = u . a (a: the activations entering the last hidden layer, u > 0) plus a pair of identical
+    neurons that fire only where d is in its top `deep` quantile (deep inside the object) and enter the density with weights
+    +A, -A: they cancel in every evaluation.  In the PLANTED model the IEEE-half copy of the second neuron's weight row -- what
+    pass A multiplies by -- is zero, so the coarse pass alone is off by A silu(g (d - T)) there, and nowhere else.
+    -> (planes, clean PackedMLP, planted PackedMLP, thr, facts)"""
+    from sculptmate_amd import ops
+
+    rng = np.random.default_rng([seed, 77])
+    Ws, bs = synth.decoder_lists(synth.decoder_state(seed=seed))
+    Ws, bs = [w.copy() for w in Ws], [b.copy() for b in bs]
+    tri_np = synth.smooth_triplane(seed=seed + 1, scale=3.0)
+    tri = torch.from_numpy(tri_np).to(cuda)
+    u = (np.abs(rng.standard_normal(64)) * 0.3).astype(np.float32)
+    W, b, WL, bL = Ws[-2], bs[-2], Ws[-1], bs[-1]
+    W[0], W[1], W[2], W[3] = u, -u, 0.0, 0.0
+    b[0:4] = 0.0
+    WL[0] = 0.0
+    WL[0, 0], WL[0, 1] = 1.0, -1.0     # silu(x) - silu(-x) = x: the density row reads u . a
+    bL[0] = 0.0
+    probe = ops.density_grid(tri, ops.PackedMLP(Ws, bs, cuda), R, density_bias=0.0, precision="bf16l3")
+    s = torch.log(probe).double().cpu().numpy()
+    level, T, hi = np.quantile(s, 1.0 - inside), np.quantile(s, 1.0 - deep), np.quantile(s, 1.0 - deep / 6)
+    assert T > 0 and hi > T > level
+    g = np.float32(max(25.0 / T, 6.0 / (hi - T), 20.0 / (T - level)))
+    A = np.float32(A_of(level, T, hi))
+    W[2] = W[3] = g * u
+    b[2] = b[3] = -g * np.float32(T)
+    WL[0, 2], WL[0, 3] = A, -A
+    clean = ops.PackedMLP(Ws, bs, cuda)
+    W_bad = [w.copy() for w in Ws]
+    W_bad[-2][3] = 0.0
+    bad = ops.PackedMLP(W_bad, bs, cuda)
+    # the planted model: the clean blob with the leading IEEE-half part of the last hidden layer taken from `bad`
+    hd = clean.blob[:16].view(torch.int32).cpu().numpy()
+    NH, off_x3h = int(hd[2]), int(hd[12])
+    assert NH == len(Ws) - 2 and bad.blob[:16].view(torch.int32).cpu().numpy()[12] == off_x3h
+    lo = off_x3h + (NH - 1) * 4096
+    planted = ops.PackedMLP(Ws, bs, cuda)
+    assert torch.equal(planted.blob, clean.blob)
+    planted.blob[lo:lo + 2048] = bad.blob[lo:lo + 2048]
+    assert not torch.equal(planted.blob, clean.blob)
+    thr = float(np.exp(level))      # density_bias = 0 in these tests
+    return tri, clean, planted, thr, dict(level=level, T=T, hi=hi, g=float(g), A=float(A), s=s)
+
+
+def _far_and_near_errors(tri, planted, R, thr, margin):
+    """Largest coarse error |log d~ - log d| of the planted model near the level (what the round-5 guard looked at) and far."""
+    from sculptmate_amd import ops
+
+    full = ops.density_grid(tri, planted, R, density_bias=0.0, precision="bf16l3").clone()
+    coarse, _ = ops.density_grid_filtered(tri, planted, R, 0.0, density_bias=0.0, coarse="fp16", mark_all=True, passes="A")
+    err = (torch.log(coarse.double()) - torch.log(full.double())).abs()
+    dist = (torch.log(full.double()) - np.log(thr)).abs()
+    return float(err[dist < 2 * margin].max()), float(err[dist >= 2 * margin].max()), full
+
+
+def test_guard_audit_sees_a_coarse_error_planted_far_from_the_level(cuda):
+    """A coarse error of ~1 in log density in the deepest 3 % of the object, none within reach of the level, no sign changed: the
+    points marching cubes reads are all fine (what the guard of round 5 measured), the audit sample is what reports it."""
+    from sculptmate_amd import ops
+
+    R = 96
+    tri, clean, planted, thr, f = _planted(cuda, 41, lambda level, T, hi: 0.2)
+    _, st = ops.density_grid_filtered(tri, clean, 32, 0.0, density_bias=0.0, out_add=0.0, coarse="fp16", mark_all=True)
+    margin = max(8.0 * ops.filter_stats(st)["max_err"], 1e-3)
+    near, far, full = _far_and_near_errors(tri, planted, R, thr, margin)
+    assert near <= margin / 3 and far > 10 * margin, (near, far, margin)
+    # the clean model passes ...
+    vol, st = ops.density_grid_filtered(tri, clean, R, margin, density_bias=0.0, out_add=-thr)
+    s = ops.filter_stats(st)
+    assert ops.filter_guard_error(s) <= margin / 3 and s["n_mismatch"] == 0
+    # ... the planted one is caught by the audit sample alone: no sign is wrong, the re-evaluated points show nothing
+    vol, st = ops.density_grid_filtered(tri, planted, R, margin, density_bias=0.0, out_add=-thr)
+    s = ops.filter_stats(st)
+    assert int(((vol > 0) != (full - np.float32(thr) > 0)).sum()) == 0 and s["n_mismatch"] == 0
+    assert 3 * margin < s["audit_err"] <= far * 1.001 + 1e-5, (s, margin, far)
+    assert ops.filter_guard_error(s) > margin / 3
+    # (the field is steep at this resolution: some end points of sign-changing edges lie deep inside, so the re-evaluated points
+    # report the planted error too -- max_err now covers every one of them, not only those within two margins of the level)
+
+
+def test_guard_counts_unmarked_sign_errors_planted_deep_inside(cuda):
+    """The same neuron with a negative weight: the coarse pass puts the deepest part of the object OUTSIDE.  The rim of that hole
+    is a set of sign-changing lattice edges of the planes, pass C re-evaluates their end points and finds unmarked points on the
+    wrong side: n_mismatch > 0, the call is void whatever the audit saw."""
+    from sculptmate_amd import ops
+
+    R = 96
+    tri, clean, planted, thr, f = _planted(cuda, 43, lambda level, T, hi: -(hi - level) / 3.0)
+    _, st = ops.density_grid_filtered(tri, clean, 32, 0.0, density_bias=0.0, out_add=0.0, coarse="fp16", mark_all=True)
+    margin = max(8.0 * ops.filter_stats(st)["max_err"], 1e-3)
+    near, far, full = _far_and_near_errors(tri, planted, R, thr, margin)
+    assert near <= margin / 3 and far > 10 * margin, (near, far, margin)
+    coarse, _ = ops.density_grid_filtered(tri, planted, R, margin, density_bias=0.0, out_add=-thr, passes="A")
+    wrong = int(((coarse > 0) != (full - np.float32(thr) > 0)).sum())
+    assert wrong > 100          # the hole exists in the coarse volume
+    vol, st = ops.density_grid_filtered(tri, planted, R, margin, density_bias=0.0, out_add=-thr)
+    s = ops.filter_stats(st)
+    assert s["n_mismatch"] > 0 and s["max_err"] == float("inf") and ops.filter_guard_error(s) == float("inf")
+    assert s["audit_err"] > 3 * margin      # (the audit sample sees the hole too)
+    vol, st = ops.density_grid_filtered(tri, clean, R, margin, density_bias=0.0, out_add=-thr)
+    assert ops.filter_stats(st)["n_mismatch"] == 0
+
+
+def test_guard_trips_on_a_margin_below_the_coarse_error(cuda):
+    """A deliberately small margin (a quarter of the largest coarse error of the probe): marked points come out further from the
+    level than the margin, or unmarked ones on the other side of it -- either way the call reports it."""
+    from sculptmate_amd import ops
+
+    R = 64
+    tri, mlp, _, _ = _field(cuda, 21, inside=0.1)
+    margin, probe_err = _margin(tri, mlp, "fp16")
+    small = probe_err / 4.0
+    full = ops.density_grid(tri, mlp, R, out_add=-THR, precision="bf16l3").clone()
+    vol, st = ops.density_grid_filtered(tri, mlp, R, small, out_add=-THR)
+    s = ops.filter_stats(st)
+    assert ops.filter_guard_error(s) > small / 3.0, (s, small)
+    # every marked point's error is recorded wherever its exact value lies: at least the errors up to the margin are seen
+    assert s["max_err"] > small / 3.0
+    # the right margin on the same field: passes, and then the volume is the full evaluation's for marching cubes
+    vol, st = ops.density_grid_filtered(tri, mlp, R, margin, out_add=-THR)
+    assert ops.filter_guard_error(ops.filter_stats(st)) <= margin / 3.0
+    _assert_same_for_marching_cubes(vol, full, R)
+
+
+def test_sign_planes_view_is_refused_once_the_workspace_is_rewritten(cuda):
+    from sculptmate_amd import _lib, ops
+
+    R = 40
+    tri, mlp, _, _ = _field(cuda, 21, inside=0.1)
+    margin, _ = _margin(tri, mlp, "fp16")
+    vol, _ = ops.density_grid_filtered(tri, mlp, R, margin, out_add=-THR)
+    signs = ops.filter_sign_planes(R, tri.device)
+    ref = ops.marching_cubes(vol.view(R, R, R), 0.0)
+    assert _same_mesh(ops.marching_cubes(vol.view(R, R, R), 0.0, sign_planes=signs), ref)
+    ops.density_grid_filtered(tri, mlp, 32, 0.0, out_add=0.0, mark_all=True)      # a calibration probe in between
+    with pytest.raises(_lib.SculptError):
+        ops.marching_cubes(vol.view(R, R, R), 0.0, sign_planes=signs)
+    with pytest.raises(_lib.SculptError):
+        ops.filter_sign_planes(R, tri.device)                                      # the last call was not an R = 40 grid
+
+
+def test_tsr_guard_catches_the_planted_error_and_returns_the_full_evaluations_mesh(cuda):
+    """Through TSR.extract_meshes: calibrated on the clean decoder, then the planted one (either kind) -- one fallback, the mesh
+    of the unfiltered model, bit for bit."""
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+
+    sd = synth.tsr_state(3, SMALL_CFG)
+    for seed, A_of in ((41, lambda level, T, hi: 0.2), (43, lambda level, T, hi: -(hi - level) / 3.0)):
+        tri, clean, planted, thr, f = _planted(cuda, seed, A_of)
+        a = _small_tsr(cuda, sd, decoder_filter=False)
+        b = _small_tsr(cuda, sd)
+        a.renderer.cfg.density_bias = b.renderer.cfg.density_bias = 0.0
+        a.decoder, b.decoder = clean, clean
+        b.calibrate_decoder_filter(tri)
+        assert b.filter_info["usable"] and b.filter_info["coarse"] == "fp16"
+        ma = a.extract_meshes(tri[None], resolution=96, threshold=thr)[0]
+        mb = b.extract_meshes(tri[None], resolution=96, threshold=thr)[0]
+        assert b.filter_info["filtered"] == 1 and b.filter_info["fallbacks"] == 0
+        assert torch.equal(ma.faces, mb.faces) and torch.equal(ma.vertices.view(torch.int32), mb.vertices.view(torch.int32))
+        b.decoder = planted
+        mb = b.extract_meshes(tri[None], resolution=96, threshold=thr)[0]
+        assert b.filter_info["fallbacks"] == 1 and b.filter_info["filtered"] == 1, b.filter_info
+        assert torch.equal(ma.faces, mb.faces) and torch.equal(ma.vertices.view(torch.int32), mb.vertices.view(torch.int32))
+        # the re-calibration on this scene sees the planted error on its probe: the margin now covers it, or the filter is off
+        assert (not b.filter_info["usable"]) or b.filter_info["margin"] >= 8 * 0.5 * abs(f["A"])
 
 
 # ------------------------------------------------------------------------------------------------- through TSR.extract_meshes
