@@ -51,7 +51,9 @@ extern "C" {
  *    sculpt_mc_emit_capped, sculpt_attention_f32_l3_batched, sculpt_mc_count_launch_signed,
  *    sculpt_density_filter_sign_offset
  * 4: the two-pass grid's guard: 12 statistics words instead of 8 (sculpt_density_filter_stats fills SCULPT_FILTER_STATS_WORDS),
- *    word 1 covers every re-evaluated point, the audit sample and the sign mismatches are new */
+ *    word 1 covers every re-evaluated point, the audit sample and the sign mismatches are new; the marching-cubes workspace
+ *    is a record pool with a capacity (SCULPT_ERR_MC_WORKSPACE, sculpt_mc_workspace_bytes_for, sculpt_mc_count_launch_for,
+ *    sculpt_mc_count_read_ex) */
 #define SCULPT_ABI_VERSION 4
 
 typedef void *sculpt_stream_t;
@@ -222,8 +224,16 @@ int sculpt_grid_decode(const void *mlp_packed, int n_hidden_64, int R, int x_beg
 #define SCULPT_ERR_MC_LEVEL 11
 #define SCULPT_ERR_MC_EMPTY 12
 #define SCULPT_ERR_MC_NAN 13 /* the volume contains NaN (e.g. a 16-bit split density mode left its range) */
+#define SCULPT_ERR_MC_WORKSPACE 14 /* more active cells than the workspace's record pool holds: repeat with a larger one (below) */
 
+/* Workspace: per-row arrays + 8 bytes per ACTIVE cell (a cell whose corner signs differ) in a record pool.
+ * sculpt_mc_workspace_bytes sizes the pool for one active cell per 8 cells (a closed surface at 256^3 has ~1 per 17): 21 MB at
+ * 256^3, 166 MB at 512^3; sculpt_mc_workspace_bytes_for for max_active_cells of them (<= 0: the default).  A count phase that runs
+ * out of pool still returns the right totals, with SCULPT_ERR_MC_WORKSPACE and -- through sculpt_mc_count_read_ex -- the number
+ * of active cells; the caller allocates sculpt_mc_workspace_bytes_for(.., that many) and repeats the count with
+ * sculpt_mc_count_launch_for(.., max_active_cells = that many, ..).  (The emit phase after an overflow writes nothing.) */
 size_t sculpt_mc_workspace_bytes(int n0, int n1, int n2);
+size_t sculpt_mc_workspace_bytes_for(int n0, int n1, int n2, int64_t max_active_cells);
 int sculpt_mc_count(const float *vol, int n0, int n1, int n2, double level, unsigned flags,
                     void *workspace, int64_t *n_verts_host, int64_t *n_faces_host,
                     float *minmax_host /* [2] data min,max or NULL */, sculpt_stream_t stream);
@@ -251,6 +261,14 @@ int sculpt_mc_count_launch_signed(const float *vol, const uint32_t *sign_planes,
                                   double level, unsigned flags, void *workspace, sculpt_stream_t stream);
 int sculpt_mc_count_read(int n0, int n1, int n2, double level, unsigned flags, const void *workspace, int64_t *n_verts_host,
                          int64_t *n_faces_host, float *minmax_host /* [2] or NULL */, sculpt_stream_t stream);
+/* The count phase into a workspace of sculpt_mc_workspace_bytes_for(n0, n1, n2, max_active_cells) bytes: sign_planes NULL (then
+ * words_per_row is ignored) = sculpt_mc_count_launch, non-NULL with SCULPT_MC_SIGNED in flags = sculpt_mc_count_launch_signed.
+ * sculpt_mc_count_read_ex: sculpt_mc_count_read + the number of active cells (what a SCULPT_ERR_MC_WORKSPACE caller asks for). */
+int sculpt_mc_count_launch_for(const float *vol, const uint32_t *sign_planes /* or NULL */, int words_per_row, int n0, int n1, int n2,
+                               double level, unsigned flags, int64_t max_active_cells, void *workspace, sculpt_stream_t stream);
+int sculpt_mc_count_read_ex(int n0, int n1, int n2, double level, unsigned flags, const void *workspace, int64_t *n_verts_host,
+                            int64_t *n_faces_host, float *minmax_host /* [2] or NULL */, int64_t *n_active_host /* or NULL */,
+                            sculpt_stream_t stream);
 int sculpt_mc_emit_capped(const float *vol, int n0, int n1, int n2, double level, unsigned flags, void *workspace, float vert_div,
                           float vert_mul, float vert_add, int axis0_offset, float *verts, int64_t cap_verts, void *faces,
                           int64_t cap_faces, int *top_plane_map /* or NULL */, sculpt_stream_t stream);

@@ -86,6 +86,9 @@ SIGNATURES = {
     "sculpt_density_grid_filtered": (_i, [_vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _u, _vp]),
     "sculpt_density_filter_stats": (_i, [_vp, _vp, _vp]),
     "sculpt_mc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sculpt_mc_workspace_bytes_for": (_sz, [_i, _i, _i, _i64]),
+    "sculpt_mc_count_launch_for": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.c_double, _u, _i64, _vp, _vp]),
+    "sculpt_mc_count_read_ex": (_i, [_i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _pi64, _vp]),
     "sculpt_mc_count": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _pi64, _pi64, _vp, _vp]),
     "sculpt_mc_emit": (_i, [_vp, _i, _i, _i, ctypes.c_double, _u, _vp, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "sculpt_mc_count_launch_signed": (_i, [_vp, _vp, _i, _i, _i, _i, ctypes.c_double, _u, _vp, _vp]),
@@ -183,6 +186,7 @@ LIMBS_BF16X3, LIMBS_F16X2 = 0, 1
 ERR_MC_LEVEL = 11
 ERR_MC_EMPTY = 12
 ERR_MC_NAN = 13
+ERR_MC_WORKSPACE = 14
 EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_RELU = 0, 1, 2, 3
 QUERY_ALIGN_CORNERS = 1
 QUERY_CHANNEL_LAST = 2

@@ -302,7 +302,10 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
     vol = _req(vol, torch.float32, "vol")
     assert vol.dim() == 3
     n0, n1, n2 = vol.shape
-    ws = _workspace(("mc", vol.device), lib.sculpt_mc_workspace_bytes(n0, n1, n2), vol.device)
+    # The workspace holds 8 bytes per ACTIVE cell in a record pool (default: one active cell per 8 cells).  A shape whose count
+    # phase ran out of pool once (SCULPT_ERR_MC_WORKSPACE: a noisy volume) keeps the larger capacity.
+    rec_cap = _MC_REC_CAPACITY.get((vol.device, n0, n1, n2), 0)
+    ws = _workspace(("mc", vol.device), lib.sculpt_mc_workspace_bytes_for(n0, n1, n2, rec_cap), vol.device)
     flags = 0
     if reference_order:
         flags |= _lib.MC_REFERENCE_ORDER | _lib.MC_FACES_I64
@@ -332,10 +335,10 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
 
     def launch_count():
         if sign_planes is not None:
-            check(lib.sculpt_mc_count_launch_signed(_ptr(vol), _ptr(sign_planes), sign_planes.stride(0), n0, n1, n2, float(level), flags,
-                                                    _ptr(ws), _stream()))
+            check(lib.sculpt_mc_count_launch_for(_ptr(vol), _ptr(sign_planes), sign_planes.stride(0), n0, n1, n2, float(level), rflags,
+                                                 rec_cap, _ptr(ws), _stream()))
         else:
-            check(lib.sculpt_mc_count_launch(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), _stream()))
+            check(lib.sculpt_mc_count_launch_for(_ptr(vol), None, 0, n0, n1, n2, float(level), flags, rec_cap, _ptr(ws), _stream()))
 
     launch_count()
     if cap is not None:
@@ -343,8 +346,20 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
         faces = torch.empty((cap[1], 3), dtype=fdt, device=vol.device)
         check(lib.sculpt_mc_emit_capped(_ptr(vol), n0, n1, n2, float(level), flags, _ptr(ws), float(vert_div), float(vert_mul),
                                         float(vert_add), off, _ptr(verts), cap[0], _ptr(faces), cap[1], None, _stream()))
-    rc = lib.sculpt_mc_count_read(n0, n1, n2, float(level), rflags, _ptr(ws), ctypes.byref(nv), ctypes.byref(nf),
-                                  ctypes.cast(mm, ctypes.c_void_p), _stream())
+    nact = ctypes.c_int64()
+    rc = lib.sculpt_mc_count_read_ex(n0, n1, n2, float(level), rflags, _ptr(ws), ctypes.byref(nv), ctypes.byref(nf),
+                                     ctypes.cast(mm, ctypes.c_void_p), ctypes.byref(nact), _stream())
+    while rc == _lib.ERR_MC_WORKSPACE:
+        # more active cells than the pool holds (the speculative emit above wrote nothing): a larger workspace, the count again.
+        # (The pool is handed out in up to 64 parts: half as much again covers their uneven loads; a pool that holds every cell
+        # of the grid cannot overflow, so the loop ends.)
+        rec_cap = max(2 * rec_cap, int(nact.value + nact.value // 2 + 4096))
+        _MC_REC_CAPACITY[(vol.device, n0, n1, n2)] = rec_cap
+        ws = _workspace(("mc", vol.device), lib.sculpt_mc_workspace_bytes_for(n0, n1, n2, rec_cap), vol.device)
+        cap = None
+        launch_count()
+        rc = lib.sculpt_mc_count_read_ex(n0, n1, n2, float(level), rflags, _ptr(ws), ctypes.byref(nv), ctypes.byref(nf),
+                                         ctypes.cast(mm, ctypes.c_void_p), ctypes.byref(nact), _stream())
     if sign_planes is not None and rc == _lib.ERR_MC_EMPTY:
         # no surface: whether that is skimage's ValueError (level outside the data range) or its RuntimeError needs the range
         return marching_cubes(vol, level, reference_order, vert_div, vert_mul, vert_add, use_classic, slab)
@@ -373,6 +388,7 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
 
 
 _MC_CAPACITY = {}     # (device, n0, n1, n2, flags) -> (vertex capacity, face capacity) of the speculative emit
+_MC_REC_CAPACITY = {} # (device, n0, n1, n2) -> active-cell records of the workspace once the default pool was too small
 _MC_SPECULATE = os.environ.get("SCULPT_MC_SPECULATE", "1") != "0"
 
 
