@@ -495,3 +495,39 @@ def test_tsr_filter_leaves_other_decoder_modes_alone(cuda):
     thr = float(np.quantile(ops.density_grid(planes[0], m.decoder, 32).cpu().numpy(), 0.9))
     m.extract_meshes(planes, resolution=32, threshold=thr)
     assert m.filter_info["filtered"] == 0 and m.filter_info["calibrations"] == 0
+
+
+# ------------------------------------------------------------------------------------------------- trained-like weight statistics
+@pytest.mark.parametrize("factor,expect", [(30.0, "fp16"), (100.0, "off")])
+def test_trained_like_outliers_through_both_16_bit_shortcuts(cuda, factor, expect):
+    """synth.tsr_state(outliers=factor): massive-activation channels in both residual streams, heavy-tailed decoder rows (what a
+    trained checkpoint has and the initialiser does not; tools/stress_trained_like.py runs the full-size model).  The two-limb
+    fp16 transformer stays fp32-equivalent (its operands are scaled per tensor: no range fallback up to x 10^4); the two-pass
+    grid keeps IEEE-half operands at x 30 and switches itself off at x 100 (margin beyond FILTER_MAX_MARGIN) -- the mesh is the
+    unfiltered model's bit for bit either way."""
+    from sculptmate_amd import ops
+    from sculptmate_amd.tsr import TSR
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+
+    sd = synth.tsr_state(7, SMALL_CFG, outliers=factor)
+    img = torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=400, size=SMALL_CFG["cond_image_size"]))).to(cuda)
+    models = {}
+    for prec in ("fp16l2", "bf16l3"):
+        models[prec] = TSR(SMALL_CFG, pos_embed_mode="scale_factor", precision=prec)
+        models[prec].load_state_dict(sd)
+        models[prec].to(cuda)
+    a, b = models["fp16l2"].forward(img), models["bf16l3"].forward(img)
+    assert bool(torch.isfinite(a).all()) and float((a - b).norm() / b.norm()) < 1e-5
+    assert models["fp16l2"].range_fallbacks == 0
+    nof = _small_tsr(cuda, sd, precision="bf16l3", decoder_filter=False, pos_embed_mode="scale_factor")
+    dens = ops.density_grid(b[0].contiguous(), nof.decoder, 48, precision="bf16l3").double().cpu().numpy()
+    thr = float(np.quantile(dens, 0.97))
+    ma = models["bf16l3"].extract_meshes(b, resolution=80, threshold=thr)[0]
+    mb = nof.extract_meshes(b, resolution=80, threshold=thr)[0]
+    assert torch.equal(ma.faces, mb.faces) and torch.equal(ma.vertices.view(torch.int32), mb.vertices.view(torch.int32))
+    info = models["bf16l3"].filter_info
+    if expect == "off":
+        assert not info["usable"] and info["filtered"] == 0 and info["fallbacks"] == 0
+    else:
+        assert info["usable"] and info["coarse"] == expect and info["filtered"] == 1 and info["fallbacks"] == 0
+        assert ops.filter_guard_error(info["last"]) <= info["margin"] / 3

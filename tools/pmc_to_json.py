@@ -10,6 +10,11 @@ dst = sys.argv[2]
 import collections
 
 NAME = {}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sculptmate_amd import build as _build  # noqa: E402
+
+# what the counters were measured ON: bench.py uses the figures only while the library it loads carries the same digest
+SOURCE_DIGEST = _build.built_digest()
 
 
 def per_launch(sub, counter):
@@ -53,7 +58,7 @@ if any("density_coarse_kernel" in k for k in ff):
     write_kb = sum(v for v, _ in fw.values())
     res = {
         "kernel": "density_coarse_kernel + filter_cells + filter_points + density_list_l3k_kernel (one 256^3 call of sculpt_density_grid_filtered)",
-        "mode": "bf16l3+filter",
+        "mode": "bf16l3+filter", "source_digest": SOURCE_DIGEST,
         "FETCH_SIZE_KB_raw": {k: v for k, (v, _) in ff.items()}, "WRITE_SIZE_KB_raw": {k: v for k, (v, _) in fw.items()},
         "full_size_launches": {k: n for k, (_, n) in ff.items()},
         "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",
@@ -62,7 +67,7 @@ if any("density_coarse_kernel" in k for k in ff):
         "note": "per call: pass A streams the plane tables (FC once per XCD) and writes the coarse volume + two bitmaps; the list kernels gather "
                 "three table rows per re-evaluated point and rewrite those points; per kernel: sum over its launches (calibration probe excluded) / calls",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
-                  "--no-optional-modes --no-extras --no-siblings`, tools/profile_bench.sh, round 5",
+                  "--no-optional-modes --no-extras --no-siblings`, tools/profile_bench.sh",
     }
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res))
@@ -74,7 +79,7 @@ R = 256
 alg = R ** 3 * 4 + 3 * R * R * 64 * 4 + 3 * 40 * 64 * 64 * 4 // 1  # density out + FA/FB/FC tables read once (+ planes upstream)
 res = {
     "kernel": NAME["kernel"].split("(")[0] + " (256^3 launch)",
-    "mode": "bf16l3" if "l3" in NAME["kernel"] else "fp32",
+    "mode": "bf16l3" if "l3" in NAME["kernel"] else "fp32", "source_digest": SOURCE_DIGEST,
     "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb, "full_size_launches": [nf, nw],
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact",
     "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
