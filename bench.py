@@ -36,8 +36,7 @@ FLOP_PER_POINT = 82.4e3          # 81 408 MLP + ~960 sampling (A
 #   bf16l3: 8 hidden layers x 48 v_mfma_f32_32x32x16_bf16 (32 768 FLOP each) per 32 points = six 64x64 products per layer
 #   fp32  : 8 hidden layers x 64 v_mfma_f32_32x32x2_f32 (4 096 FLOP each) per 32 points   = one 64x64 product per layer
 # (layer 0 is hoisted into the separable plane tables, the last layer is a VALU dot: neither is on the matrix pipe)
-EXECUTED_FLOP_PER_POINT = {"bf16l3": 8 * 48 * 32768 / 32, "fp32": 8 * 64 * 4096 / 32, "bf16x3": 8 * 24 * 32768 / 32,
-                           "fp16x3": 8 * 24 * 32768 / 32}
+EXECUTED_FLOP_PER_POINT = {"bf16l3": 8 * 48 * 32768 / 32, "fp32": 8 * 64 * 4096 / 32}
 # the two-pass ("filtered") grid, TSR's default since round 5 (csrc/density_filter.hip): pass A = one 16-bit product per hidden layer at
 # EVERY point (8 MFMAs per layer and 32 points), pass C = the six-product arithmetic at the re-evaluated points only
 COARSE_FLOP_PER_POINT = 8 * 8 * 32768 / 32
@@ -49,14 +48,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (dense)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak
 KERNEL_NAME = {"bf16l3": "density_grid_l3k_kernel (fused triplane-sum + NeRF-MLP; hidden layers as six exact bf16-limb products on "
                          "v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
-               "fp32": "density_grid_kernel (fused triplane-sum + NeRF-MLP, exact fp32 on v_mfma_f32_32x32x2_f32)",
-               "bf16x3": "density_grid_x3_kernel<bf16> (two-limb experiment, 16-bit operands)",
-               "fp16x3": "density_grid_x3_kernel<f16> (two-limb experiment, 22-bit operands)"}
+               "fp32": "density_grid_kernel (fused triplane-sum + NeRF-MLP, exact fp32 on v_mfma_f32_32x32x2_f32)"}
 DTYPE = {"bf16l3": "fp32-equivalent (bf16 3-limb split, 24 bits, fp32 accumulate) density MLP / f32 tables, SiLU, marching cubes / "
                    "bf16 transformer",
-         "fp32": "f32 (density MLP + marching cubes) / bf16 (transformer)",
-         "bf16x3": "bf16x3 split operands (16 bits), fp32 accumulate (density MLP hidden layers) / f32 (tables, SiLU, marching cubes) / bf16 (transformer)",
-         "fp16x3": "fp16x3 split operands (22 bits), fp32 accumulate (density MLP hidden layers) / f32 (tables, SiLU, marching cubes) / bf16 (transformer)"}
+         "fp32": "f32 (density MLP + marching cubes) / bf16 (transformer)"}
 MC_RES = 256
 THRESHOLD = 25.0
 
@@ -350,15 +345,16 @@ def parity_mode_extra(sd, model, imgs, imgs_np, cpu_verts, steps, precision="fp1
     dt = time.perf_counter() - t0
     dtype = ("f32 storage; matrix products: bf16 3-limb split of both operands (24 bits), fp32 accumulate; f32 norms / softmax"
              if precision == "bf16l3" else
-             "f32 storage; Linears: fp16 2-limb operands (22 bits), 3 products; attention products: bf16 3-limb (24 bits), 6 products; "
-             "fp32 accumulate; f32 norms / softmax")
+             "f32 storage; Linears AND attention products: fp16 2-limb operands (22 bits), 3 products (the image tokenizer's small "
+             "attention launches: bf16 3-limb, 6 products); fp32 accumulate; f32 norms / softmax")
     out = {"mode": 'TSR(precision="%s")' % precision, "forward_ms": float(np.median([a.elapsed_time(b) for a, b in ev])),
            "ms_per_step": dt / n * 1e3, "meshes_per_s": n / dt, "dtype": dtype,
-           # 2.96 TFLOP algorithmic per image (2.10 in the Linears, 0.86 in the attention products); x 6 (3) limb products executed
+           # 2.96 TFLOP algorithmic per image (2.10 in the Linears, 0.86 in the attention products, 0.03 of them the image
+           # tokenizer's); bf16l3 executes 6 limb products per product, fp16l2 3 (6 in the tokenizer's attention)
            "transformer_tflops_algorithmic": None, "steps_timed": n}
     out["transformer_tflops_algorithmic"] = 2.96 / (out["forward_ms"] * 1e-3)
-    out["mfma_executed_tflops"] = (6 * 2.96 if precision == "bf16l3" else 3 * 2.10 + 6 * 0.86) / (out["forward_ms"] * 1e-3)
-    # operands split once (weights at load time, activations by their producers; csrc/gemm_l3p.hip) -- SCULPT_L3P=0: in every GEMM
+    out["mfma_executed_tflops"] = (6 * 2.96 if precision == "bf16l3" else 3 * (2.10 + 0.83) + 6 * 0.03) / (out["forward_ms"] * 1e-3)
+    # operands split once (weights at load time, activations by their producers; csrc/gemm_l3p.hip) -- SCULPT_L3_TILE=split: in every GEMM
     out["limbs_once"] = bool(getattr(m, "l3p", False))
     try:   # the same mode with four images per transformer pass (TSR.forward on a list; every attention one launch over batch x heads)
         keep = m.max_batch
@@ -431,27 +427,6 @@ def kernel_parity(model, img_dev):
             "lattice_points_on_different_sides_of_threshold": int(flips.numel()),
             "flipped_points": [[int(i), float(a[i]), float(b[i])] for i in flips[:8]],
             "density_max_rel_dev": rel}
-
-
-def optional_mode_rates(model, imgs, steps):
-    """Whole-step rate with the two-limb experiment modes (narrower than fp32, never `value`)."""
-    res = {}
-    keep = model.decoder_precision
-    try:
-        for mode in ("fp16x3", "bf16x3"):
-            model.decoder_precision = mode
-            one_step(model, imgs[0])
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                one_step(model, imgs[i % len(imgs)])
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            res[mode] = {"meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3,
-                         "density_max_rel_dev_vs_fp32_kernel": density_deviation(model, imgs[0], mode)}
-    finally:
-        model.decoder_precision = keep
-    return res
 
 
 def mesh_distance(v, rv, extent):
@@ -723,12 +698,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optional-modes", action="store_true",
-                    help="skip the informational split-operand rates (profiling runs: keeps the kernel rows to the default path)")
+                    help="accepted for old command lines: the two-limb decoder modes it used to skip were removed in round 6")
     ap.add_argument("--no-siblings", action="store_true",
                     help="skip the exact-fp32 kernel's sibling measurement and the kernel-parity pass (profiling runs)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys measured after the timed region (boundary, slab512, sf3d)")
-    ap.add_argument("--decoder-precision", choices=("bf16l3", "fp32", "fp16x3", "bf16x3"), default="bf16l3",
+    ap.add_argument("--decoder-precision", choices=("bf16l3", "fp32"), default="bf16l3",
                     help="bf16l3 (default = TSR's default: fp32-equivalent three-limb bf16 split), fp32 (exact-fp32 MFMA kernel), "
                          "or a two-limb experiment mode")
     ap.add_argument("--check-rounds", type=int, default=5,
@@ -902,8 +877,6 @@ def main():
                     out["batched"] = batched_rates(model, imgs, args.steps)
                 except Exception as e:  # an extra must never take the headline line down
                     out["batched"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            if single and not args.no_optional_modes:
-                out["optional_modes"] = optional_mode_rates(model, imgs, args.steps)  # informational, not `value`
             if single and not args.no_extras:
                 for key, fn in (("slab512", lambda: slab512_extra(model, imgs[0])), ("sf3d", lambda: sf3d_extra(device))):
                     t0 = time.perf_counter()

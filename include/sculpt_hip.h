@@ -136,14 +136,8 @@ int sculpt_plane_features_ex(const float *planes, int C, int H, int W, const voi
 int sculpt_density_grid(const void *mlp_packed, int n_hidden_64, int R, int x_begin, int x_end,
                         float density_bias, float out_add, const void *workspace, float *out,
                         sculpt_stream_t stream);
-/* Same with flags.  SCULPT_DENSITY_BF16X3 (optional fast mode, NOT the default): the 64x64 hidden layers run on bf16
- * MFMA with both operands split into bf16 pairs (W.x ~= Wh.xh + Wh.xl + Wl.xh, fp32 accumulate: ~2^-17 relative
- * product error, fp32 range); tables, SiLU, last layer and exp stay fp32. */
-#define SCULPT_DENSITY_BF16X3 1u
-/* SCULPT_DENSITY_FP16X3: the same with IEEE-half parts (11-bit significands: operands represented to ~2^-22,
- * hidden activations and weights must stay inside the fp16 range, |v| < 65504). */
-#define SCULPT_DENSITY_FP16X3 2u
-/* SCULPT_DENSITY_BF16L3: fp32-equivalent mode on the 16-bit matrix pipe (what TSR.extract_meshes uses by default): both
+/* Same with flags (values 1 and 2 were the two-limb experiments SCULPT_DENSITY_BF16X3 / _FP16X3 of rounds 2-5: removed, refused).
+ * SCULPT_DENSITY_BF16L3: fp32-equivalent mode on the 16-bit matrix pipe (what TSR.extract_meshes uses by default): both
  * operands split EXACTLY into three bf16 limbs (8 + 8 + 8 = 24 significant bits, fp32 exponent range),
  * W.x = W1.x3 + W3.x1 + W2.x2 + W1.x2 + W2.x1 + W1.x1 with every product exact and fp32 accumulation; the three dropped
  * products are below 2^-23 |W||x|.  No range limit, no fallback.  Replaces NeRFMLP's hidden Linear layers,

@@ -190,8 +190,6 @@ ERR_MC_WORKSPACE = 14
 EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_RELU = 0, 1, 2, 3
 QUERY_ALIGN_CORNERS = 1
 QUERY_CHANNEL_LAST = 2
-DENSITY_BF16X3 = 1
-DENSITY_FP16X3 = 2
 DENSITY_BF16L3 = 4
 FILTER_COARSE_FP16 = 8
 FILTER_MARK_ALL = 16
@@ -206,3 +204,9 @@ def last_error():
 def check(rc):
     if rc != 0:
         raise SculptError(last_error() or ("sculpt error %d" % rc), rc)
+
+
+def form_has(var, token):
+    """Non-default kernel forms for tests and A/B: one environment variable per kernel family (SCULPT_GEMM_TILE, SCULPT_L3_TILE,
+    SCULPT_ATTN_FORM, SCULPT_DENSITY_FORM, SCULPT_MC_FORM), a comma-separated list of tokens (csrc/common.h: form_has)."""
+    return any(t == token or t.startswith(token + "=") for t in os.environ.get(var, "").split(",") if t)

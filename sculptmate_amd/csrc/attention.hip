@@ -347,7 +347,7 @@ static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int l
     // count, a launch lasts ceil(workgroups / CUs) rounds (the 16-wave form fits one per CU; smaller ones are counted the same
     // way: a second resident workgroup shares the CU's matrix pipe).  3072 queries x 16 heads: 192 workgroups of 256 (3/4 of
     // the CUs for 8 units of time), 384 of 128 (two rounds of 4), 256 of 192 -- every CU once, 6 units.
-    static const int force = [] { const char *e = getenv("SCULPT_ATTN_NQB"); return e ? atoi(e) : 0; }();
+    const int force = form_int("SCULPT_ATTN_FORM", "nqb", 0);   // A/B: nqb=4 / 6 / 8
     // (measured: self-attention 51.1 -> 48.8 us, cross 25.2 -> 23.5 us with 192; a smaller workgroup re-stages the head's K / V
     // more often, so it has to win by more than 15 %: SF3D's 27 648 queries, 54 against 56 units, ran 4 % slower with 192)
     const long bh = (long)heads * batch;
@@ -371,8 +371,8 @@ static int attention_launch(const uint16_t *Q, int ldq, const uint16_t *K, int l
     const AttnBatch ab{heads, vt_cols, q_bs, k_bs, vt_bs, o_bs};
 #define SCULPT_ATTN_LAUNCH(NQB, PRE, SC) \
     hipLaunchKernelGGL((attention_kernel<NQB, PRE>), grid, block, 0, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, SC, ab)
-    const char *epipe = getenv("SCULPT_ATTN_PIPE");  // 0: the phase-separated loop for pre-scaled queries too (A/B); read per call
-    const bool pipe = prescaled && nqb != 8 && !(epipe && atoi(epipe) == 0);
+    // SCULPT_ATTN_FORM=nopipe: the phase-separated loop for pre-scaled queries too (tests pin the pipelined kernel against it)
+    const bool pipe = prescaled && nqb != 8 && !form_has("SCULPT_ATTN_FORM", "nopipe");
     if (pipe) {
         attention_pipe_launch(nqb, grid, block, st, Q, ldq, K, ldk, Vt, ldvt, O, ldo, Tq, Tk, ab);
     } else if (prescaled) {  // Q carries scale * log2(e) already

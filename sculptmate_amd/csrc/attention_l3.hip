@@ -562,10 +562,11 @@ static int attention_l3_go(const float *Q, int ldq, const float *K, int ldk, con
     unsigned char *olt = reinterpret_cast<unsigned char *>(O_lt);
     // the pipelined 8-wave form (256 queries per workgroup) where it keeps at least 2/3 of the CUs busy -- the backbone's 3072
     // queries x 16 heads = 192 workgroups --; otherwise (the image tokenizer: 1025 queries x 12 heads) the plain 4-wave form
-    const char *e = getenv("SCULPT_L3_ATTN_PIPE");   // 0 / 1: never / always the pipelined form (A/B); read per call
+    // SCULPT_ATTN_FORM tokens l3pipe / nol3pipe: always / never the pipelined form (A/B, tests; read per call)
+    const int fpipe = form_has("SCULPT_ATTN_FORM", "l3pipe") ? 1 : (form_has("SCULPT_ATTN_FORM", "nol3pipe") ? 0 : -1);
     // (the two-limb arithmetic exists in the pipelined form only, and that form wins there even on the image tokenizer's 60
     // workgroups: 53 against 59 us on three limbs and 4 waves)
-    const bool pipe = e ? atoi(e) != 0 : (two_fp16_limbs || (long)cdiv(Tq, 256) * heads * batch * 3 >= 2L * num_cus());
+    const bool pipe = fpipe >= 0 ? fpipe != 0 : (two_fp16_limbs || (long)cdiv(Tq, 256) * heads * batch * 3 >= 2L * num_cus());
     // two fp16 limbs per operand (attention_l2.hip: half the matrix work) where the pipelined form runs; the small launches (the
     // image tokenizer's) stay on the three-limb 4-wave kernel
     if (pipe && two_fp16_limbs)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <string>
 
 #include "../../include/sculpt_hip.h"
@@ -37,6 +39,30 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // number of CUs of the current device (cached)
 int num_cus();
+
+// Non-default kernel forms, for the tests that pin each adopted form against another and for A/B timing: ONE environment variable
+// per kernel family (SCULPT_GEMM_TILE, SCULPT_L3_TILE, SCULPT_ATTN_FORM, SCULPT_DENSITY_FORM, SCULPT_MC_FORM), a comma-separated
+// list of tokens read per call.  form_has(var, "nopipe"): the token is there; form_int(var, "gm", -1): the value of "gm=4".
+static inline bool form_token(const char *list, const char *token, const char **value) {
+    if (!list) return false;
+    const size_t n = strlen(token);
+    for (const char *p = list; *p;) {
+        const char *q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len >= n && strncmp(p, token, n) == 0 && (len == n || p[n] == '=')) {
+            if (value) *value = len == n ? nullptr : p + n + 1;
+            return true;
+        }
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+static inline bool form_has(const char *var, const char *token) { return form_token(getenv(var), token, nullptr); }
+static inline int form_int(const char *var, const char *key, int dflt) {
+    const char *v = nullptr;
+    return (form_token(getenv(var), key, &v) && v) ? atoi(v) : dflt;
+}
 
 // XCD-aware tile order (guide T1, bijective form): workgroups are handed to the 8 XCDs round-robin by linear id, and
 // every XCD has a private L2; this returns a tile index such that the workgroups sharing an XCD (same id % 8) get a

@@ -617,9 +617,11 @@ int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R,
         SC_HIP(hipMemsetAsync(v.hd, 0, sizeof(FilterHeader), st));
         auto kern = (flags & SCULPT_FILTER_COARSE_FP16) ? density_coarse_kernel<tf16x8> : density_coarse_kernel<tbf16x8>;
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        // EXPERIMENT (tools/try_coresident.py): "threads,lds_kb" -- a narrower workgroup with its LDS padded so that only one fits a CU
         int threads = 1024;
         size_t lds_launch = lds_c;
+#ifdef SCULPT_EXPERIMENTS
+        // tools/try_coresident.py (builds with SCULPT_EXTRA_HIPCC_FLAGS=-DSCULPT_EXPERIMENTS only): SCULPT_COARSE_WG="threads,lds_kb"
+        // -- a narrower workgroup with its LDS padded so that only one fits a CU
         if (const char *e = getenv("SCULPT_COARSE_WG")) {
             int t = 0, kb = 0;
             if (sscanf(e, "%d,%d", &t, &kb) == 2 && (t == 256 || t == 512 || t == 1024)) {
@@ -628,6 +630,7 @@ int sculpt_density_grid_filtered(const void *mlp_packed, int n_hidden_64, int R,
                 SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
             }
         }
+#endif
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds_launch, st, blob, FA, FB, FC, R, nx, density_bias, out_add, level_log,
                            margin, mark_all ? 1 : 0, out, v.sign, v.mark, v.audit,

@@ -1122,10 +1122,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     GemmArgs g{A, lda, W, ldw, bias, residual, ldr, out_f32, out_bf16, ldo, out_bf16_t, ldt, M, N, K, n_split,
                w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
     SC_REQUIRE(w_rows <= ZERO_FLOATS, "gemm_bf16: N=%d too large", N);
-    {
-        const char *ens = getenv("SCULPT_GEMM_DBG_NOSTORE");   // timing experiments only (read per call)
-        g.m_store = (ens && atoi(ens) != 0) ? 0 : M;
-    }
+    g.m_store = M;
     g.zeros = reinterpret_cast<const float *>(zero_page());
     SC_REQUIRE(g.zeros, "gemm_bf16: could not allocate the zero page");
     SC_REQUIRE((!bias || ((uintptr_t)bias & 15) == 0) && (!ln || !ln->colsum || ((uintptr_t)ln->colsum & 15) == 0),
@@ -1148,11 +1145,11 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     hipStream_t st = as_stream(stream);
     // Grouped tile order (GemmArgs::gm): group height ~ sqrt(R * weight rows per tile / activation rows per tile) with R the
     // workgroups an XCD keeps resident (32 CUs x 1 or 2), as a power of two; launches whose tiles are all resident at once (or
-    // whose grid is shorter than two groups) keep the band order.  SCULPT_GEMM_GM=0 restores the band order everywhere (A/B),
-    // =n forces a group height; read per call.
+    // whose grid is shorter than two groups) keep the band order.  SCULPT_GEMM_TILE=gm=0 restores the band order everywhere (A/B),
+    // gm=n forces a group height.
+    constexpr const char *FORM = "SCULPT_GEMM_TILE";   // tokens: 256 / no256, 192 / no192, res / nores, bm192 / nobm192, ks0, nostage, gm=n
     auto group_rows = [&](int w_rows_tile, int a_rows_tile, int wg_per_cu, long tiles, int gy) -> int {
-        const char *e = getenv("SCULPT_GEMM_GM");
-        const int forced = e ? atoi(e) : -1;
+        const int forced = form_int(FORM, "gm", -1);
         if (forced >= 0) return forced;
         const long R = 32L * wg_per_cu;
         if (tiles <= 8 * R) return 0;
@@ -1167,23 +1164,21 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     // TripoSR's own launches -- FF1 is 384 such tiles = 1.5 rounds, the fused QKV 144 -- stay on the 128-row tiles
     // (tools/time_gemm256.py: 72.8 vs 60.7 us, 38.1 vs 34.9 us; outputs bit-identical).  No residual / statistics / n_store.
     {
-        const char *e256 = getenv("SCULPT_GEMM_256");  // 0: never, 1 (default): by the rules below, 2: whenever legal (tests, A/B)
-        const int p256 = e256 ? atoi(e256) : 1;
+        // no256: never, default: by the rules below, 256: whenever legal (tests, A/B)
+        const int p256 = form_has(FORM, "no256") ? 0 : (form_has(FORM, "256") ? 2 : 1);
         const int nout = epilogue == SCULPT_EPI_GEGLU ? 128 : 256;
         const long tiles = (long)(N / nout) * cdiv(M, 256), tiles192 = (long)(N / nout) * cdiv(M, 192);
         const bool pays = tiles >= 2L * num_cus() && (epilogue == SCULPT_EPI_GEGLU || N >= 4096) && (M % 256 == 0 || M % 256 >= 128);
         // 192 x 256 tiles (round 4, tools/gemm_order_ab.py, interleaved in one process): wherever 3072-row multiples give them at
         // least 3/4 of the CUs a tile -- B = 1: FF1 512 tiles 58.8 vs 61.4 us on the 128-row tiles, fused Q|K|V^T 192 tiles 31.3 vs
         // 35.0; a 4-image batch: Q|K|V^T 93.8 vs 101.0, cross-attention q 33.2 vs 36.6 -- except where the 256-row tile has four
-        // rounds of its own (FF1 of a 4-image batch: 211.9 vs 225.7 us).  SCULPT_GEMM_192=0 / 1 forces never / always.
-        const char *e192 = getenv("SCULPT_GEMM_192");
-        const int f192 = e192 ? atoi(e192) : -1;
+        // rounds of its own (FF1 of a 4-image batch: 211.9 vs 225.7 us).  no192 / 192 force never / always.
+        const int f192 = form_has(FORM, "no192") ? 0 : (form_has(FORM, "192") ? 1 : -1);
         const bool pays192 = M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus());
         // the residual form on 192 x 256 tiles (round 4): every CU gets a tile where the 128-row tiles need three -- the N = 1024
         // projections of a batched pass (to_out of both attentions, FF2): M = 12288 -> 4 x 64 = 256 tiles
         {
-            const char *eres = getenv("SCULPT_GEMM_RES256");   // 0 / 1: never / whenever legal (A/B, tests); read per call
-            const int fres = eres ? atoi(eres) : -1;
+            const int fres = form_has(FORM, "nores") ? 0 : (form_has(FORM, "res") ? 1 : -1);   // never / whenever legal (A/B, tests)
             const bool legal = p256 && residual && out_f32 && epilogue == SCULPT_EPI_NONE && n_store == N && n_split == N && !out_bf16_t &&
                                N % 256 == 0 && K >= 2 * BK && (long)N * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L;
             const long t192 = (long)(N / 256) * cdiv(M, 192);
@@ -1206,10 +1201,10 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             g.gm = group_rows(256, bm192 ? 192 : 256, 1, (long)grid.x * grid.y, grid.y);
             {
                 // staged stores: bf16 outputs only, every tile entirely token-major or entirely transposed, 16-byte aligned rows
-                const char *est = getenv("SCULPT_GEMM_STAGE");   // 0: direct stores from the accumulator layout (A/B); read per call
                 const bool split = out_bf16_t && n_split < N;
                 // (out_bf16 must exist: the token-major tiles of a split launch are written through it unconditionally)
-                g.stage = !(est && atoi(est) == 0) && !out_f32 && out_bf16 && (!out_bf16_t || split) &&
+                // nostage: direct stores from the accumulator layout (A/B)
+                g.stage = !form_has(FORM, "nostage") && !out_f32 && out_bf16 && (!out_bf16_t || split) &&
                           (!split || (n_split % nout == 0 && M % 8 == 0 && ldt % 8 == 0 && ((uintptr_t)out_bf16_t & 15) == 0)) &&
                           ldo % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0;
             }
@@ -1230,9 +1225,8 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     // the two transformers except the deep-K 64-row-tile case (K = 4096, N = 1024: -4 %), which keeps 4 waves
     // ... unless the launch has fewer workgroups than CUs (the ViT's 1025 x 768 x 3072): then 8 waves are the only
     // latency hiding a CU gets
-    static const int force = [] { const char *e = getenv("SCULPT_GEMM_NW8S"); return e ? atoi(e) : -1; }();
     const bool underfilled = (long)(N / 64) * mt < (long)num_cus();
-    const bool nw8 = true, nw8s = force >= 0 ? force != 0 : (K < 2048 || underfilled);
+    const bool nw8 = true, nw8s = K < 2048 || underfilled;
     if (epilogue == SCULPT_EPI_GEGLU) {
         SC_REQUIRE(N % 64 == 0, "gemm_bf16(GEGLU): N=%d must be a multiple of 64", N);
         SC_REQUIRE(!residual && !out_bf16_t, "gemm_bf16(GEGLU): residual/transposed output unsupported");
@@ -1260,38 +1254,25 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             // Fewer tiles than CUs: every workgroup has a CU to itself and its K loop runs at that CU's L2 -> LDS fill rate
             // (~57 GB/s, whatever the ring depth or the number of barriers: a six-stage ring and two K-tiles per barrier both
             // measured +-0); 64 x 64 tiles put the same bytes through up to twice as many CUs.
-            static const int bm64_env = [] { const char *e = getenv("SCULPT_GEMM_BM64"); return e ? atoi(e) : 1; }();
             // One round of 192 x 64 tiles (round 5): M = 3072, N = 1024 is exactly 16 x 16 = 256 tiles, one per CU, where the 128 x 64
             // tiles are 384 (1.5 per CU) and move 14 % more bytes through L2 -> LDS -- these launches run at the chip's L2 -> LDS
             // rate (~17 TB/s; hipBLASLt's 128 x 96 stream-K kernel on the same shape moves 486 MB at the same rate), so the bytes
-            // are the time.  SCULPT_GEMM_BM192=0 / 1: never / whenever legal (A/B); read per call.
-            const char *e192r = getenv("SCULPT_GEMM_BM192");
-            const int f192r = e192r ? atoi(e192r) : -1;
+            // are the time.  nobm192 / bm192: never / whenever legal (A/B).  (A 96 x 128 tile -- the same 256 tiles with 12.5 %
+            // fewer bytes again -- was built in round 5, measured bit-identical and NOT faster (FF2 43.6 against 42.6 us, to_out
+            // 18.3 / 18.1): below ~540 MB per launch the bytes stop being the time.  Removed in round 6, DESIGN_HISTORY.md.)
+            const int f192r = form_has(FORM, "nobm192") ? 0 : (form_has(FORM, "bm192") ? 1 : -1);
             const long t192r = (long)(N / 64) * (M / 192);
             const bool one_round = M % 192 == 0 && t192r <= (long)num_cus() && t192r * 4 >= 3L * num_cus();
-            // ... and 96 x 128 (activation x weight rows; 4 x 2 waves of 32 x 48, three-stage ring): the same 256 tiles with 12.5 %
-            // fewer bytes again ((96 + 128) against (192 + 64) rows of K per tile) -- bit-identical and NOT faster (FF2 43.6 against
-            // 42.6 us, to_out 18.3 / 18.1, tools/gemm_bm192_ab.py): below ~540 MB per launch the bytes stop being the time.  Kept
-            // behind SCULPT_GEMM_BM96=1 for A/B only.
-            const char *e96 = getenv("SCULPT_GEMM_BM96");
-            if (e96 && atoi(e96) == 2 && M % 96 == 0 && N % 128 == 0) {
-                // 4 waves of 64 weight x 48 activation rows (hipBLASLt's wave tile on this shape: 7 fragment reads per 12 MFMAs)
+            if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
                 g.gm = 0;
-                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 4, false, 96, 2>), dim3(N / 128, M / 96), dim3(256), 0, st, g);
-            } else if (e96 && atoi(e96) != 0 && M % 96 == 0 && N % 128 == 0) {
-                g.gm = 0;
-                hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 128, 8, false, 96, 4>), dim3(N / 128, M / 96), dim3(512), 0, st, g);
-            } else if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
-                g.gm = 0;
-                // k-split pairs (see the kernel): FF2 + residual 41.6 -> 38.4 us, plain K = 4096 37.5 -> 33.9, K = 1024 -0.3 us
-                // (tools/gemm_bm192_ab.py); SCULPT_GEMM_KS=0: the weight-row split, bit-identical to the 128 x 64 tiles (A/B, tests)
-                const char *eks = getenv("SCULPT_GEMM_KS");
-                if (!(eks && atoi(eks) == 0))
+                // k-split pairs (see the kernel): FF2 + residual 41.6 -> 38.4 us, plain K = 4096 37.5 -> 33.9, K = 1024 -0.3 us;
+                // ks0: the weight-row split, bit-identical to the 128 x 64 tiles (A/B, tests)
+                if (!form_has(FORM, "ks0"))
                     hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192, 2, true>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
                 else
                     hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
             } else
-            if (small && underfilled && bm64_env && (long)(N / 64) * cdiv(M, 64) <= 2L * num_cus())
+            if (small && underfilled && (long)(N / 64) * cdiv(M, 64) <= 2L * num_cus())
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 64>), dim3(N / 64, cdiv(M, 64)), dim3(512), 0, st, g);
             else if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
             else if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 4>), dim3(N / 64, mt), dim3(256), 0, st, g);

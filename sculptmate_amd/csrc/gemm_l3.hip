@@ -245,14 +245,14 @@ __global__ __launch_bounds__(256, 2) void gemm_l3_kernel(GemmF32Args g_in) {
 }
 
 int gemm_l3_launch(const GemmF32Args &g, int epilogue, int batch, hipStream_t st) {
-    const char *e = getenv("SCULPT_L3_PIPE");   // 0: the plain (phase-separated) K loop, for A/B; read per call
-    const bool pipe = !(e && atoi(e) == 0);
-    const char *e64 = getenv("SCULPT_L3_BM64");  // 0 / 1: never / always the 64-row tile (A/B); default: by CU fill
+    // SCULPT_L3_TILE tokens (A/B, tests; read per call): nopipe = the plain (phase-separated) K loop; bm64 / nobm64 = always /
+    // never the 64-row tile (default: by CU fill)
+    const bool pipe = !form_has("SCULPT_L3_TILE", "nopipe");
     const int gx = epilogue == SCULPT_EPI_GEGLU ? g.N / 64 : cdiv(g.N, FBW);
     const long tiles128 = (long)gx * cdiv(g.M, 128) * batch;
     // fewer than 3 tiles per CU at 128 rows (tools/time_l3_gemm.py: fused Q|K|V 149 -> 133 us, to_out 65 -> 56, FF2 213 -> 190, the
     // image tokenizer's f2 151 -> 99; FF1 with 6 tiles per CU: 286 -> 313, stays)
-    const bool bm64 = e64 ? atoi(e64) != 0 : tiles128 < 3L * num_cus();
+    const bool bm64 = form_has("SCULPT_L3_TILE", "bm64") ? true : (form_has("SCULPT_L3_TILE", "nobm64") ? false : tiles128 < 3L * num_cus());
     const int mt = cdiv(g.M, bm64 ? 64 : 128);
 #define L3_GO(E)                                                                                                          \
     do {                                                                                                                  \

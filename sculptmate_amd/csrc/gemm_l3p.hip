@@ -330,9 +330,8 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha,
     hipStream_t st = as_stream(stream);
     const int gx = geglu ? N / 64 : N / 128;
     // XCD band order: measured equal to the natural order on every shape of the two transformers (tools/time_l3p.py; the operands
-    // sit in the Infinity Cache): off unless SCULPT_L3P_ORDER=1
-    const char *eo = getenv("SCULPT_L3P_ORDER");
-    a.n_major = (eo && atoi(eo) == 1) ? ((geglu ? 2 * N : N) > M ? 1 : 0) : -1;
+    // sit in the Infinity Cache): off unless SCULPT_L3_TILE has the token "xcd"
+    a.n_major = form_has("SCULPT_L3_TILE", "xcd") ? ((geglu ? 2 * N : N) > M ? 1 : 0) : -1;
     // Tile form by the number of 128 x 128 tiles (tools/time_l3p.py, one MI355X, three bf16 limbs, us; 4 waves 128 / 4 waves 64 /
     // 8 waves 128):
     //   image tokenizer (1025 rows)  o    54 tiles  34.7 / 24.5 / 31.0     f2   54 tiles  115.8 / 82.6 / 108.6
@@ -341,13 +340,14 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha,
     //                                Q|K|V 576     127.5 / 136.5 / 124.0   FF1 1536       248.1 / 297.1 / 253.2
     // fewer tiles than half the CUs: 64-row tiles (twice the workgroups); up to three per CU: the 8-wave form (two waves per SIMD
     // even where a CU holds one workgroup); more: 4 waves, two workgroups per CU.
-    const char *e64 = getenv("SCULPT_L3P_BM64");   // 0 / 1: never / always the 64-row tile (A/B)
-    const char *e8 = getenv("SCULPT_L3P_NW8");     // 0 / 1: never / always 8 waves on the 128-row tile (A/B)
+    // SCULPT_L3_TILE tokens (A/B, tests; read per call): bm64 / nobm64 = always / never the 64-row tile; nw8 / nonw8 = always / never
+    // 8 waves on the 128-row tile
     const long tiles128 = (long)gx * cdiv(M, 128);
-    const bool bm64 = e64 ? atoi(e64) != 0 : 2 * tiles128 < num_cus();
+    const bool bm64 = form_has("SCULPT_L3_TILE", "bm64") ? true : (form_has("SCULPT_L3_TILE", "nobm64") ? false : 2 * tiles128 < num_cus());
+    const int f8 = form_has("SCULPT_L3_TILE", "nw8") ? 1 : (form_has("SCULPT_L3_TILE", "nonw8") ? 0 : -1);
     // (two fp16 limbs, tools/time_l3p_f16_forms.py: the 8-wave form only where a CU holds at most one workgroup -- fused Q|K|V
     // 77.8 against 80.8 us and FF1 + GEGLU 158 against 173 on 4 waves)
-    const bool nw8 = !bm64 && (e8 ? atoi(e8) != 0 : tiles128 <= (format == LT_F16X2 ? 1L : 3L) * num_cus());
+    const bool nw8 = !bm64 && (f8 >= 0 ? f8 != 0 : tiles128 <= (format == LT_F16X2 ? 1L : 3L) * num_cus());
 #define L3P_GO2(E, F)                                                                                                      \
     do {                                                                                                                   \
         if (bm64) hipLaunchKernelGGL((gemm_l3p_kernel<E, 64, 4, F>), dim3(gx, cdiv(M, 64)), dim3(256), 0, st, a);          \

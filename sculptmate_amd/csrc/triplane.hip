@@ -407,88 +407,6 @@ __global__ __launch_bounds__(1024) void lattice_decode_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16x3 mode of the dense grid (optional, SCULPT_DENSITY_BF16X3): the eight 64x64 hidden layers on
-// v_mfma_f32_32x32x16_bf16 with BOTH operands split into bf16 pairs, x = xh + xl, W = Wh + Wl, and
-//   W.x ~= Wh.xh + Wh.xl + Wl.xh      (every bf16 x bf16 product is exact in fp32; fp32 accumulate)
-// i.e. products carry ~2^-17 relative error instead of fp32's 2^-24 -- "fp32-range, 16-bit-mantissa products".
-// 24 bf16 MFMAs (768 cycles) per layer and 32 points instead of 64 fp32 MFMAs (4096 cycles).  First layer
-// (fp32 tables), SiLU, the last layer and exp stay fp32.  The accumulator of layer l is the B operand of layer
-// l+1 after the split (k order permuted, see sculpt_mlp_pack), so activations still never leave registers.
-// ---------------------------------------------------------------------------------------------
-
-template <typename V8>  // tbf16x8 (bf16x3) or tf16x8 (fp16x3)
-__global__ __launch_bounds__(1024) void density_grid_x3_kernel(
-    const float *__restrict__ blob, const float *__restrict__ FA, const float *__restrict__ FB,
-    const float *__restrict__ FC, int R, int nx, float density_bias, float out_add, float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [x3 weights NH*4096][bacc][wlast][blast]
-    const MlpPackHeader hd = *reinterpret_cast<const MlpPackHeader *>(blob);
-    const int NH = hd.NH;
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(blob + (sizeof(V8) && __is_same(V8, tf16x8) ? hd.off_x3h : hd.off_x3));
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-        for (int i = threadIdx.x; i < NH * 1024; i += blockDim.x) dst[i] = src[i];
-        float *bacc = smem + NH * 4096;
-        for (int i = threadIdx.x; i < (NH + 1) * 64; i += blockDim.x) bacc[i] = blob[hd.off_bacc + i];
-        float *wl = bacc + (NH + 1) * 64;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) wl[i] = blob[hd.off_wlast + i];
-        if (threadIdx.x < 4) wl[256 + threadIdx.x] = blob[hd.off_blast + threadIdx.x];
-        __syncthreads();
-    }
-    const LdsView L = lds_view(smem, NH);
-    const int lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = lane & 31, h = lane >> 5;
-    const int nzb = (R + 31) / 32;
-    const long ntiles = (long)nx * nzb * R;
-    const long nw_total = (long)gridDim.x * nwave;
-    long wid = (long)blockIdx.x * nwave + wave;
-    if (gridDim.x % 8 == 0) wid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * nwave + wave;
-    const long t_begin = ntiles * wid / nw_total, t_end = ntiles * (wid + 1) / nw_total;
-    int iy = (int)(t_begin % R);
-    int zb = (int)((t_begin / R) % nzb), ixl = (int)((t_begin / R) / nzb);
-    const V8 *A = reinterpret_cast<const V8 *>(smem) + lane;  // [l][part][T][s][lane]
-
-    for (long t = t_begin; t < t_end; ++t, ++iy) {
-        if (iy == R) {
-            iy = 0;
-            if (++zb == nzb) { zb = 0; ++ixl; }
-        }
-        const int iz = zb * 32 + p;
-        const int izc = min(iz, R - 1);
-        f32x16 x0, x1, y0, y1;
-        load_row32(FA + ((long)ixl * R + iy) * 64 + h * 32, x0, x1);
-        load_row32(FB + ((long)ixl * R + izc) * 64 + h * 32, y0, y1);
-        x0 += y0; x1 += y1;
-        load_row32(FC + ((long)iy * R + izc) * 64 + h * 32, y0, y1);
-        x0 += y0; x1 += y1;
-        x0 = silu16(x0); x1 = silu16(x1);
-        for (int l = 0; l < NH; ++l) {
-            V8 bh[4], bl[4];  // B operands of the four k-steps: tiles (x0: s = 0,1), (x1: s = 2,3)
-            split16(x0, bh, bl);
-            split16(x1, bh + 2, bl + 2);
-            f32x16 acc0 = lds_bias16(L.bacc, l + 1, h, 0);
-            f32x16 acc1 = lds_bias16(L.bacc, l + 1, h, 1);
-            const V8 *Al = A + (long)l * 16 * 64;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const V8 ah0 = Al[((0 * 2 + 0) * 4 + s4) * 64], ah1 = Al[((0 * 2 + 1) * 4 + s4) * 64];
-                const V8 al0 = Al[((1 * 2 + 0) * 4 + s4) * 64], al1 = Al[((1 * 2 + 1) * 4 + s4) * 64];
-                acc0 = mfma16(al0, bh[s4], acc0);
-                acc1 = mfma16(al1, bh[s4], acc1);
-                acc0 = mfma16(ah0, bl[s4], acc0);
-                acc1 = mfma16(ah1, bl[s4], acc1);
-                acc0 = mfma16(ah0, bh[s4], acc0);
-                acc1 = mfma16(ah1, bh[s4], acc1);
-            }
-            x0 = silu16(acc0);
-            x1 = silu16(acc1);
-        }
-        const float d = last_dot(L, 0, h, x0, x1);
-        if (h == 0 && iz < R) out[((long)ixl * R + iy) * R + iz] = exp_f(d + density_bias) + out_add;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // bf16 THREE-LIMB mode of the dense grid (SCULPT_DENSITY_BF16L3, the default of TSR.extract_meshes): the eight 64x64
 // hidden layers on v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 limbs,
 //     x = x1 + x2 + x3,  W = W1 + W2 + W3        EXACTLY (8 + 8 + 8 = 24 significant bits, fp32 exponent range:
@@ -734,7 +652,8 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
                 for (int r = 0; r < 16; ++r)
                     o[hd.off_wlast + ((oo * 2 + h) * 2 + t) * 16 + r] = (float)((double)WL[(size_t)oo * HID + nrow(t, r, h)] * LN2);
     for (int oo = 0; oo < 4; ++oo) o[hd.off_blast + oo] = bh[n_layers - 1][oo];
-    // bf16x3 mode: W = Wh + Wl (both bf16, round-to-nearest-even), k order = the accumulator order of the previous
+    // W = W1 + W2 (+ W3 below) as bf16 limbs, round-to-nearest-even (the three-limb kernels; pass A of the filtered grid multiplies
+    // by W1 alone), k order = the accumulator order of the previous
     // layer seen as a 32x32x16 B operand: k(s, kg, j) = 16 s + 8 (j >> 2) + 4 kg + (j & 3)
     uint16_t *x3 = reinterpret_cast<uint16_t *>(o + hd.off_x3);
     for (int l = 0; l < NH; ++l) {
@@ -768,7 +687,7 @@ int sculpt_mlp_pack(const float *const *Wh, const float *const *bh, int n_layers
                         w3[(size_t)l * 4096 + (((T * 4 + s4) * 64 + lane) * 8) + j] = host_f32_to_bf16(r1 - w2);
                     }
     }
-    // fp16x3 mode: the same with IEEE half parts (11-bit significands: W - (Wh + Wl) ~ 2^-22 |W|)
+    // the same with IEEE half parts (11-bit significands): pass A's fp16 operands are the leading part
     _Float16 *x3h = reinterpret_cast<_Float16 *>(o + hd.off_x3h);
     for (int l = 0; l < NH; ++l) {
         const float *Wl = Wh[l + 1];
@@ -877,6 +796,7 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
                            sculpt_stream_t stream) {
     hipStream_t st = as_stream(stream);
     SC_REQUIRE(mlp_packed && workspace && out, "density_grid: null argument");
+    SC_REQUIRE((flags & ~SCULPT_DENSITY_BF16L3) == 0, "density_grid: unknown flags %u (the two-limb modes 1 / 2 were removed)", flags);
     SC_REQUIRE(R >= 2 && x_begin >= 0 && x_end <= R && x_begin < x_end, "density_grid: bad range [%d,%d) of %d", x_begin, x_end, R);
     SC_REQUIRE(n_hidden_64 >= 0, "density_grid: bad n_hidden_64");
     const size_t lds = lds_bytes_for(n_hidden_64);
@@ -887,43 +807,24 @@ int sculpt_density_grid_ex(const void *mlp_packed, int n_hidden_64, int R, int x
     const float *FC = FB + (size_t)nx * R * 64;
     const long ntiles = (long)nx * ((R + 31) / 32) * R;
     if ((flags & SCULPT_DENSITY_BF16L3) && n_hidden_64 >= 1) {  // without hidden layers there is nothing to split: fp32 kernel
-        // A/B knobs (read per call: a debugging aid, not an interface): workgroup size, and SCULPT_DENSITY_L3_KSTEP=0 selects
-        // the phase-separated kernel instead of the k-step pipeline
-        const int l3_threads = getenv("SCULPT_DENSITY_L3_THREADS") ? atoi(getenv("SCULPT_DENSITY_L3_THREADS")) : 1024;
-        const bool kstep = !(getenv("SCULPT_DENSITY_L3_KSTEP") && atoi(getenv("SCULPT_DENSITY_L3_KSTEP")) == 0);
-        const int nt = l3_threads == 768 ? 768 : (l3_threads == 512 ? 512 : 1024);
-        auto kern = kstep ? (nt == 1024 ? density_grid_l3k_kernel<1024> : nt == 768 ? density_grid_l3k_kernel<768> : density_grid_l3k_kernel<512>)
-                          : (nt == 1024 ? density_grid_l3_kernel<1024> : nt == 768 ? density_grid_l3_kernel<768> : density_grid_l3_kernel<512>);
+        // SCULPT_DENSITY_FORM=nokstep (read per call): the phase-separated kernel instead of the k-step pipeline -- the same
+        // arithmetic in the same order, the reference the pipelined kernel is pinned to bit for bit (tests/test_gpu_triplane.py)
+        const bool kstep = !form_has("SCULPT_DENSITY_FORM", "nokstep");
+        constexpr int nt = 1024;
+        auto kern = kstep ? density_grid_l3k_kernel<1024> : density_grid_l3_kernel<1024>;
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nwave = nt / 64;
-        int grid = (int)std::min<long>((ntiles + nwave - 1) / nwave, num_cus());
-        if (getenv("SCULPT_DENSITY_L3_GRID")) grid = std::min(grid, atoi(getenv("SCULPT_DENSITY_L3_GRID")));  // DVFS experiment
+        const int grid = (int)std::min<long>((ntiles + nwave - 1) / nwave, num_cus());
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), lds, st, reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx,
                            density_bias, out_add, out);
         SC_LAUNCH_CHECK();
         return 0;
     }
-    if (flags & (SCULPT_DENSITY_BF16X3 | SCULPT_DENSITY_FP16X3)) {
-        auto kern = (flags & SCULPT_DENSITY_FP16X3) ? density_grid_x3_kernel<tf16x8> : density_grid_x3_kernel<tbf16x8>;
-        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, reinterpret_cast<const float *>(mlp_packed),
-                           FA, FB, FC, R, nx, density_bias, out_add, out);
-        SC_LAUNCH_CHECK();
-        return 0;
-    }
-    static int nthreads = getenv("SCULPT_DENSITY_THREADS") ? atoi(getenv("SCULPT_DENSITY_THREADS")) : 1024;
-    static int xcd_band = getenv("SCULPT_DENSITY_NO_XCD_BAND") ? 0 : 1;
-    if (nthreads == 1024) {
+    {
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int grid = (int)std::min<long>((ntiles + 15) / 16, num_cus());
         hipLaunchKernelGGL(density_grid_kernel<1024>, dim3(grid), dim3(1024), lds, st,
-                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out, xcd_band);
-    } else {
-        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(density_grid_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int grid = (int)std::min<long>((ntiles + 7) / 8, num_cus());
-        hipLaunchKernelGGL(density_grid_kernel<512>, dim3(grid), dim3(512), lds, st,
-                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out, xcd_band);
+                           reinterpret_cast<const float *>(mlp_packed), FA, FB, FC, R, nx, density_bias, out_add, out, 1);
     }
     SC_LAUNCH_CHECK();
     return 0;

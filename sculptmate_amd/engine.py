@@ -5,20 +5,22 @@ fp32:   every GEMM / attention / norm on the exact-fp32 parity kernels (the refe
 fp16l2: "bf16l3" with the hot Linears (limbs once, below) on TWO fp16 limbs per operand: 22 significant bits, three products per
         multiply instead of six; weights are stored pre-scaled into the fp16 range, activations must stay below 65504 in magnitude
         (they are LayerNorm outputs, attention outputs, GELU / GEGLU products; a value beyond it makes the result non-finite, which
-        the model checks for and answers with its three-limb twin).  Attention products and the cold Linears stay on three bf16 limbs.
+        the model checks for and answers with its three-limb twin).  The attention products run on two fp16 limbs as well
+        (csrc/attention_l2.hip: scores and P.V, three products each) wherever the pipelined limb attention runs -- the backbone;
+        the image tokenizer's small launches and the cold Linears stay on three bf16 limbs.
 bf16l3: fp32 storage and fp32 norms / softmax like "fp32", but every matrix product (Linears, QK^T, PV) on the bf16 matrix pipe
         through the exact three-limb split of both operands, fp32 accumulate (csrc/gemm_l3.hip): fp32-equivalent, ~6x faster.
-        "Limbs once" (default in this mode, SCULPT_L3P=0 restores the form that splits inside every GEMM): a subclass that
+        "Limbs once" (default in this mode, SCULPT_L3_TILE=split restores the form that splits inside every GEMM): a subclass that
         stores its hot Linear weights as ops.Limbs (split at load time) and allocates the activations that only feed such a
         Linear with _lt() gets them written as limbs by their producers -- LayerNorm, attention, the GELU / GEGLU epilogue -- and
         multiplied by csrc/gemm_l3p.hip: the same products in the same order, bit-identical results, no split in any K loop.
-A subclass provides self.precision ("bf16" | "fp32" | "bf16l3"), self.device and self._buf = {}.
+A subclass provides self.precision ("bf16" | "fp32" | "bf16l3" | "fp16l2"), self.device and self._buf = {}.
 """
 import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 BF16 = torch.bfloat16
 
@@ -92,8 +94,8 @@ class KernelEngine:
         launches over all heads: scores = alpha Q K^T into an fp32 [heads][Tq][Tk] scratch, row softmax, P V)."""
         if self.precision == "bf16":
             return ops.attention(Q, K, Vt, O, Tq, Tk, heads, scale, batch, q_bs, k_bs, vt_bs, o_bs)
-        # bf16l3: one fused launch, no score matrix; SCULPT_L3_ATTN_FUSED=0 keeps the three-launch composition (A/B)
-        fused = self.l3 and os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0"
+        # bf16l3: one fused launch, no score matrix; SCULPT_ATTN_FORM=l3unfused keeps the three-launch composition (A/B)
+        fused = self.l3 and not _lib.form_has("SCULPT_ATTN_FORM", "l3unfused")
         if fused:
             chunks = [(0, heads, None)]
         else:

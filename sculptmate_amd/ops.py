@@ -110,7 +110,7 @@ def _workspace(key, nbytes, device):
     return t
 
 
-_DENSITY_FLAGS = {"fp32": 0, "bf16x3": _lib.DENSITY_BF16X3, "fp16x3": _lib.DENSITY_FP16X3, "bf16l3": _lib.DENSITY_BF16L3}
+_DENSITY_FLAGS = {"fp32": 0, "bf16l3": _lib.DENSITY_BF16L3}
 
 
 def lattice_decode(planes, mlp, axis, radius, density_bias=0.0, out_add=0.0, want=("density_act",), align_corners=True,
@@ -146,9 +146,8 @@ def density_grid(planes, mlp, resolution, radius=0.87, density_bias=-1.0, x_begi
     """density_act (+ out_add) over the lattice slab ix in [x_begin, x_end): f32 [(x_end-x_begin)*R*R]
     (TSR.extract_mesh's dense query, system.py:171-183; out_add=-threshold folds system.py:184).
     events: optional (start, stop) torch.cuda.Event pair recorded around the fused MLP launch only.
-    precision: "fp32" (exact fp32 MFMA; this function's default), "bf16l3" (three exact bf16 limbs per operand, six products,
-    fp32 accumulate: fp32-equivalent, what TSR.extract_meshes uses), or the two-limb experiments "bf16x3" / "fp16x3"
-    (operands represented to ~2^-17 / ~2^-22)."""
+    precision: "fp32" (exact fp32 MFMA; this function's default) or "bf16l3" (three exact bf16 limbs per operand, six products,
+    fp32 accumulate: fp32-equivalent, what TSR.extract_meshes uses)."""
     if precision not in _DENSITY_FLAGS:
         raise SculptError("density_grid: precision must be one of %s" % sorted(_DENSITY_FLAGS))
     planes = _req(planes, torch.float32, "planes")
@@ -389,7 +388,7 @@ def marching_cubes(vol, level=0.0, reference_order=False, vert_div=1.0, vert_mul
 
 _MC_CAPACITY = {}     # (device, n0, n1, n2, flags) -> (vertex capacity, face capacity) of the speculative emit
 _MC_REC_CAPACITY = {} # (device, n0, n1, n2) -> active-cell records of the workspace once the default pool was too small
-_MC_SPECULATE = os.environ.get("SCULPT_MC_SPECULATE", "1") != "0"
+_MC_SPECULATE = not _lib.form_has("SCULPT_MC_FORM", "nospeculate")   # A/B: the two-phase path every time
 
 
 # ----------------------------------------------------------------------------------------------

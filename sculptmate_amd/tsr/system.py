@@ -129,7 +129,7 @@ class PendingMesh:
         return self._mesh
 
 
-_MC_SIGN_PLANES = os.environ.get("SCULPT_MC_SIGN_PLANES", "1") != "0"
+_MC_SIGN_PLANES = not _lib.form_has("SCULPT_MC_FORM", "noplanes")   # A/B: the plain count phase over the whole volume
 
 
 class PendingTokens:
@@ -212,8 +212,6 @@ class TSR(KernelEngine):
                    exponent range), six exact products per weight on the bf16 matrix pipe, fp32 accumulation; no range
                    limit and no fallback; measured error against the CPU oracle = the fp32 kernel's own.
           "fp32":  the exact-fp32 MFMA kernel (a k-ordered fmaf chain, 1.5x slower): the parity mode.
-          "fp16x3" / "bf16x3": two-limb experiments with 22 / 16-bit operands (fp16x3 needs |activation| < 65504 and falls
-                   back to fp32 when the volume comes out non-finite); kept for A/B only, never the default.
         decoder_filter (default True; applies to decoder_precision "bf16l3"): extract_mesh evaluates the dense grid in two passes
           (csrc/density_filter.hip) -- every lattice point with one 16-bit product per hidden layer, then the three-limb arithmetic at
           all corners of every cell that can be active -- which gives the mesh of the full evaluation bit for bit as long as no coarse
@@ -222,8 +220,8 @@ class TSR(KernelEngine):
           margin (filter_info counts both).  False: every lattice point with the three-limb arithmetic."""
         if precision not in ("bf16", "fp32", "bf16l3", "fp16l2"):
             raise ValueError("precision must be 'bf16', 'fp32', 'bf16l3' or 'fp16l2'")
-        if decoder_precision not in ("fp32", "bf16l3", "bf16x3", "fp16x3"):
-            raise ValueError("decoder_precision must be 'bf16l3', 'fp32', 'fp16x3' or 'bf16x3'")
+        if decoder_precision not in ("fp32", "bf16l3"):
+            raise ValueError("decoder_precision must be 'bf16l3' or 'fp32'")
         self.decoder_precision = decoder_precision
         self.decoder_filter = bool(decoder_filter)
         # state of the two-pass density grid: margin (None = not calibrated yet), coarse operand type, counters
@@ -303,9 +301,11 @@ class TSR(KernelEngine):
         sd, cfg = self._sd, self.cfg
         wt = _bf if self.precision == "bf16" else _f32  # GEMM weight storage
         # "limbs once" (engine.py): in the three-limb mode the Linears of the two transformers keep their weights split
-        # (the attention must be the fused kernel: the three-launch composition, SCULPT_L3_ATTN_FUSED=0, has no limb output)
-        fused_attn = os.environ.get("SCULPT_L3_ATTN_FUSED", "1") != "0"
-        self.l3p = self.precision == "fp16l2" or (self.precision == "bf16l3" and os.environ.get("SCULPT_L3P", "1") != "0" and fused_attn)
+        # (the attention must be the fused kernel: the three-launch composition has no limb output)
+        # A/B forms (tests): SCULPT_ATTN_FORM=l3unfused = the three-launch composition of the limb attention; SCULPT_L3_TILE=split =
+        # every GEMM splits its operands while staging (the form before limbs-once)
+        fused_attn = not _lib.form_has("SCULPT_ATTN_FORM", "l3unfused")
+        self.l3p = self.precision == "fp16l2" or (self.precision == "bf16l3" and not _lib.form_has("SCULPT_L3_TILE", "split") and fused_attn)
         if self.l3p:
             # sculpt_gemm_l3p's tiles: N % 128 == 0 (N % 64 per GEGLU half), K % 32 == 0 for every Linear kept as limbs.  A model
             # with other widths runs "bf16l3" on the splitting GEMM (csrc/gemm_l3.hip: N % 4), as it did before limbs-once.
@@ -319,7 +319,7 @@ class TSR(KernelEngine):
                 if bad or not fused_attn:
                     raise ValueError("precision='fp16l2' needs Linear widths the limb GEMM tiles (multiples of 128; cross-attention "
                                      "width a multiple of 32) and the fused limb attention (SCULPT_L3_ATTN_FUSED unset): "
-                                     + (", ".join(bad) or "SCULPT_L3_ATTN_FUSED=0"))
+                                     + (", ".join(bad) or "SCULPT_ATTN_FORM=l3unfused"))
             elif bad:
                 self.l3p = False
         self.limb_format = "f16x2" if self.precision == "fp16l2" else "bf16x3"
@@ -807,14 +807,7 @@ class TSR(KernelEngine):
                 out.append(Mesh(v_pos, t_pos_idx, color))
                 continue
             vol = ops.density_grid(planes, self.decoder, R, precision=self.decoder_precision, events=density_events, **dkw)
-            try:
-                v_pos, t_pos_idx = mc(vol)
-            except _lib.SculptError as e:
-                if e.code != _lib.ERR_MC_NAN or self.decoder_precision != "fp16x3":
-                    raise  # fp32 and the bf16 limb modes have the fp32 range: a NaN there is a NaN of the model
-                # the fp16 split left its range (|hidden activation| >= 65504): redo this grid in exact fp32
-                vol = ops.density_grid(planes, self.decoder, R, out=vol, **dkw)
-                v_pos, t_pos_idx = mc(vol)
+            v_pos, t_pos_idx = mc(vol)   # (both decoder modes have the fp32 range: a NaN here is a NaN of the model)
             color = None
             if enable_texture:
                 color = self.renderer.query_triplane(self.decoder, v_pos, planes)["color"]
@@ -905,7 +898,7 @@ class TSR(KernelEngine):
         r = self.renderer.cfg.radius
         planes = scene_code.contiguous()
         kw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, threshold=threshold,
-                  precision="fp32" if self.decoder_precision == "fp16x3" else self.decoder_precision)
+                  precision=self.decoder_precision)
         if self._filter_applies(planes, resolution, threshold):
             # every slab through the two-pass grid (cells inside the slab's planes only: the halo plane is part of the slab)
             dkw = dict(radius=r, density_bias=self.renderer.cfg.density_bias, out_add=-threshold)

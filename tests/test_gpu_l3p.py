@@ -45,7 +45,7 @@ def test_l3p_gemm_equals_the_splitting_kernel_bit_for_bit(M, N, K, bm64, monkeyp
     from sculptmate_amd import ops
 
     if bm64 is not None:
-        monkeypatch.setenv("SCULPT_L3P_BM64", bm64)
+        monkeypatch.setenv("SCULPT_L3_TILE", "bm64" if bm64 == "1" else "nobm64")
     g = torch.Generator().manual_seed(M + N)
     A, W, bias = _rand((M, K), g), _rand((N, K), g, K ** -0.5), _rand((N,), g)
     res = _rand((M, N), g)
@@ -152,7 +152,7 @@ def test_layernorm_and_attention_write_the_limbs_of_their_fp32_results():
 
 
 def test_limbs_once_forward_is_bit_identical_to_the_splitting_kernels(monkeypatch):
-    """TSR(precision="bf16l3") with the operands split once (default) against SCULPT_L3P=0 (every GEMM splits while staging): the
+    """TSR(precision="bf16l3") with the operands split once (default) against SCULPT_L3_TILE=split (every GEMM splits while staging): the
     same products in the same order -> the same scene code, bit for bit; one image and a batch of two."""
     from sculptmate_amd import synth
     from sculptmate_amd.tsr.spec import SMALL_CFG
@@ -162,7 +162,7 @@ def test_limbs_once_forward_is_bit_identical_to_the_splitting_kernels(monkeypatc
     imgs = [torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=s, size=SMALL_CFG["cond_image_size"]))).to(_dev()) for s in (1, 2)]
     codes = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("SCULPT_L3P", flag)
+        monkeypatch.setenv("SCULPT_L3_TILE", "" if flag == "1" else "split")
         m = TSR(SMALL_CFG, pos_embed_mode="size", precision="bf16l3")
         m.load_state_dict(sd)
         m.to(_dev())
@@ -212,8 +212,7 @@ def test_l3p_smallest_and_ragged_shapes(M, N, K, monkeypatch):
     want = res.clone()
     ops.gemm_f32(A, W, bias=bias, residual=want, out=want, l3=True)
     for bm64, nw8 in (("0", "0"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("SCULPT_L3P_BM64", bm64)
-        monkeypatch.setenv("SCULPT_L3P_NW8", nw8)
+        monkeypatch.setenv("SCULPT_L3_TILE", "%s,%s" % ("bm64" if bm64 == "1" else "nobm64", "nw8" if nw8 == "1" else "nonw8"))
         got = res.clone()
         ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, residual=got, out=got)
         assert torch.equal(got, want), (bm64, nw8)
@@ -251,12 +250,12 @@ def test_two_fp16_limbs_format():
     ref = (ja.double() @ jw.double().t() + bias.double())
     for bm64, nw8 in (("0", "0"), ("1", "0"), ("0", "1")):
         import os
-        os.environ["SCULPT_L3P_BM64"], os.environ["SCULPT_L3P_NW8"] = bm64, nw8
+        os.environ["SCULPT_L3_TILE"] = "%s,%s" % ("bm64" if bm64 == "1" else "nobm64", "nw8" if nw8 == "1" else "nonw8")
         try:
             got = torch.empty(M, N, device=_dev())
             ops.gemm_l3p(A_lt, W_lt, M, N, K, bias=bias, out=got)
         finally:
-            os.environ.pop("SCULPT_L3P_BM64"); os.environ.pop("SCULPT_L3P_NW8")
+            os.environ.pop("SCULPT_L3_TILE")
         bound = (ja.abs().double() @ jw.abs().double().t())
         assert float(((got.double() - ref).abs() / bound).max()) < 3e-7, (bm64, nw8)
     # and against fp64 on the fp32 operands: 22-bit operand rounding
@@ -323,7 +322,7 @@ def test_two_fp16_limb_attention_vs_fp64(Tq, Tk, heads, gain, monkeypatch):
 
     from sculptmate_amd import ops
 
-    monkeypatch.setenv("SCULPT_L3_ATTN_PIPE", "1")     # the pipelined form on every shape (the small ones default to the 4-wave kernel)
+    monkeypatch.setenv("SCULPT_ATTN_FORM", "l3pipe")     # the pipelined form on every shape (the small ones default to the 4-wave kernel)
     g = torch.Generator().manual_seed(Tq + Tk)
     D = heads * 64
     Q, K = _rand((Tq, D), g, gain), _rand((Tk, D), g)

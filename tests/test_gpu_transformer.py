@@ -153,7 +153,7 @@ def test_attention_prescaled_q_with_forced_rescales(cuda, Tq, Tk, heads):
 @pytest.mark.parametrize("Tq,heads", [(3072, 16), (1025, 12), (130, 2)])
 def test_attention_pipelined_loop_against_the_phase_separated_loop(cuda, monkeypatch, Tq, heads):
     """attention_pipe_kernel (pre-scaled queries: softmax of tile t in the MFMA shadows of the scores of t + 1 and of P.V of t, K
-    rows read in a permuted order, one score tile computed ahead) against attention_kernel<., true> (SCULPT_ATTN_PIPE=0) and the
+    rows read in a permuted order, one score tile computed ahead) against attention_kernel<., true> (SCULPT_ATTN_FORM=nopipe) and the
     fp64 softmax of the same bf16 operands -- at every key count around the tile boundaries: the look-ahead tile is missing,
     ragged, belongs to the other key half only, or is a complete pair."""
     from sculptmate_amd import ops
@@ -169,8 +169,8 @@ def test_attention_pipelined_loop_against_the_phase_separated_loop(cuda, monkeyp
         vt = torch.zeros(D, ((Tk + 63) // 64) * 64, dtype=BF, device=cuda)
         vt[:, :Tk] = torch.randn(Tk, D, generator=g).to(BF).t().to(cuda)
         outs = []
-        for pipe in ("1", "0"):
-            monkeypatch.setenv("SCULPT_ATTN_PIPE", pipe)   # read per call
+        for form in ("", "nopipe"):
+            monkeypatch.setenv("SCULPT_ATTN_FORM", form)   # read per call
             o = torch.full((Tq, D), float("nan"), dtype=BF, device=cuda)
             ops.attention(qs, k, vt, o, Tq, Tk, heads, None)
             outs.append(o.double().cpu())
@@ -203,8 +203,8 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_128_row_tiles(cuda, monkeyp
     stats = torch.randn(K // 64, M, 2, generator=g).abs().to(cuda) + 0.5
     Mp = (M + 63) // 64 * 64
 
-    def run(mode):
-        monkeypatch.setenv("SCULPT_GEMM_256", mode)
+    def run(tile):
+        monkeypatch.setenv("SCULPT_GEMM_TILE", tile)   # read per call: one variable, comma-separated tokens (csrc/common.h)
         if split:
             o = torch.zeros(M, split, dtype=BF, device=cuda)
             ot = torch.zeros(N - split, Mp, dtype=BF, device=cuda)
@@ -215,12 +215,11 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_128_row_tiles(cuda, monkeyp
         ops.gemm(A, W, bias=bias, out_bf16=o, out_f32=of, epilogue=epi, ln_stats=stats, ln_colsum=cs, ln_eps=1e-5)
         return o, of
 
-    ref = run("0")
+    ref = run("no256")
     assert torch.isfinite(ref[1].float()).all()
-    for bm192 in ("0", "1"):  # 256- and 192-row tiles
-        monkeypatch.setenv("SCULPT_GEMM_192", bm192)
+    for bm192 in ("no192", "192"):  # 256- and 192-row tiles
         for rep in range(5):
-            got = run("2")
+            got = run("256," + bm192)
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (bm192, rep)
 
 
@@ -237,10 +236,9 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
     b = torch.randn(N, generator=g).to(cuda)
     h0 = (torch.randn(M, N, generator=g) + 2.0 * torch.randn(M, 1, generator=g)).to(cuda)
 
-    monkeypatch.setenv("SCULPT_GEMM_KS", "0")   # the 128-row side in its k order (the k-split pairs differ by fp32 rounding)
-
     def run(flag):
-        monkeypatch.setenv("SCULPT_GEMM_RES256", flag)
+        # ks0: the 128-row side in its k order (the k-split pairs differ by fp32 rounding)
+        monkeypatch.setenv("SCULPT_GEMM_TILE", "ks0," + flag)
         h = h0.clone()
         hb = torch.empty(M, N, dtype=BF, device=cuda)
         st = torch.zeros(N // 64, M, 2, device=cuda)
@@ -248,8 +246,8 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
             ops.gemm(A, W, bias=b, residual=h, out_f32=h, out_bf16=hb, stats_out=st)
         return h, hb, st
 
-    h1, hb1, st1 = run("0")
-    h2, hb2, st2 = run("1")
+    h1, hb1, st1 = run("nores")
+    h2, hb2, st2 = run("res")
     assert torch.equal(h1, h2) and torch.equal(hb1, hb2)
     assert _rel(st2, st1)[0] < 1e-6
     ref = h0.double().cpu() + 2 * (A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
@@ -261,9 +259,9 @@ def test_gemm_residual_form_of_the_192_row_tile_kernel(cuda, monkeypatch, M, K):
 @pytest.mark.parametrize("M,K,N,residual", [(3072, 1024, 1024, True), (3072, 4096, 1024, True), (3072, 1024, 1024, False),
                                             (1536, 256, 2048, True), (960, 128, 1024, False)])
 def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, K, N, residual):
-    """gemm_bf16_kernel<NONE, 64, 8, false, 192> and <NONE, 128, 8, false, 96, 4> (round 5: M = 3072, N = 1024 as ONE round of 256
-    tiles of 192 x 64 or 96 x 128; SCULPT_GEMM_KS=0: the weight-row split) against the 128 x 64 tiles on the same operands: the same k order per output, so h, bf16(h), the slice statistics (residual form) or the
-    LayerNorm-folded bf16 output are equal bit for bit, over repeated in-place launches."""
+    """gemm_bf16_kernel<NONE, 64, 8, false, 192> (round 5: M = 3072, N = 1024 as ONE round of 256 tiles of 192 x 64; token ks0: the
+    weight-row split) against the 128 x 64 tiles on the same operands: the same k order per output, so h, bf16(h), the slice
+    statistics (residual form) or the LayerNorm-folded bf16 output are equal bit for bit, over repeated in-place launches."""
     from sculptmate_amd import ops
 
     g = torch.Generator().manual_seed(M + K + N)
@@ -276,10 +274,8 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
     stats_in[..., 1] = 64.0 + torch.rand(K // 64, M, device=cuda)
     cs = W.float().sum(1).contiguous()
 
-    def run(bm192, bm96, ks="0"):
-        monkeypatch.setenv("SCULPT_GEMM_BM192", bm192)
-        monkeypatch.setenv("SCULPT_GEMM_BM96", bm96)
-        monkeypatch.setenv("SCULPT_GEMM_KS", ks)
+    def run(tile):
+        monkeypatch.setenv("SCULPT_GEMM_TILE", tile)
         if residual:
             h = h0.clone()
             hb = torch.empty(M, N, dtype=BF, device=cuda)
@@ -291,13 +287,13 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
         ops.gemm(A, W, bias=b, out_bf16=o, ln_stats=stats_in, ln_colsum=cs, ln_eps=1e-5)
         return (o,)
 
-    a = run("0", "0")
-    for c in (run("1", "0"), run("0", "1")):   # 192 x 64 tiles; 96 x 128 tiles (4 x 2 waves, uneven staging, three-stage ring)
-        for x, y in zip(a, c):
-            assert torch.equal(x, y)
+    a = run("nobm192")
+    c = run("bm192,ks0")   # 192 x 64 tiles, weight-row split
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)
     # the shipped form of the 192 x 64 tiles: the two waves of a band split the K-tile instead of the weight rows (30 % fewer LDS
     # fragment bytes) -- the sum is (even k-steps) + (odd k-steps): equal to fp32 rounding, bf16 outputs to one rounding flip
-    c = run("1", "0", ks="1")
+    c = run("bm192")
     assert _rel(c[0].float(), a[0].float())[0] < (1e-6 if residual else 1e-3)   # fp32 h: rounding of two partial sums; bf16: flips
     if residual:
         assert (c[1].float() - a[1].float()).abs().max() <= 2.0 ** -7 * a[1].float().abs().max()
@@ -305,7 +301,7 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
         ref = h0.double().cpu() + 2 * (A.double().cpu() @ W.double().cpu().t() + b.double().cpu())
         assert _rel(a[0], ref.float())[0] < 1e-5 and _rel(c[0], ref.float())[0] < 1e-5
         for _ in range(2):   # and it is reproducible
-            c2 = run("1", "0", ks="1")
+            c2 = run("bm192")
             assert all(torch.equal(x, y) for x, y in zip(c, c2))
 
 
@@ -326,11 +322,8 @@ def test_gemm256_staged_stores_equal_direct_stores(cuda, monkeypatch, M, K, N, e
     stats = torch.zeros(K // 64, M, 2, device=cuda); stats[..., 1] = 64.0 + torch.rand(K // 64, M, device=cuda)
     cs = W.float().sum(1).contiguous()
     Mp = ((M + 63) // 64) * 64
-    monkeypatch.setenv("SCULPT_GEMM_256", "2")
-    monkeypatch.setenv("SCULPT_GEMM_192", str(bm192))
-
     def run(stage):
-        monkeypatch.setenv("SCULPT_GEMM_STAGE", stage)
+        monkeypatch.setenv("SCULPT_GEMM_TILE", "256,%s%s" % ("192" if bm192 else "no192", "" if stage == "1" else ",nostage"))
         ncol = split if split else N
         buf = torch.full((M + 3, ncol + 8), 7.0, dtype=BF, device=cuda)     # the output is a column slice of a wider buffer
         o = buf[:M, :ncol]

@@ -141,48 +141,26 @@ def test_channel_last_query_is_bit_identical_to_reference_layout(cuda, align):
         assert torch.equal(a[k], b[k]), k
 
 
-def test_density_grid_bf16x3_mode_accuracy_and_mesh(cuda):
-    """Optional split-operand bf16 mode of the dense query: density within 1e-3 relative of the fp32 kernel and of the
-    oracle (measured 3-4e-4), mesh vertices within 1e-4 of the bounding box of the fp32 mesh (north-star tolerance)."""
-    import torch
-    from scipy.spatial import cKDTree
+def test_density_grid_refuses_the_removed_two_limb_modes(cuda):
+    """The two-limb decoder experiments of rounds 2-5 ("bf16x3" / "fp16x3", flags 1 / 2 of sculpt_density_grid_ex) are gone: the
+    names are refused by the binding and the flag values by the library."""
+    import ctypes
 
-    from sculptmate_amd import ops, synth
+    from sculptmate_amd import _lib, ops, synth
 
-    sd = synth.decoder_state(1)
-    Ws, bs = synth.decoder_lists(sd)
-    tri_np = synth.smooth_triplane(seed=2, scale=3.0)
-    pre = np.log(capi.density_grid(tri_np, Ws, bs, 16)) + 1.0
-    bs[-1] = bs[-1].copy()
-    bs[-1][0] += synth.calibrate_density_bias(pre, inside_fraction=0.1)
+    Ws, bs = synth.decoder_lists(synth.decoder_state(1))
     mlp = ops.PackedMLP(Ws, bs, cuda)
-    tri = torch.from_numpy(tri_np).to(cuda)
-    R = 96
-    a = ops.density_grid(tri, mlp, R)
-    b = ops.density_grid(tri, mlp, R, precision="bf16x3")
-    rel = ((a - b).abs() / a).max().item()
-    assert rel < 1e-3, rel
-    ref = capi.density_grid(tri_np, Ws, bs, R)
-    assert np.abs(np.log(b.cpu().numpy()) - np.log(ref)).max() < 1e-3
-    # slabs of the lattice are consistent in this mode too
-    c = ops.density_grid(tri, mlp, R, precision="bf16x3", x_begin=10, x_end=20)
-    assert torch.equal(c, b.view(R, R, R)[10:20].reshape(-1))
-    va, fa = ops.marching_cubes((a - 25.0).view(R, R, R), 0.0)
-    vb, fb = ops.marching_cubes((b - 25.0).view(R, R, R), 0.0)
-    assert abs(va.shape[0] - vb.shape[0]) <= max(4, va.shape[0] // 500)
-    d, _ = cKDTree(va.cpu().numpy()).query(vb.cpu().numpy())
-    assert np.quantile(d, 0.999) < 1e-4 * (R - 1), np.quantile(d, 0.999)  # voxel units: 1e-4 of the box edge
-    with pytest.raises(Exception):
-        ops.density_grid(tri, mlp, R, precision="bf16")
-    # fp16x3: half parts carry 22 bits -> the same error class as the fp32 kernel against the CPU oracle
-    h = ops.density_grid(tri, mlp, R, precision="fp16x3")
-    e32 = np.abs(np.log(a.cpu().numpy()) - np.log(ref)).max()
-    e16 = np.abs(np.log(h.cpu().numpy()) - np.log(ref)).max()
-    assert e16 < 1e-4 and e16 < 4 * e32 + 1e-6, (e16, e32)
-    vh, fh = ops.marching_cubes((h - 25.0).view(R, R, R), 0.0)
-    assert abs(va.shape[0] - vh.shape[0]) <= max(2, va.shape[0] // 5000)
-    d, _ = cKDTree(va.cpu().numpy()).query(vh.cpu().numpy())
-    assert np.quantile(d, 0.999) < 1e-5 * (R - 1)
+    tri = torch.from_numpy(synth.smooth_triplane(seed=2, scale=3.0)).to(cuda)
+    for prec in ("bf16x3", "fp16x3", "bf16"):
+        with pytest.raises(_lib.SculptError):
+            ops.density_grid(tri, mlp, 16, precision=prec)
+    out = ops.density_grid(tri, mlp, 16)     # leaves the plane tables in the workspace
+    ws = ops._ws_cache[("dg", tri.device)]
+    for flag in (1, 2, 3, 8):
+        rc = _lib.lib.sculpt_density_grid_ex(ctypes.c_void_p(mlp.blob.data_ptr()), mlp.n_hidden, 16, 0, 16, -1.0, 0.0,
+                                             ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(out.data_ptr()), flag,
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0 and "unknown flags" in _lib.last_error()
 
 
 @pytest.mark.parametrize("R", [8, 33, 64])
@@ -214,11 +192,11 @@ def test_density_grid_bf16l3_other_depths(cuda, n_hidden_layers):
     for prec in ("fp32", "bf16l3"):
         out = ops.density_grid(tri, mlp, R, precision=prec).cpu().numpy()
         np.testing.assert_allclose(np.log(out), ref, rtol=0, atol=5e-5, err_msg=prec)
-    os.environ["SCULPT_DENSITY_L3_KSTEP"] = "0"   # the phase-separated form of the same arithmetic
+    os.environ["SCULPT_DENSITY_FORM"] = "nokstep"   # the phase-separated form of the same arithmetic
     try:
         out0 = ops.density_grid(tri, mlp, R, precision="bf16l3").cpu().numpy()
     finally:
-        del os.environ["SCULPT_DENSITY_L3_KSTEP"]
+        del os.environ["SCULPT_DENSITY_FORM"]
     np.testing.assert_allclose(np.log(out0), ref, rtol=0, atol=5e-5)
 
 
@@ -326,32 +304,3 @@ def test_tsr_default_decoder_mode_is_the_three_limb_kernel():
     assert TSR(SMALL_CFG).decoder_precision == "bf16l3"
     with pytest.raises(ValueError):
         TSR(SMALL_CFG, decoder_precision="bf16")
-
-
-def test_fp16x3_range_overflow_falls_back_to_fp32(cuda):
-    """Hidden activations beyond the fp16 range make the split mode produce NaN; TSR.extract_meshes redoes the grid in
-    exact fp32 (same mesh as a pure fp32 model)."""
-    import torch
-
-    from sculptmate_amd import _lib, ops, synth
-    from sculptmate_amd.tsr import TSR
-    from sculptmate_amd.tsr.spec import SMALL_CFG
-
-    sd = synth.tsr_state(3, SMALL_CFG)
-    # blow up one hidden layer and undo it in the next: fp32 is fine with 1e6-sized activations, fp16 parts are not
-    sd["decoder.layers.4.weight"] = (sd["decoder.layers.4.weight"] * np.float32(1e6)).astype(np.float32)
-    sd["decoder.layers.4.bias"] = (sd["decoder.layers.4.bias"] * np.float32(1e6)).astype(np.float32)
-    sd["decoder.layers.6.weight"] = (sd["decoder.layers.6.weight"] * np.float32(1e-6)).astype(np.float32)
-    planes = torch.from_numpy(synth.smooth_triplane(seed=5, size=16, scale=2.0)).to(cuda)[None]
-    meshes = {}
-    for prec in ("fp32", "fp16x3"):
-        m = TSR(SMALL_CFG, decoder_precision=prec)
-        m.load_state_dict(sd)
-        m.to(cuda)
-        dens = ops.density_grid(planes[0], m.decoder, 32, precision=prec)
-        if prec == "fp16x3":
-            assert not torch.isfinite(dens).all()
-        thr = float(np.quantile(ops.density_grid(planes[0], m.decoder, 32).cpu().numpy(), 0.9))
-        meshes[prec] = m.extract_meshes(planes, resolution=32, threshold=thr)[0]
-    assert torch.equal(meshes["fp32"].faces, meshes["fp16x3"].faces)
-    assert torch.equal(meshes["fp32"].vertices, meshes["fp16x3"].vertices)

@@ -12,11 +12,11 @@ dev = torch.device("cuda:0")
 sd = synth.tsr_state(seed=0)
 img = torch.from_numpy(synth.composite_rgb(synth.image_rgba(seed=100))).to(dev)
 codes = {}
-# "bf16l3-split": the same mode with SCULPT_L3P=0, every GEMM splitting its operands while staging them (the form before "limbs once")
+# "bf16l3-split": the same mode with SCULPT_L3_TILE=split, every GEMM splitting its operands while staging them (the form before "limbs once")
 modes = [sys.argv[sys.argv.index("--prof") + 1]] if "--prof" in sys.argv else ["fp16l2", "bf16l3", "bf16l3-split", "fp32", "bf16"]
 with torch.no_grad():
     for mode in modes:
-        os.environ["SCULPT_L3P"] = "0" if mode.endswith("-split") else "1"
+        os.environ["SCULPT_L3_TILE"] = "split" if mode.endswith("-split") else ""
         m = TSR(pos_embed_mode="scale_factor", precision=mode.split("-")[0]); m.load_state_dict(sd); m.to(dev)
         for _ in range(2):
             c = m([img], device=dev)
