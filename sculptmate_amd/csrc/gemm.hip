@@ -125,7 +125,7 @@ static constexpr int LN_SLOT = 64;  // columns per statistics slice (a BW=64 til
 // TI + ... fragments: (2 TI + TJ) reads per 2 TI TJ MFMAs where the weight-row split reads 2 (TI + TJ)), and after the K loop the
 // pair exchanges halves through the (free) LDS ring, so that every wave ends with the sums of its usual TI x TJ tiles and the
 // epilogue is unchanged.  Same MFMAs, 30 % fewer LDS fragment bytes (192 x 64 tile: 7 instead of 10 reads per K-tile and wave):
-// these K loops are bound by LDS read bandwidth.  The sum is (even k-steps) + (odd k-steps): not the
+// these K loops are bound by LDS read bandwidth (DESIGN_HISTORY.md, transformer stack, round 5).  The sum is (even k-steps) + (odd k-steps): not the
 // k order of the other tile forms, i.e. equal to them to fp32 rounding, not bit for bit.
 template <int EPI, int BW, int NW, bool CONV = false, int BM = BM_DEFAULT, int NWR = 2, bool KS = false>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     // either way 64-72 KiB, i.e. two workgroups per CU (a third stage at 96 KiB measured slower: one
     // workgroup per CU leaves the epilogue and the ramp-up uncovered).
     // (A 256 x 128 tile -- one 144-KiB workgroup per CU, 25 % fewer L2 -> LDS bytes per flop -- measured slower on every shape
-    // of the two transformers, as did a 96 x 64 tile inside the pipeline: DESIGN.md 3.3.)
+    // of the two transformers, as did a 96 x 64 tile inside the pipeline: DESIGN.md 3.4, DESIGN_HISTORY.md.)
     constexpr int NSTAGE = (BW == 64 || BM == 96) ? 3 : 2;
     constexpr int DIST = NSTAGE - 1;  // prefetch distance in K-tiles
     // [stage][W | A], then 2 KiB of exchange space for the LayerNorm statistics (ONE shared array: a second __shared__ object
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
 // 256 x 256 tile, 8 waves (2 along the weight rows x 4 along the activation rows: a wave owns 128 x 64 = 8 x 4 MFMA tiles, 128
 // accumulator registers), one workgroup per CU, for the two big LayerNorm-folded projections of a backbone block (the fused
 // Q|K|V^T projection and FF1 + GEGLU).  Why a second kernel: the 128-row tiles above move 768 B of LDS fragments per MFMA (wave
-// tile 32 x 64) and their K loop runs at the rate at which a CU's LDS can be filled while it is being read; a
+// tile 32 x 64) and their K loop runs at the rate at which a CU's LDS can be filled while it is being read (DESIGN_HISTORY.md); a
 // 128 x 64 wave tile needs 384 B per MFMA -- but with only two waves per SIMD nothing hides a fragment read or a DMA round
 // trip unless the loop does it itself.  So the K-tile (BK = 64) is cut into four phases of 16 MFMAs (one 64 x 32 quadrant of
 // the wave tile x K = 64), and the loop is pipelined at FRAGMENT granularity:

@@ -27,7 +27,7 @@ BF16 = torch.bfloat16
 
 def prepare_ln_linear(L, key, W, bias, gamma, beta, fold, to_weight, to_f32, q_rows=0, q_scale=1.0):
     """A Linear fed by a LayerNorm, prepared for KernelEngine._ln_gemm.  fold (bf16 mode): the LayerNorm is folded into the
-    GEMM (ops.fold_layernorm; DESIGN 3.3): L[key] = bf16(W * gamma), L[key_b] = bias + W . beta, L[key_cs] = column sums.
+    GEMM (ops.fold_layernorm; DESIGN 3.4): L[key] = bf16(W * gamma), L[key_b] = bias + W . beta, L[key_cs] = column sums.
     Otherwise (fp32 mode): plain weights + the LayerNorm's own parameters for the stand-alone kernel.
     q_rows / q_scale (fold only): the first q_rows output rows are an attention's query projection and carry
     softmax_scale * log2(e) -- multiplied in BEFORE the bf16 rounding of the weights, so q is stored as bf16(c q), one rounding as

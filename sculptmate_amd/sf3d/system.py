@@ -353,7 +353,7 @@ class SF3D(KernelEngine):
         pre = self.precision == "bf16"   # query projections carry softmax_scale * log2(e) (sculpt_attention_bf16_prescaled)
 
         def ln_linear(L, key, W, bias, gamma, beta, q_rows=0, head_dim=1):
-            """A Linear fed by a LayerNorm: folded into the GEMM in bf16 mode (engine.prepare_ln_linear, DESIGN 3.3), with the
+            """A Linear fed by a LayerNorm: folded into the GEMM in bf16 mode (engine.prepare_ln_linear, DESIGN 3.4), with the
             first q_rows output rows (an attention's queries) carrying softmax_scale * log2(e)."""
             prepare_ln_linear(L, key, W, bias, torch.as_tensor(gamma), torch.as_tensor(beta), pre, lambda x: wt(x, dev),
                               lambda x: _f32(x, dev), q_rows if pre else 0, 1.4426950408889634 / math.sqrt(head_dim))

@@ -244,7 +244,7 @@ class TSR(KernelEngine):
         self.mesh_sink = None  # callable(verts, faces, colors, name); default: bpy if importable
         # forward(): images per transformer pass.  1 (default): image by image -- forward([a, b]) is the stack of the single-image
         # passes bit for bit.  > 1 (opt in, like run(batch=...)): the reference's batched pass (system.py:82-115), whose launches
-        # take other tile shapes, so the scene codes differ from the single-image pass by bf16 rounding
+        # take other tile shapes, so the scene codes differ from the single-image pass by bf16 rounding (DESIGN_HISTORY.md)
         self.max_batch = 1
         self._w = None
         self._pos_cache = {}
@@ -969,7 +969,7 @@ class TSR(KernelEngine):
         batch = 1 (default): image by image with the tokenizer look-ahead -- the meshes are bit-identical to single-image calls.
         batch > 1: the transformer runs `batch` images per pass like the reference's batched forward (system.py:82-115; 3.9
         instead of 5.3 ms per image at 4), the meshes are extracted and copied out one by one under the next pass; the scene
-        codes then differ from the single-image pass by bf16 rounding, i.e. so do the meshes."""
+        codes then differ from the single-image pass by bf16 rounding (DESIGN_HISTORY.md), i.e. so do the meshes."""
         images = _as_image_list(images)
         if batch <= 1 or len(images) < 2:
             return [p.result() for p in self.run_pipelined(images, mc_resolution, threshold, enable_texture)]

@@ -136,7 +136,7 @@ print("rccl one-rank exchange ok", tuple(v.shape), tuple(f.shape))
 
 
 def test_cu_masked_stream_runs_the_kernels_and_refuses_bad_ranges(cuda):
-    """sculpt_stream_create_cu_mask (the CU-partition experiment's entry point, DESIGN 3.3): a stream restricted to a quarter of
+    """sculpt_stream_create_cu_mask (the CU-partition experiment's entry point, DESIGN 3.4): a stream restricted to a quarter of
     the CUs runs the density grid + marching cubes to the same bits as the default stream; out-of-range masks are refused."""
     import ctypes
 
