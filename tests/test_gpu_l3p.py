@@ -405,3 +405,61 @@ def test_fp16l2_through_the_pipelined_entry(monkeypatch):
         got = m2.forward_tokens(tok)
         want = m3([imgs[0]], device=_dev())
     assert m2.range_fallbacks == 1 and torch.equal(got, want)
+
+
+def test_reloading_weights_drops_the_range_twin_and_the_filter_calibration():
+    """state derived from the weights -- the bf16l3 twin an fp16l2 model falls back to, the two-pass grid's margin -- must
+    not survive load_state_dict: after a reload the fallback has to answer with the NEW weights' scene code."""
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import SMALL_CFG
+    from sculptmate_amd.tsr.system import TSR
+
+    key = "backbone.transformer_blocks.1.norm3.weight"
+    img = synth.composite_rgb(synth.image_rgba(seed=11, size=SMALL_CFG["cond_image_size"]))
+    sds = []
+    for seed in (7, 8):
+        sd = dict(synth.tsr_state(seed, SMALL_CFG))
+        sd[key] = sd[key] * 3e5          # leaves the fp16 range: every forward goes through the twin
+        sds.append(sd)
+    m = TSR(SMALL_CFG, pos_embed_mode="size", precision="fp16l2")
+    m.load_state_dict(sds[0])
+    m.to(_dev())
+    with torch.no_grad():
+        a = m([img], device=_dev())
+        assert m.range_fallbacks == 1 and m._range_twin is not None
+        m.filter_info.update(margin=0.123, usable=False)
+        m.load_state_dict(sds[1])
+        assert m._range_twin is None and m.filter_info["margin"] is None and m.filter_info["usable"]
+        b = m([img], device=_dev())
+        ref = TSR(SMALL_CFG, pos_embed_mode="size", precision="bf16l3")
+        ref.load_state_dict(sds[1])
+        ref.to(_dev())
+        want = ref([img], device=_dev())
+    assert m.range_fallbacks == 2 and torch.equal(b, want) and not torch.equal(a, b)
+
+
+def test_bf16l3_falls_back_to_the_splitting_gemm_for_widths_the_limb_gemm_cannot_tile():
+    """limbs-once needs Linear widths that are multiples of 128 (gemm_l3p's tiles); a model with another width (here the
+    image tokenizer's MLP: 320; the hidden sizes are multiples of 256 for the LayerNorm kernel anyway) runs "bf16l3" on the
+    splitting GEMM as before (l3p False), and "fp16l2" -- which exists on limbs only -- says so."""
+    import pytest
+
+    from sculptmate_amd import synth
+    from sculptmate_amd.tsr.spec import make_cfg
+    from sculptmate_amd.tsr.system import TSR
+
+    cfg = make_cfg(vit_hidden=256, vit_layers=1, vit_heads=4, vit_mlp=320, channels=256, plane_size=8, heads=4, head_dim=64, layers=1,
+                   cond_image_size=64)
+    sd = synth.tsr_state(5, cfg)
+    m = TSR(cfg, pos_embed_mode="size", precision="bf16l3")
+    m.load_state_dict(sd)
+    m.to(_dev())
+    assert m.l3p is False
+    img = synth.composite_rgb(synth.image_rgba(seed=3, size=64))
+    with torch.no_grad():
+        code = m([img], device=_dev())
+    assert bool(torch.isfinite(code).all())
+    m2 = TSR(cfg, pos_embed_mode="size", precision="fp16l2")
+    m2.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        m2.to(_dev())
