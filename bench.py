@@ -106,18 +106,25 @@ def boundary_rate(model, imgs_host, steps):
         nbytes = meshes[-1].vertices.nbytes + meshes[-1].faces.nbytes
         del meshes
     dt_run = time.perf_counter() - t0
-    # the same entry with batched transformer passes (TSR.run(images, batch=4)): meshes differ from the one-image pass by bf16 rounding
-    batched4 = None
+    # the same entry one image per transformer pass (round 5's default: tokenizer look-ahead only).  Since round 6 TSR.run stacks
+    # four images per pass by default in the bf16 mode: every GEMM keeps the single-image tile form, so the meshes are those of
+    # one-at-a-time calls bit for bit (checked below on the first list)
+    serial = None
     try:
-        model.run(lists[0], MC_RES, THRESHOLD, batch=4)
+        ref = model.run(lists[0][:4], MC_RES, THRESHOLD, batch=1)
+        got = model.run(lists[0][:4], MC_RES, THRESHOLD)
+        same = all(np.array_equal(a.vertices.view(np.uint32), b.vertices.view(np.uint32)) and np.array_equal(a.faces, b.faces)
+                   for a, b in zip(ref, got))
+        del ref, got
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nb = 0
         for lst in lists:
-            nb += len(model.run(lst, MC_RES, THRESHOLD, batch=4))
-        batched4 = {"entry": "TSR.run(images, batch=4): four images per transformer pass", "meshes_per_s": nb / (time.perf_counter() - t0)}
+            nb += len(model.run(lst, MC_RES, THRESHOLD, batch=1))
+        serial = {"entry": "TSR.run(images, batch=1): one image per transformer pass, tokenizer look-ahead",
+                  "meshes_per_s": nb / (time.perf_counter() - t0), "default_run_meshes_identical_to_these": bool(same)}
     except Exception as e:
-        batched4 = {"error": "%s: %s" % (type(e).__name__, e)}
+        serial = {"error": "%s: %s" % (type(e).__name__, e)}
     # the hand-rolled loop: one run_async per image, mesh i collected while image i + 1 runs, no tokenizer look-ahead
     prev = model.run_async(imgs_host[0], MC_RES, THRESHOLD)
     for i in range(1, 5):
@@ -142,7 +149,8 @@ def boundary_rate(model, imgs_host, steps):
         lat.append((time.perf_counter() - t1) * 1e3)
     return {"entry": "TSR.run([host fp32 HWC 512x512 images]) -> host (pinned) vertices + int64 faces per image; lists of %d" % chunk,
             "meshes_per_s": n_run / dt_run, "ms_per_step": dt_run / n_run * 1e3, "images_timed": n_run,
-            "batched4": batched4,
+            "images_per_transformer_pass": int(getattr(model, "RUN_BATCH", 1)) if model.precision == "bf16" else 1,
+            "one_image_per_pass": serial,
             "run_async_loop": {"entry": "TSR.run_async(image) per image, mesh i collected under image i + 1, no tokenizer look-ahead",
                                "meshes_per_s": steps / dt, "ms_per_step": dt / steps * 1e3},
             "latency_ms_single_image": float(np.median(lat)),
@@ -290,10 +298,14 @@ def batched_rates(model, imgs, steps):
     B x 1025 stacked token rows, attention over B x heads) + extract_meshes of the B scene codes.  `value` stays the strict
     one-image step; this is the throughput form."""
     res = {"entry": "TSR.forward([B images resident in HBM]) as one batched pass + TSR.extract_meshes(codes, 256); forward_ms = HIP "
-                    "events around forward() (tokenizer + backbone + upsampler of the B images)"}
-    keep = model.max_batch
-    for B in (2, 4, 8):
+                    "events around forward() (tokenizer + backbone + upsampler of the B images).  B2 / B4 / B8: every GEMM keeps the "
+                    "tile form of the single-image pass (TSR.batch_exact, the default since round 6): scene codes bit-identical to "
+                    "one image at a time.  B4_fastest_tiles: batch_exact = False, the tile forms that are fastest for the stacked "
+                    "rows (rounds 4-5: scene codes 2.7e-3 from the single-image ones)"}
+    keep, keep_exact = model.max_batch, model.batch_exact
+    for B, exact in ((2, True), (4, True), (8, True), (4, False)):
         model.max_batch = B   # forward() batches only when asked to (default 1: image by image)
+        model.batch_exact = exact
         group = [imgs[i % len(imgs)] for i in range(B)]
         n = max(2, min(steps, 24) // B + 1)
         for _ in range(2):
@@ -309,11 +321,11 @@ def batched_rates(model, imgs, steps):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         fwd = float(np.median([a.elapsed_time(b) for a, b in ev]))
-        res["B%d" % B] = {"ms_per_image": dt / (n * B) * 1e3, "meshes_per_s": n * B / dt, "transformer_ms_per_image": fwd / B,
+        res["B%d" % B if exact else "B%d_fastest_tiles" % B] = {"ms_per_image": dt / (n * B) * 1e3, "meshes_per_s": n * B / dt, "transformer_ms_per_image": fwd / B,
                           "forward_ms": fwd, "passes_timed": n,
                           # 2.96 TFLOP per image over the forward time: the transformer's fraction of the bf16 peak
                           "transformer_tflops": 2.96 * B / (fwd * 1e-3), "transformer_frac": 2.96 * B / (fwd * 1e-3) / PEAK_BF16_MFMA_TFLOPS}
-    model.max_batch = keep
+    model.max_batch, model.batch_exact = keep, keep_exact
     torch.cuda.empty_cache()
     return res
 

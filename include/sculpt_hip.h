@@ -310,6 +310,10 @@ typedef struct sculpt_ln_fold {
     float eps;
     float *stats_out;      /* [N/64][stats_ld][2] or NULL */
     int stats_ld;          /* rows per slice plane of stats_in / stats_out, >= M */
+    int rows_per_image;    /* 0, or the rows of ONE image when A stacks the token rows of several (a batched pass): the tile form
+                            * is then the one a single image takes (on a taller grid), so that every output and statistic is
+                            * accumulated in the single-image order -- the batched pass gives each image the bits of its own pass.
+                            * The statistics pointers may all be NULL when only this hint is wanted.  (ABI 4) */
 } sculpt_ln_fold_t;
 int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias,
                         const float *residual, int ldr, float *out_f32, uint16_t *out_bf16, int ldo,

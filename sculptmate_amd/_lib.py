@@ -173,7 +173,8 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 class LnFold(ctypes.Structure):
     """sculpt_ln_fold_t (include/sculpt_hip.h)."""
-    _fields_ = [("stats_in", _vp), ("slots_in", _i), ("colsum", _vp), ("eps", _f), ("stats_out", _vp), ("stats_ld", _i)]
+    _fields_ = [("stats_in", _vp), ("slots_in", _i), ("colsum", _vp), ("eps", _f), ("stats_out", _vp), ("stats_ld", _i),
+                ("rows_per_image", _i)]
 
 
 MC_FACES_I64 = 1

@@ -1142,6 +1142,12 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
         g.stats_out = ln->stats_out;
     }
     const int mt = cdiv(M, BM_DEFAULT);
+    // The tile FORM is chosen for Mh rows: M itself, or -- a batched pass that stacks the token rows of several images and says so
+    // (ln->rows_per_image) -- the rows of one image: the pass then runs the kernels of the single-image pass on taller grids, so
+    // that every output AND every slice statistic is accumulated in the single-image order (the k-split pairs of the 192 x 64
+    // tiles, the half-slice merges of the 64-row weight tiles): scene codes bit-identical to one image at a time.
+    const int Mh = (ln && ln->rows_per_image > 0 && ln->rows_per_image < M) ? ln->rows_per_image : M;
+    const int mth = cdiv(Mh, BM_DEFAULT);
     hipStream_t st = as_stream(stream);
     // Grouped tile order (GemmArgs::gm): group height ~ sqrt(R * weight rows per tile / activation rows per tile) with R the
     // workgroups an XCD keeps resident (32 CUs x 1 or 2), as a power of two; launches whose tiles are all resident at once (or
@@ -1167,22 +1173,22 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
         // no256: never, default: by the rules below, 256: whenever legal (tests, A/B)
         const int p256 = form_has(FORM, "no256") ? 0 : (form_has(FORM, "256") ? 2 : 1);
         const int nout = epilogue == SCULPT_EPI_GEGLU ? 128 : 256;
-        const long tiles = (long)(N / nout) * cdiv(M, 256), tiles192 = (long)(N / nout) * cdiv(M, 192);
-        const bool pays = tiles >= 2L * num_cus() && (epilogue == SCULPT_EPI_GEGLU || N >= 4096) && (M % 256 == 0 || M % 256 >= 128);
+        const long tiles = (long)(N / nout) * cdiv(Mh, 256), tiles192 = (long)(N / nout) * cdiv(Mh, 192);
+        const bool pays = tiles >= 2L * num_cus() && (epilogue == SCULPT_EPI_GEGLU || N >= 4096) && (Mh % 256 == 0 || Mh % 256 >= 128);
         // 192 x 256 tiles (round 4, tools/gemm_order_ab.py, interleaved in one process): wherever 3072-row multiples give them at
         // least 3/4 of the CUs a tile -- B = 1: FF1 512 tiles 58.8 vs 61.4 us on the 128-row tiles, fused Q|K|V^T 192 tiles 31.3 vs
         // 35.0; a 4-image batch: Q|K|V^T 93.8 vs 101.0, cross-attention q 33.2 vs 36.6 -- except where the 256-row tile has four
         // rounds of its own (FF1 of a 4-image batch: 211.9 vs 225.7 us).  no192 / 192 force never / always.
         const int f192 = form_has(FORM, "no192") ? 0 : (form_has(FORM, "192") ? 1 : -1);
-        const bool pays192 = M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus());
+        const bool pays192 = Mh % 192 == 0 && M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus());
         // the residual form on 192 x 256 tiles (round 4): every CU gets a tile where the 128-row tiles need three -- the N = 1024
         // projections of a batched pass (to_out of both attentions, FF2): M = 12288 -> 4 x 64 = 256 tiles
         {
             const int fres = form_has(FORM, "nores") ? 0 : (form_has(FORM, "res") ? 1 : -1);   // never / whenever legal (A/B, tests)
             const bool legal = p256 && residual && out_f32 && epilogue == SCULPT_EPI_NONE && n_store == N && n_split == N && !out_bf16_t &&
                                N % 256 == 0 && K >= 2 * BK && (long)N * ldw * 2 < 0xffff0000L && (long)M * lda * 2 < 0xffff0000L;
-            const long t192 = (long)(N / 256) * cdiv(M, 192);
-            const bool pays_res = M % 192 == 0 && t192 * 4 >= 3L * num_cus() && t192 * 2 <= 5L * num_cus();
+            const long t192 = (long)(N / 256) * cdiv(Mh, 192);
+            const bool pays_res = Mh % 192 == 0 && M % 192 == 0 && t192 * 4 >= 3L * num_cus() && t192 * 2 <= 5L * num_cus();
             if (legal && (fres >= 0 ? fres != 0 : pays_res)) {
                 const dim3 grid(N / 256, cdiv(M, 192));
                 g.gm = group_rows(256, 192, 1, (long)grid.x * grid.y, grid.y);
@@ -1225,7 +1231,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
     // the two transformers except the deep-K 64-row-tile case (K = 4096, N = 1024: -4 %), which keeps 4 waves
     // ... unless the launch has fewer workgroups than CUs (the ViT's 1025 x 768 x 3072): then 8 waves are the only
     // latency hiding a CU gets
-    const bool underfilled = (long)(N / 64) * mt < (long)num_cus();
+    const bool underfilled = (long)(N / 64) * mth < (long)num_cus();
     const bool nw8 = true, nw8s = K < 2048 || underfilled;
     if (epilogue == SCULPT_EPI_GEGLU) {
         SC_REQUIRE(N % 64 == 0, "gemm_bf16(GEGLU): N=%d must be a multiple of 64", N);
@@ -1238,7 +1244,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
         // fill the chip: with fewer than ~1.5 tiles per CU use the 64-row weight tile
         // (128 x 128 tiles for the N = 1024 launches -- 192 workgroups, a third fewer L2 -> LDS bytes -- measured the same at
         // K = 1024 and 10 % slower at K = 4096: one workgroup per CU pulls ~35 GB/s through its LDS-DMA queue, two pull ~57)
-        const bool small = (long)(N / 128) * mt < (long)num_cus() * 3 / 2;
+        const bool small = (long)(N / 128) * mth < (long)num_cus() * 3 / 2;
         g.gm = small ? group_rows(64, BM_DEFAULT, 2, (long)(N / 64) * mt, mt) : group_rows(128, BM_DEFAULT, 2, (long)(N / 128) * mt, mt);
         if (epilogue == SCULPT_EPI_GELU) {
             if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_GELU, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
@@ -1261,8 +1267,8 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
             // fewer bytes again -- was built in round 5, measured bit-identical and NOT faster (FF2 43.6 against 42.6 us, to_out
             // 18.3 / 18.1): below ~540 MB per launch the bytes stop being the time.  Removed in round 6, DESIGN_HISTORY.md.)
             const int f192r = form_has(FORM, "nobm192") ? 0 : (form_has(FORM, "bm192") ? 1 : -1);
-            const long t192r = (long)(N / 64) * (M / 192);
-            const bool one_round = M % 192 == 0 && t192r <= (long)num_cus() && t192r * 4 >= 3L * num_cus();
+            const long t192r = (long)(N / 64) * (Mh / 192);
+            const bool one_round = Mh % 192 == 0 && M % 192 == 0 && t192r <= (long)num_cus() && t192r * 4 >= 3L * num_cus();
             if (f192r >= 0 ? (f192r != 0 && M % 192 == 0) : one_round) {
                 g.gm = 0;
                 // k-split pairs (see the kernel): FF2 + residual 41.6 -> 38.4 us, plain K = 4096 37.5 -> 33.9, K = 1024 -0.3 us;
@@ -1272,7 +1278,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                 else
                     hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 192>), dim3(N / 64, M / 192), dim3(512), 0, st, g);
             } else
-            if (small && underfilled && (long)(N / 64) * cdiv(M, 64) <= 2L * num_cus())
+            if (small && underfilled && (long)(N / 64) * cdiv(Mh, 64) <= 2L * num_cus())
                 hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8, false, 64>), dim3(N / 64, cdiv(M, 64)), dim3(512), 0, st, g);
             else if (small && nw8s) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 8>), dim3(N / 64, mt), dim3(512), 0, st, g);
             else if (small) hipLaunchKernelGGL((gemm_bf16_kernel<SCULPT_EPI_NONE, 64, 4>), dim3(N / 64, mt), dim3(256), 0, st, g);

@@ -4,6 +4,7 @@ torch is plumbing here: it owns HBM allocations and the current HIP stream; ever
 passes raw device pointers + sizes into libsculpt_hip.so.  No function has a CPU path.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -411,12 +412,15 @@ def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None
     if out_f32 is not None and out_bf16 is not None:
         assert out_f32.stride(0) == out_bf16.stride(0)
     ln = None
+    if _TILE_ROWS[0] and ln_stats is None and stats_out is None:
+        ln = _lib.LnFold(None, 0, None, float(ln_eps), None, 0, int(_TILE_ROWS[0]))
     if ln_stats is not None or stats_out is not None:
         # statistics arrays are slice-major: [K/64 or N/64][rows][2]
         # (a view of a band of rows, [:, r0:r1], keeps the plane stride of the whole array: ld comes from the stride)
         ref = ln_stats if ln_stats is not None else stats_out
         ld = ref.stride(0) // 2
-        ln = _lib.LnFold(_ptr(ln_stats), K // LN_SLOT if ln_stats is not None else 0, _ptr(ln_colsum), float(ln_eps), _ptr(stats_out), ld)
+        ln = _lib.LnFold(_ptr(ln_stats), K // LN_SLOT if ln_stats is not None else 0, _ptr(ln_colsum), float(ln_eps), _ptr(stats_out), ld,
+                         int(_TILE_ROWS[0]))
         if ln_stats is not None:
             assert ln_stats.dtype == torch.float32 and ln_stats.shape[0] >= K // LN_SLOT and ln_stats.stride(0) == 2 * ld and ln_colsum is not None
             assert ln_stats.shape[1] >= M and ln_stats.stride(1) == 2
@@ -427,6 +431,36 @@ def gemm(A, W, bias=None, residual=None, out_f32=None, out_bf16=None, out_t=None
                                   residual.stride(0) if residual is not None else 0, _ptr(out_f32), _ptr(out_bf16),
                                   ldo, _ptr(out_t), out_t.stride(0) if out_t is not None else 0, int(n_split), 0, M, N, K,
                                   epilogue, ctypes.byref(ln) if ln is not None else None, _stream()))
+
+
+class _TileRows(threading.local):
+    def __init__(self):
+        self.v = 0
+
+    def __getitem__(self, i):
+        return self.v
+
+    def __setitem__(self, i, value):
+        self.v = value
+
+
+_TILE_ROWS = _TileRows()   # per thread: 0, or the rows of one image while a stacked pass is being issued
+
+
+class single_image_tiles:
+    """with ops.single_image_tiles(rows): every bf16 GEMM issued inside chooses its tile form as for `rows` activation rows
+    (sculpt_ln_fold_t::rows_per_image) -- a batched pass over stacked token rows then gives each image the bits of its own pass."""
+
+    def __init__(self, rows):
+        self.rows = int(rows)
+
+    def __enter__(self):
+        self.prev = _TILE_ROWS[0]
+        _TILE_ROWS[0] = self.rows
+
+    def __exit__(self, *exc):
+        _TILE_ROWS[0] = self.prev
+        return False
 
 
 def fold_layernorm(W, bias, gamma, beta):

@@ -242,10 +242,14 @@ class TSR(KernelEngine):
         self.isosurface_helper = None
         self.decoder = None  # ops.PackedMLP after to(device)
         self.mesh_sink = None  # callable(verts, faces, colors, name); default: bpy if importable
-        # forward(): images per transformer pass.  1 (default): image by image -- forward([a, b]) is the stack of the single-image
-        # passes bit for bit.  > 1 (opt in, like run(batch=...)): the reference's batched pass (system.py:82-115), whose launches
-        # take other tile shapes, so the scene codes differ from the single-image pass by bf16 rounding (DESIGN_HISTORY.md)
+        # forward(): images per transformer pass.  1 (default): image by image.  > 1: the reference's batched pass
+        # (system.py:82-115) over stacked token rows; in the bf16 mode it gives each image the bits of its single-image pass
+        # (every GEMM keeps the single-image tile form: encode_images), which is why run() batches by default there
         self.max_batch = 1
+        # A stacked pass keeps the tile forms of the single-image pass (True: each image gets the scene code of its own pass bit for
+        # bit; bf16 mode) or takes the forms that are fastest for the stacked rows (False: round 4-5 behaviour -- 0.7 ms per image
+        # faster at four images, scene codes 2.7e-3 from the single-image ones: bf16 roundings flip in the LayerNorm statistics)
+        self.batch_exact = True
         self._w = None
         self._pos_cache = {}
         self._buf = {}
@@ -594,12 +598,17 @@ class TSR(KernelEngine):
             self._self_attention(st1, self._w["blocks"][0])
             st = self._broadcast_state(st1, B)
             join.record(side)
-        ctx, _ = self.image_tokens(list(images))
-        main.wait_event(join)
+        # Every GEMM of the pass picks the tile form ONE image takes (ops.single_image_tiles): the stacked pass then accumulates every
+        # output and every LayerNorm slice statistic in the single-image order, and each image gets the scene code of its own pass,
+        # bit for bit (test_full_size_batched_forward_equals_single_image_passes) -- which is what lets TSR.run batch by default.
         T = self.cfg["image_tokenizer"]
         n_side = images[0].shape[0] // T["patch_size"]
-        st = self._run_blocks(st, ctx, first_self_attention_done=True, batch=B, ctx_tokens=n_side * n_side + 1)
-        return self._backbone_tail(st, B)
+        with ops.single_image_tiles(n_side * n_side + 1 if self.batch_exact else 0):
+            ctx, _ = self.image_tokens(list(images))
+        main.wait_event(join)
+        with ops.single_image_tiles(3 * self.cfg["tokenizer"]["plane_size"] ** 2 if self.batch_exact else 0):
+            st = self._run_blocks(st, ctx, first_self_attention_done=True, batch=B, ctx_tokens=n_side * n_side + 1)
+            return self._backbone_tail(st, B)
 
     def backbone_tokens(self, ctx: torch.Tensor):
         """Triplane1DTokenizer + Transformer1D for one image; ctx bf16 [Tc, cross_dim].
@@ -751,7 +760,8 @@ class TSR(KernelEngine):
                     codes.append(self.scene_code(outb)[None])
             else:   # the reference's batched pass (system.py:82-115)
                 _, outb = self.encode_images(group)
-                codes.append(self.scene_code(outb, len(group)))
+                with ops.single_image_tiles(n_tok if self.batch_exact else 0):   # the upsampler's GEMM too (encode_images)
+                    codes.append(self.scene_code(outb, len(group)))
         out = torch.cat(codes, 0) if len(codes) > 1 else codes[0]
         if self.precision == "fp16l2" and not bool(torch.isfinite(out).all()):
             # an fp16 limb overflowed (an activation of 65504 or more in magnitude) or the input was not finite: never hand on a
@@ -963,17 +973,23 @@ class TSR(KernelEngine):
             done.record(copy)
         return PendingMesh(host, done, tuple(leases))
 
-    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False, batch: int = 1) -> List[Mesh]:
-        """Headless entry point: images -> list of Mesh with host (NumPy) arrays.  With several images the device -> host
-        copy of mesh i overlaps the kernels of image i + 1 (run_async).
-        batch = 1 (default): image by image with the tokenizer look-ahead -- the meshes are bit-identical to single-image calls.
-        batch > 1: the transformer runs `batch` images per pass like the reference's batched forward (system.py:82-115; 3.9
-        instead of 5.3 ms per image at 4), the meshes are extracted and copied out one by one under the next pass; the scene
-        codes then differ from the single-image pass by bf16 rounding (DESIGN_HISTORY.md), i.e. so do the meshes."""
+    def run(self, images, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False, batch=None) -> List[Mesh]:
+        """Headless entry point: images -> list of Mesh with host (NumPy) arrays; the device -> host copy of mesh i overlaps the
+        kernels that follow it.
+        batch (images per transformer pass; None = the default): in the bf16 mode a stacked pass of several images gives each
+        image the scene code of its own single-image pass BIT FOR BIT (every GEMM keeps the single-image tile form,
+        ops.single_image_tiles), so several images run four per pass by default -- the reference's batched forward
+        (system.py:82-115), 3.5-3.9 instead of 5.2 ms of transformer per image -- and the meshes are those of one-at-a-time calls
+        (test_run_batches_by_default_and_returns_the_serial_meshes).  The limb modes default to one image per pass with the
+        tokenizer look-ahead (run_pipelined).  batch=1 forces that everywhere."""
         images = _as_image_list(images)
+        if batch is None:
+            batch = self.RUN_BATCH if (self.precision == "bf16" and len(images) >= 2) else 1
         if batch <= 1 or len(images) < 2:
             return [p.result() for p in self.run_pipelined(images, mc_resolution, threshold, enable_texture)]
         return [p.result() for p in self.run_batched(images, batch, mc_resolution, threshold, enable_texture)]
+
+    RUN_BATCH = 4   # images per transformer pass of TSR.run in the bf16 mode
 
     def run_batched(self, images, batch: int = 4, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
         """images (host or device) -> list of PendingMesh through batched forward passes of `batch` images each."""
