@@ -111,8 +111,8 @@ def boundary_rate(model, imgs_host, steps):
     # one-at-a-time calls bit for bit (checked below on the first list)
     serial = None
     try:
-        ref = model.run(lists[0][:4], MC_RES, THRESHOLD, batch=1)
-        got = model.run(lists[0][:4], MC_RES, THRESHOLD)
+        ref = model.run(lists[0][:9], MC_RES, THRESHOLD, batch=1)
+        got = model.run(lists[0][:9], MC_RES, THRESHOLD)     # a full stacked pass and a ragged one
         same = all(np.array_equal(a.vertices.view(np.uint32), b.vertices.view(np.uint32)) and np.array_equal(a.faces, b.faces)
                    for a, b in zip(ref, got))
         del ref, got

@@ -978,7 +978,7 @@ class TSR(KernelEngine):
         kernels that follow it.
         batch (images per transformer pass; None = the default): in the bf16 mode a stacked pass of several images gives each
         image the scene code of its own single-image pass BIT FOR BIT (every GEMM keeps the single-image tile form,
-        ops.single_image_tiles), so several images run four per pass by default -- the reference's batched forward
+        ops.single_image_tiles), so several images run RUN_BATCH = 8 per pass by default -- the reference's batched forward
         (system.py:82-115), 3.5-3.9 instead of 5.2 ms of transformer per image -- and the meshes are those of one-at-a-time calls
         (test_run_batches_by_default_and_returns_the_serial_meshes).  The limb modes default to one image per pass with the
         tokenizer look-ahead (run_pipelined).  batch=1 forces that everywhere."""
@@ -989,7 +989,7 @@ class TSR(KernelEngine):
             return [p.result() for p in self.run_pipelined(images, mc_resolution, threshold, enable_texture)]
         return [p.result() for p in self.run_batched(images, batch, mc_resolution, threshold, enable_texture)]
 
-    RUN_BATCH = 4   # images per transformer pass of TSR.run in the bf16 mode
+    RUN_BATCH = 8   # images per transformer pass of TSR.run in the bf16 mode (4: 139.7, 8: 143.5 meshes/s device to device)
 
     def run_batched(self, images, batch: int = 4, mc_resolution: int = 256, threshold: float = 25.0, enable_texture: bool = False):
         """images (host or device) -> list of PendingMesh through batched forward passes of `batch` images each."""

@@ -227,7 +227,7 @@ imgs = [synth.composite_rgb(synth.image_rgba(seed=100 + i)) for i in range(8)]
 with torch.no_grad():
     synth.calibrate_tsr_density_bias(m, sd, torch.from_numpy(imgs[0]).to(dev), threshold=25.0)
     def plain():       # the same 8 images through run_async with the tokenizer look-ahead, nothing written
-        t0 = time.perf_counter(); ms = m.run(imgs, 256, 25.0); return time.perf_counter() - t0, ms
+        t0 = time.perf_counter(); ms = m.run(imgs, 256, 25.0, batch=1); return time.perf_counter() - t0, ms
     def sharded(out, writers):
         t0 = time.perf_counter(); batch.run_sharded(m, imgs, 256, 25.0, out_dir=out, fmt="ply", keep=False, writers=writers)
         return time.perf_counter() - t0

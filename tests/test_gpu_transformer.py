@@ -617,7 +617,7 @@ def test_batch_of_images_equals_one_at_a_time(cuda):
 
 
 def test_run_batches_by_default_and_returns_the_serial_meshes(cuda):
-    """TSR.run on a list (the entry north_star names): in the bf16 mode it stacks RUN_BATCH = 4 images per transformer pass by
+    """TSR.run on a list (the entry north_star names): in the bf16 mode it stacks RUN_BATCH images per transformer pass by
     default -- each image gets the scene code of its own pass bit for bit, so the meshes are those of one-at-a-time calls -- over
     a list that is not a multiple of four; batch=1 is the tokenizer look-ahead path of round 5; the limb modes stay on it."""
     from sculptmate_amd import ops
@@ -626,6 +626,7 @@ def test_run_batches_by_default_and_returns_the_serial_meshes(cuda):
     m, sd = _small_model(cuda, seed=47)
     S = SMALL_CFG["cond_image_size"]
     imgs = [synth.composite_rgb(synth.image_rgba(seed=70 + i, size=S)) for i in range(6)]
+    m.RUN_BATCH = 4          # two passes over the six images: four, then a ragged one of two
     thr = float(ops.density_grid(m([imgs[0]], device=cuda)[0].contiguous(), m.decoder, 32).median())
     calls = []
     rb, rp = m.run_batched, m.run_pipelined
@@ -697,9 +698,9 @@ def test_tokenizer_lookahead_gives_the_serial_meshes(cuda):
         for g, i in zip(got, idx):
             assert np.array_equal(want[i][0], g.vertices) and np.array_equal(want[i][1], g.faces) and np.array_equal(want[i][2], g.vertex_colors), i
 
-    same(m.run(imgs, mc_resolution=32, threshold=thr, enable_texture=True), range(7))
+    same(m.run(imgs, mc_resolution=32, threshold=thr, enable_texture=True, batch=1), range(7))   # batch=1: the look-ahead path
     order = [5, 2, 6, 0, 3]
-    same(m.run([imgs[i] for i in order], mc_resolution=32, threshold=thr, enable_texture=True), order)
+    same(m.run([imgs[i] for i in order], mc_resolution=32, threshold=thr, enable_texture=True, batch=1), order)
     # serial calls between pipelined ones, and a scene code computed the serial way while tokens are in flight
     t3 = m.tokens_async(imgs[3])
     codes_serial = m([imgs[4]], device=cuda)
@@ -711,7 +712,8 @@ def test_tokenizer_lookahead_gives_the_serial_meshes(cuda):
     assert np.array_equal(mesh4.vertices.cpu().numpy(), want[4][0]) and np.array_equal(mesh4.faces.cpu().numpy(), want[4][1])
     # device-resident images take the same path
     dev_imgs = [torch.from_numpy(im).to(cuda) for im in imgs[:3]]
-    same(m.run(dev_imgs, mc_resolution=32, threshold=thr, enable_texture=True), range(3))
+    same(m.run(dev_imgs, mc_resolution=32, threshold=thr, enable_texture=True, batch=1), range(3))
+    same(m.run(dev_imgs, mc_resolution=32, threshold=thr, enable_texture=True), range(3))             # ... and the stacked default
 
 
 def test_run_async_pipeline_and_pinned_buffer_lifetime(cuda):
