@@ -221,8 +221,8 @@ int sculpt_grid_decode(const void *mlp_packed, int n_hidden_64, int R, int x_beg
 #define SCULPT_ERR_MC_WORKSPACE 14 /* more active cells than the workspace's record pool holds: repeat with a larger one (below) */
 
 /* Workspace: per-row arrays + 8 bytes per ACTIVE cell (a cell whose corner signs differ) in a record pool.
- * sculpt_mc_workspace_bytes sizes the pool for one active cell per 8 cells (a closed surface at 256^3 has ~1 per 17): 21 MB at
- * 256^3, 166 MB at 512^3; sculpt_mc_workspace_bytes_for for max_active_cells of them (<= 0: the default).  A count phase that runs
+ * sculpt_mc_workspace_bytes sizes the pool for one active cell per 8 cells (a closed surface at 256^3 has ~1 per 17): 23 MB at
+ * 256^3, 181 MB at 512^3; sculpt_mc_workspace_bytes_for for max_active_cells of them (<= 0: the default).  A count phase that runs
  * out of pool still returns the right totals, with SCULPT_ERR_MC_WORKSPACE and -- through sculpt_mc_count_read_ex -- the number
  * of active cells; the caller allocates sculpt_mc_workspace_bytes_for(.., that many) and repeats the count with
  * sculpt_mc_count_launch_for(.., max_active_cells = that many, ..).  (The emit phase after an overflow writes nothing.) */

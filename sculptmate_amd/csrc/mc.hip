@@ -16,13 +16,13 @@
 // Passes (each one thread per cell, 256 cells per workgroup, wave-level prefix scans):
 //   count : classify, per-block (ntri, nown) sums, data min/max
 //   scan  : exclusive scan of the block sums (single workgroup), totals
-//   verts : active cells only (one record per active cell from the count pass): owners write vertex positions
-//   faces : active cells only: every cell writes its triangles; the id of a vertex on edge e is the OWNER's vertex base + the
+//   emit  : active cells only (one record per active cell from the count pass), one workgroup per brick of rows: owners write
+//           vertex positions, every cell writes its triangles; the id of a vertex on edge e is the OWNER's vertex base + the
 //           rank of e among the owner's vertices, read from the owner's record (a neighbour cell at offset {0,-1}^3, found
-//           through the per-row active masks): no lattice-wide edge -> id map (round 6; it was int32 [R^3][4], 268 MB at 256^3)
+//           through the rows' chunk tables, in LDS): no lattice-wide edge -> id map (round 6; it was int32 [R^3][4], 268 MB at 256^3)
 // Workspace: per-row arrays (counts, offsets, 256-bit active masks) + 8 bytes per ACTIVE cell in a pool whose capacity the caller
 // chooses (sculpt_mc_workspace_bytes_for); a count pass that runs out of pool reports SCULPT_ERR_MC_WORKSPACE and the number of
-// active cells, and the caller repeats it with a larger workspace.  21 MB at 256^3 and 166 MB at 512^3 with the default pool
+// active cells, and the caller repeats it with a larger workspace.  23 MB at 256^3 and 181 MB at 512^3 with the default pool
 // (one active cell per 8 cells), where the dense records + map of round 5 took 403 MB and 3.2 GB.
 #include <float.h>
 #include <math.h>
@@ -465,7 +465,7 @@ struct CellRec;
 //     (vertex base of the owner's block) + (owned vertices of the earlier cells of the block: the owner's record) + (rank of the
 //      edge among the owner's own vertices, in first-appearance order of its triangle list).
 // The owner's record is the k-th of its block's, k = number of active cells before it in the row segment: one 16-byte entry of
-// the block's chunk table (RowChunk) and a popcount.  mc_faces_brick_kernel does all this on LDS copies of the rows around a
+// the block's chunk table (RowChunk) and a popcount.  mc_emit_brick_kernel does all this on LDS copies of the rows around a
 // brick; the function below is the same from global memory (owners in the previous row SEGMENT, the slab top plane).  The rank comes from two bits of the record for an interior owner on the Lewiner tables (it owns
 // only the vertices on edges 5, 6, 10 and the centre: LUT_ROWRANK), from a walk over its triangle list otherwise (cells on the
 // low faces of the volume, classic tables).
@@ -572,7 +572,7 @@ __device__ __forceinline__ unsigned rank_bits_to_w1(unsigned rk) { return ((rk &
 //      the active cells of the WHOLE brick packed onto consecutive lanes (a row segment has ~13 active cells on a
 //      typical surface: 1/20 of a workgroup; a brick ~200), corners read from LDS;
 //   4. per-row exclusive prefix of the counts (one wave per row) and the record stores, into a piece of the record pool the
-//      brick takes with one atomic add (the order of the pieces is irrelevant: rec_base[b] names each row's).
+//      brick takes with one atomic add (the order of the pieces is irrelevant: the row's chunk table names its piece).
 static constexpr int MC_TZ = 4, MC_TY = 4, MC_ROWS = MC_TZ * MC_TY;
 static constexpr int MC_SRC_LD = 260;  // floats per staged lattice row (257 used)
 
@@ -999,14 +999,14 @@ __device__ __forceinline__ int edge_vertex_id(const EdgeIds &E, const Grid &g, i
     return lattice_edge_vertex_id(E, g, axis, lx, ly, lz);
 }
 
-// The emit pass: vertices and triangles of the active cells, one workgroup per EMIT BRICK of MC_EZ x MC_EY rows x 64 cells
+// The emit pass: vertices and triangles of the active cells, one workgroup per EMIT BRICK of MC_EZ x MC_EY = 8 x 6 rows x 64 cells
 // (grid-stride; a brick without an active cell costs one look at its rows' chunk-table entries).
 //   * A cell writes the vertices it OWNS (owns_edge) at (vertex base of its block) + (owned vertices of the earlier cells of
 //     the block: its record) + rank, and its triangles at the same kind of offset.
 //   * The id of a vertex on an edge of cell (x, y, z) is the owner's base + the rank of the edge among the owner's vertices
 //     (lattice_edge_vertex_id); the owner is a cell at offset {0, -1} along each axis, i.e. in one of the (MC_EZ + 1) x
 //     (MC_EY + 1) rows around the brick.  The workgroup copies the second word of those rows' records -- all an interior
-//     owner's ids need -- into LDS once (coalesced; at most 45 rows x 64 cells), and a look-up is two LDS reads: no lattice-wide
+//     owner's ids need -- into LDS once (coalesced; 63 rows), and a look-up is two LDS reads: no lattice-wide
 //     edge -> id map (round 5: int32 [R^3][4], written and read with one divergent global access per vertex reference).
 //     Owners outside the copy (x - 1 of the brick's first column) or on a low face of the volume go through global memory.
 //   * 64 cells along x, not a whole 256-cell row segment: a surface lying flat along x fills a brick, and the kernel ends
@@ -1015,9 +1015,12 @@ __device__ __forceinline__ int edge_vertex_id(const EdgeIds &E, const Grid &g, i
 //     its tiling, each a divergent read.
 //   * The kernel is bound by the bricks in flight (every step of a brick waits on the one before: rows -> records -> cells),
 //     i.e. by its LDS and registers: 25 KiB and 80 registers a workgroup / lane, six workgroups per CU (38 KiB, 117
-//     registers, four per CU: 136 us instead of 124; 128 threads instead of 256 on the same LDS: 190 us).
+//     registers, four per CU: 136 us instead of 124 with 4 x 8-row bricks; 128 threads instead of 256 on the same LDS: 190 us;
+//     1536 / 2048 record words instead of 1024: 113 us instead of 105).
 // Volume reads: the 8 corners of every cell that owns a vertex, requested together.
-static constexpr int MC_EZ = 4, MC_EY = 8, MC_EX = 64;        // rows (z, y) and cells along x of an emit brick
+// rows (z, y) and cells along x of an emit brick.  (EZ, EY) with (EZ + 1)(EY + 1) <= 64, bench volume: (8, 6) 104-106 us, (15, 3)
+// 108, (7, 7) 112, (9, 5) 114, (6, 8) 117, (4, 8) 125, (12, 3) 125, (4, 11) 129, (8, 4) 137, (2, 8) 152, (4, 4) 169
+static constexpr int MC_EZ = 8, MC_EY = 6, MC_EX = 64;
 static constexpr int MC_EROWS = MC_EZ * MC_EY, MC_EHROWS = (MC_EZ + 1) * (MC_EY + 1);
 static constexpr int MC_EREC = 1024;                          // records (their w1) in LDS; a brick of a closed surface has 100-400 with
                                                               // the rows around it (more than this: look-ups through global memory)
