@@ -78,11 +78,16 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN (plain cast path of the guide is not available for raw bits)
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round to nearest even, a NaN stays a NaN: v_cvt_pk_bf16_f32.  (Until round 6 this was the integer form u + 0x7fff + ((u >> 16) & 1)
+// with a NaN test in front: ~8 instructions and, the test being a branch, a pair of exec-mask edits per value in an unrolled
+// epilogue -- gemm256_kernel's 96 conversions per lane were 105 s_and_saveexec / 91 s_nop, tools/gemm_timeline.py.  Same bits for
+// every number; a NaN keeps its sign and turns quiet either way.)
+typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sc_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const sc_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sc_bf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
 }  // namespace sculpt

@@ -98,7 +98,34 @@ struct GemmArgs {
     // tools/gemm_store_cost.py); the transposed (V^T) part of a column-split launch is staged transposed and written the same way
     // instead of as 2-byte scalars.  Set by the launcher when every tile is entirely token-major or entirely transposed.
     int stage;
+    // -DSCULPT_EXPERIMENTS builds only (tools/gemm_timeline.py): per workgroup 16 words -- s_memrealtime (100 MHz) at entry, first
+    // K-tile landed, K loop done, epilogue arithmetic done, exit; HW_ID; XCC_ID; [8..12] s_memtime (shader clock) at the same points.  nullptr in every product launch.
+    unsigned long long *stamps;
 };
+
+#ifdef SCULPT_EXPERIMENTS
+#define GEMM_STAMP(g, k)                                                                                                        \
+    do {                                                                                                                        \
+        if ((g).stamps && threadIdx.x == 0) {                                                                                   \
+            unsigned long long *sp_ = (g).stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;                          \
+            sp_[k] = __builtin_amdgcn_s_memrealtime();                                                                          \
+            sp_[8 + (k)] = __builtin_amdgcn_s_memtime();                                                                        \
+        }                                                                                                                       \
+    } while (0)
+#define GEMM_STAMP_IDS(g)                                                                                                       \
+    do {                                                                                                                        \
+        if ((g).stamps && threadIdx.x == 0) {                                                                                   \
+            unsigned long long *sp_ = (g).stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;                          \
+            sp_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                                 \
+            sp_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                                \
+        }                                                                                                                       \
+    } while (0)
+static unsigned long long *g_gemm_stamps = nullptr;
+extern "C" void sculpt_experiment_gemm_stamps(void *p) { g_gemm_stamps = static_cast<unsigned long long *>(p); }
+#else
+#define GEMM_STAMP(g, k) do { } while (0)
+#define GEMM_STAMP_IDS(g) do { } while (0)
+#endif
 
 // (n tile, m tile) of workgroup-linear index `lin` in a grid of gx weight tiles x gy activation-row tiles
 __device__ __forceinline__ void gemm_tile_of(const GemmArgs &g, int lin, int gx, int gy, int &nt, int &mt) {
@@ -158,6 +185,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
     int nt_, mt_;
     gemm_tile_of(g, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, nt_, mt_);
     const int n0 = nt_ * NOUT, m0 = mt_ * BM;
+    GEMM_STAMP(g, 0);
 
     // ---- staging addresses.  One wave instruction fills 8 tile rows (1 KiB).  Lane l of the
     // instruction that fills rows 8q..8q+7 writes LDS chunk (row = 8q + l/8, slot = l%8) and must
@@ -312,6 +340,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+#ifdef SCULPT_EXPERIMENTS
+        if (kt == 0) GEMM_STAMP(g, 1);
+#endif
         // every wave finished reading stage (kt-1)%NSTAGE == (kt+DIST)%NSTAGE before it passed the barrier
         if (kt + DIST < nk) STAGE((kt + DIST) % NSTAGE, kt + DIST);
         const unsigned char *wb = smem + buf * (WT + AT);
@@ -401,6 +432,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
         }
     }
 
+    GEMM_STAMP(g, 2);
     float ln_mean[TJ], ln_rstd[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) { ln_mean[j] = 0.f; ln_rstd[j] = 1.f; }
@@ -497,6 +529,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
                 }
         }
     }
+    GEMM_STAMP(g, 3);
     // phase 2: stores (and the slice statistics of the fp32 result)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -509,8 +542,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
                 const f32x4 o = acc[2 * ip][j];
                 if (g.out_bf16) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk.x = pack_bf16x2(o[0], o[1]);
+                    pk.y = pack_bf16x2(o[2], o[3]);
                     *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
                 }
                 if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
@@ -527,8 +560,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
                     if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
                     if (g.out_bf16) {
                         uint2 pk;
-                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        pk.x = pack_bf16x2(o[0], o[1]);
+                        pk.y = pack_bf16x2(o[2], o[3]);
                         *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
                     }
                 }
@@ -592,6 +625,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_kernel(GemmArgs g) {
             }
         }
     }
+    GEMM_STAMP(g, 4);
+    GEMM_STAMP_IDS(g);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -630,7 +665,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     constexpr int NU = 4 + AU;                 // DMA units per K-tile: 8 or 7
     constexpr int WT = BW * 128, AT = BM * 128;  // 32 KiB, 32 / 24 KiB
     constexpr int XCH = 2 * (WT + AT);           // two K-tile buffers
-    __shared__ __attribute__((aligned(16))) unsigned char smem[XCH + 2 * BM * 8];
+    constexpr int XBC = XCH + 2 * BM * 8;        // bias and column sums of the tile's 256 weight rows (2 x 1 KiB), see below
+    __shared__ __attribute__((aligned(16))) unsigned char smem[XBC + 2048];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / NWC, wc = wave % NWC;
@@ -638,6 +674,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     int nt_, mt_;
     gemm_tile_of(g, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, nt_, mt_);
     const int n0 = nt_ * NOUT, m0 = mt_ * BM;
+    GEMM_STAMP(g, 0);
 
     // staging: wave w fills rows 32 w .. 32 w + 31 of both operand tiles, 8 rows (1 KiB) per wave instruction; the LDS image is
     // lane-linear, the (row >> 1) & 7 chunk swizzle is applied to the per-lane SOURCE address and to the read address
@@ -676,6 +713,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     }
 
     const int fr = lane & 15, fq = lane >> 4;
+    // bias and LayerNorm column sums of the tile's weight rows -> LDS, now: loaded in the epilogue they were a chain of eight (GEGLU:
+    // four) dependent round trips to L2 per lane that nothing overlapped -- 3-4 us of a 6 us epilogue (tools/gemm_timeline.py).
+    // Order in LDS = the order the epilogue walks: plain, tile rows 0..255; GEGLU, the 128 value rows, then the 128 gate rows.
+    if (tid < 128) {
+        const float *srcv = tid < 64 ? (g.bias ? g.bias : g.zeros) : (g.ln_stats ? g.ln_colsum : g.zeros);
+        const int e = (tid & 63) * 4;
+        const int row = EPI == SCULPT_EPI_GEGLU ? (e < 128 ? n0 + e : g.N + n0 + e - 128) : n0 + e;
+        *reinterpret_cast<float4 *>(smem + XBC + (tid >> 6) * 1024 + e * 4) = *reinterpret_cast<const float4 *>(srcv + row);
+    }
     // LayerNorm fold: (mean, rstd) of the wave's 64 activation rows from the producer's slice statistics, BEFORE the K loop here
     // (the 16 float2 per lane the other kernel carries across its loop do not fit beside 128 accumulators); wr = 0 computes,
     // wr = 1 receives through LDS.  These plain loads make hipcc wait vmcnt(0), which also waits for the prologue's DMA: wanted.
@@ -748,6 +794,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    GEMM_STAMP(g, 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -822,6 +869,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
         if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
         ktile(kt, std::false_type{}, std::false_type{});
     }
+    GEMM_STAMP(g, 2);
 #undef G256_STAGE
 #undef G256_LDA
 #undef G256_LDB
@@ -840,15 +888,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
     // odd pieces (fq ^ 1): the 16 lanes then cover 32 distinct banks; the 16-byte read-out swaps the halves back for those rows.
     const int fqs = fq ^ (fr >> 3);
     const bool tileT = staged && EPI != SCULPT_EPI_GEGLU && g.out_t && n0 >= g.n_split;   // workgroup-uniform
-    const float *biasp = g.bias ? g.bias : g.zeros;
-    const float *csp = g.ln_stats ? g.ln_colsum : g.zeros;
+    const float4 *bias_s = reinterpret_cast<const float4 *>(smem + XBC), *cs_s = reinterpret_cast<const float4 *>(smem + XBC + 1024);
     auto f4 = [](const float4 &v, int r) -> float { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); };
     if (EPI == SCULPT_EPI_GEGLU) {
 #pragma unroll
         for (int ip = 0; ip < TI / 2; ++ip) {
             const int wv = n0 + (wr * (TI / 2) + ip) * 16 + fq * 4;  // value row; the gate row is N further
-            const float4 bv = *reinterpret_cast<const float4 *>(biasp + wv), bg = *reinterpret_cast<const float4 *>(biasp + g.N + wv);
-            const float4 cv = *reinterpret_cast<const float4 *>(csp + wv), cg = *reinterpret_cast<const float4 *>(csp + g.N + wv);
+            const int li = (wr * (TI / 2) + ip) * 16 + fq * 4;   // = wv - n0
+            const float4 bv = bias_s[li >> 2], bg = bias_s[(128 + li) >> 2], cv = cs_s[li >> 2], cg = cs_s[(128 + li) >> 2];
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int m = m0 + wc * WROWS + j * 16 + fr;
@@ -861,14 +908,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                 }
                 if (staged) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk.x = pack_bf16x2(o[0], o[1]);
+                    pk.y = pack_bf16x2(o[2], o[3]);
                     *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + ((wr * (TI / 2) + ip) * 16 + fqs * 4) * 2) = pk;
                 } else if (m < g.m_store) {
                     if (g.out_bf16) {
                         uint2 pk;
-                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        pk.x = pack_bf16x2(o[0], o[1]);
+                        pk.y = pack_bf16x2(o[2], o[3]);
                         *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + wv) = pk;
                     }
                     if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + wv) = make_float4(o[0], o[1], o[2], o[3]);
@@ -888,7 +935,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int n = n0 + wr * 128 + i * 16 + fq * 4;
-            const float4 b4 = *reinterpret_cast<const float4 *>(biasp + n), c4 = *reinterpret_cast<const float4 *>(csp + n);
+            const float4 b4 = bias_s[(n - n0) >> 2], c4 = cs_s[(n - n0) >> 2];
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -906,8 +953,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                 *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
                 if (g.out_bf16) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk.x = pack_bf16x2(o[0], o[1]);
+                    pk.y = pack_bf16x2(o[2], o[3]);
                     *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
                 }
             }
@@ -941,7 +988,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int n = n0 + wr * 128 + i * 16 + fq * 4;
-            const float4 b4 = *reinterpret_cast<const float4 *>(biasp + n), c4 = *reinterpret_cast<const float4 *>(csp + n);
+            const float4 b4 = bias_s[(n - n0) >> 2], c4 = cs_s[(n - n0) >> 2];
             const bool tpart = n >= g.n_split;  // wave-uniform per sub-tile (n_split is a multiple of 16)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
@@ -966,12 +1013,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                         const float a1 = odd ? g1 : o[1], b1 = odd ? o[3] : g1;   // ... and of my second
                         const int r0 = odd ? 2 : 0;
                         unsigned char *dst = smem + (wr * 128 + i * 16 + fq * 4 + r0) * TSB + (wc * WROWS + j * 16 + (fr & ~1)) * 2;
-                        *reinterpret_cast<uint32_t *>(dst) = (uint32_t)f32_to_bf16(a0) | ((uint32_t)f32_to_bf16(b0) << 16);
-                        *reinterpret_cast<uint32_t *>(dst + TSB) = (uint32_t)f32_to_bf16(a1) | ((uint32_t)f32_to_bf16(b1) << 16);
+                        *reinterpret_cast<uint32_t *>(dst) = pack_bf16x2(a0, b0);
+                        *reinterpret_cast<uint32_t *>(dst + TSB) = pack_bf16x2(a1, b1);
                     } else {
                         uint2 pk;
-                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        pk.x = pack_bf16x2(o[0], o[1]);
+                        pk.y = pack_bf16x2(o[2], o[3]);
                         *reinterpret_cast<uint2 *>(smem + (wc * WROWS + j * 16 + fr) * RSB + (wr * 128 + i * 16 + fqs * 4) * 2) = pk;
                     }
                     continue;
@@ -981,8 +1028,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
                     if (g.out_f32) *reinterpret_cast<float4 *>(g.out_f32 + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
                     if (g.out_bf16) {
                         uint2 pk;
-                        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                        pk.x = pack_bf16x2(o[0], o[1]);
+                        pk.y = pack_bf16x2(o[2], o[3]);
                         *reinterpret_cast<uint2 *>(g.out_bf16 + (long)m * g.ldo + n) = pk;
                     }
                 }
@@ -994,6 +1041,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             }
         }
     }
+    GEMM_STAMP(g, 3);
     if (!RES && staged) {
         // the staged tile -> HBM in whole rows: 16 bytes per lane, a row's 256 / 512 (transposed: 384 / 512) bytes contiguous
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1021,6 +1069,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
             }
         }
     }
+    GEMM_STAMP(g, 4);
+    GEMM_STAMP_IDS(g);
 }
 
 }  // namespace sculpt
@@ -1123,6 +1173,9 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                w_rows > (long)M ? 1 : 0, n_store, 0, 0, 0, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
     SC_REQUIRE(w_rows <= ZERO_FLOATS, "gemm_bf16: N=%d too large", N);
     g.m_store = M;
+#ifdef SCULPT_EXPERIMENTS
+    g.stamps = g_gemm_stamps;
+#endif
     g.zeros = reinterpret_cast<const float *>(zero_page());
     SC_REQUIRE(g.zeros, "gemm_bf16: could not allocate the zero page");
     SC_REQUIRE((!bias || ((uintptr_t)bias & 15) == 0) && (!ln || !ln->colsum || ((uintptr_t)ln->colsum & 15) == 0),

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             o[3] = (v[i][3] - mean) * rstd * gm.w + bt.w;
             if (y) {
                 uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                pk.x = pack_bf16x2(o[0], o[1]);
+                pk.y = pack_bf16x2(o[2], o[3]);
                 *reinterpret_cast<uint2 *>(y + (long)row * ldy + c) = pk;
             }
             if (yf) *reinterpret_cast<float4 *>(yf + (long)row * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void row_slice_stats_kernel(const float *__res
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v[i].x) | ((uint32_t)f32_to_bf16(v[i].y) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v[i].z) | ((uint32_t)f32_to_bf16(v[i].w) << 16);
+            pk.x = pack_bf16x2(v[i].x, v[i].y);
+            pk.y = pack_bf16x2(v[i].z, v[i].w);
             dst[i] = pk;
         }
     }
