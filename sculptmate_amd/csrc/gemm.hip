@@ -1052,8 +1052,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int c0 = 0; c0 < 256 * CPR; c0 += 512) {
                 const int c = c0 + tid, nl = c / CPR, mc = c - nl * CPR;
-                if (c < 256 * CPR && m0 + mc * 8 < g.m_store)   // (M is a multiple of 8 on this path: a piece is whole or absent)
-                    *reinterpret_cast<uint4 *>(ob + (long)nl * g.ldt + mc * 8) = *reinterpret_cast<const uint4 *>(smem + nl * TSB + mc * 16);
+                if (c < 256 * CPR && m0 + mc * 8 < g.m_store) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(smem + nl * TSB + mc * 16);
+                    if (m0 + mc * 8 + 8 <= g.m_store) {
+                        *reinterpret_cast<uint4 *>(ob + (long)nl * g.ldt + mc * 8) = v;
+                    } else {   // the ragged last piece of a row (M not a multiple of 8): its first M % 8 values, one by one
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 7; ++e)
+                            if (m0 + mc * 8 + e < g.m_store) ob[(long)nl * g.ldt + mc * 8 + e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+                    }
+                }
             }
         } else {
             constexpr int CPR = NOUT / 8;   // 16-byte pieces per tile row (16 / 32)
@@ -1233,7 +1242,11 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
         // 35.0; a 4-image batch: Q|K|V^T 93.8 vs 101.0, cross-attention q 33.2 vs 36.6 -- except where the 256-row tile has four
         // rounds of its own (FF1 of a 4-image batch: 211.9 vs 225.7 us).  no192 / 192 force never / always.
         const int f192 = form_has(FORM, "no192") ? 0 : (form_has(FORM, "192") ? 1 : -1);
-        const bool pays192 = Mh % 192 == 0 && M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus());
+        const bool pays192 = (Mh % 192 == 0 && M % 192 == 0 && K >= 1024 && tiles192 * 4 >= 3L * num_cus() && !(pays && tiles >= 4L * num_cus())) ||
+                             // ... and a wide launch whose rows leave the last 192-row tile at most 1/8 of the rows short: the cross-attention
+                             // K | V^T projection of all sixteen blocks (1025 x 32768 x 768: 62 us against 72 on the 128 x 128 tiles)
+                             (Mh == M && epilogue == SCULPT_EPI_NONE && N >= 8192 && K >= 512 && tiles192 >= 2L * num_cus() &&
+                              (long)cdiv(M, 192) * 192 - M <= M / 8);
         // the residual form on 192 x 256 tiles (round 4): every CU gets a tile where the 128-row tiles need three -- the N = 1024
         // projections of a batched pass (to_out of both attentions, FF2): M = 12288 -> 4 x 64 = 256 tiles
         {
@@ -1264,7 +1277,7 @@ extern "C" int sculpt_gemm_bf16_ln(const uint16_t *A, int lda, const uint16_t *W
                 // (out_bf16 must exist: the token-major tiles of a split launch are written through it unconditionally)
                 // nostage: direct stores from the accumulator layout (A/B)
                 g.stage = !form_has(FORM, "nostage") && !out_f32 && out_bf16 && (!out_bf16_t || split) &&
-                          (!split || (n_split % nout == 0 && M % 8 == 0 && ldt % 8 == 0 && ((uintptr_t)out_bf16_t & 15) == 0)) &&
+                          (!split || (n_split % nout == 0 && ldt % 8 == 0 && ((uintptr_t)out_bf16_t & 15) == 0)) &&
                           ldo % 8 == 0 && ((uintptr_t)out_bf16 & 15) == 0;
             }
 #define SCULPT_G256(E)                                                                                     \

@@ -307,7 +307,8 @@ def test_gemm_one_round_of_192_row_tiles_is_bit_identical(cuda, monkeypatch, M, 
 
 @pytest.mark.parametrize("M,K,N,epi,split,bm192", [(3072, 1024, 4096, 2, 0, 1), (3072, 1024, 3072, 0, 2048, 1), (12288, 1024, 1024, 0, 0, 1),
                                                      (3000, 256, 512, 0, 0, 1), (3000, 256, 512, 1, 0, 0), (2048, 128, 1024, 0, 512, 0),
-                                                     (1032, 768, 2304, 0, 1536, 0), (520, 128, 256, 2, 0, 1)])
+                                                     (1032, 768, 2304, 0, 1536, 0), (520, 128, 256, 2, 0, 1),
+                                                     (1025, 768, 4096, 0, 2048, 1), (203, 128, 512, 0, 256, 0)])   # M % 8 != 0: ragged V^T pieces
 def test_gemm256_staged_stores_equal_direct_stores(cuda, monkeypatch, M, K, N, epi, split, bm192):
     """gemm256_kernel's epilogue through LDS (whole rows, 16 bytes per lane; the V^T part staged transposed) against its direct
     stores from the accumulator layout: the same bits, ragged last row tiles, a column-sliced output buffer, several launches
