@@ -341,6 +341,31 @@ def test_gemm256_staged_stores_equal_direct_stores(cuda, monkeypatch, M, K, N, e
         assert torch.equal(dt, st) and (st[:, M:] == 5.0).all()
 
 
+def test_bf16_conversion_rounds_to_nearest_even_like_the_integer_rule(cuda):
+    """common.h f32_to_bf16 / pack_bf16x2 are v_cvt_pk_bf16_f32 since round 6.  Against the integer rule every kernel used before
+    (u + 0x7fff + ((u >> 16) & 1)) >> 16: the same bits for every number -- ties, denormals, the largest finite value rounding to
+    infinity, signed zeros, infinities; a NaN stays a NaN with its sign (its payload may differ)."""
+    from sculptmate_amd import ops
+
+    g = torch.Generator().manual_seed(77)
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 20,), generator=g, dtype=torch.int64).to(torch.int32)
+    special = torch.tensor([0x00000000, -0x80000000, 0x7f800000, -0x00800000, 0x7f7fffff, 0x7f7f8000, 0x7f7f7fff, 0x00000001, 0x00007fff,
+                            0x00008000, 0x00008001, 0x00018000, 0x00017fff, 0x3f808000, 0x3f818000, 0x3f807fff, 0x3f808001, 0x007fffff,
+                            0x00800000, 0x7fc00000, 0x7f800001, -0x00400000, 0x7fffffff], dtype=torch.int64).to(torch.int32)
+    ties = (torch.randint(0, 1 << 16, (4096,), generator=g, dtype=torch.int64) << 16 | 0x8000).to(torch.int32)   # exact ties, every exponent
+    u = torch.cat([bits, special, ties]).to(cuda)
+    x = u.view(torch.float32)
+    y = torch.empty(x.numel(), dtype=torch.int16, device=cuda)
+    ops.cast_bf16(x, y)
+    got = y.cpu().to(torch.int64) & 0xffff
+    uu = u.cpu().to(torch.int64) & 0xffffffff
+    want = ((uu + 0x7fff + ((uu >> 16) & 1)) >> 16) & 0xffff
+    nan = (uu & 0x7fffffff) > 0x7f800000
+    assert torch.equal(got[~nan], want[~nan])
+    assert nan.sum() > 1000 and (((got[nan] & 0x7fff) > 0x7f80).all()) and torch.equal(got[nan] >> 15, (uu[nan] >> 31) & 1)
+    assert torch.equal(got[~nan], (x.cpu().to(BF).view(torch.int16).to(torch.int64) & 0xffff)[~nan])   # = torch's own conversion
+
+
 def test_gemm_gelu_and_geglu_epilogues(cuda):
     from sculptmate_amd import _lib, ops
 
