@@ -90,4 +90,30 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
+// In-kernel timeline stamps of -DSCULPT_EXPERIMENTS builds (tools/gemm_timeline.py): `g` is a kernel's argument block with a member
+// `unsigned long long *stamps` (nullptr in every product launch); per workgroup 16 words -- s_memrealtime (100 MHz) at the stamped
+// points 0..4, HW_ID, XCC_ID, and at [8 + k] s_memtime (shader clock) of the same points.
+#ifdef SCULPT_EXPERIMENTS
+#define GEMM_STAMP(g, k)                                                                                                        \
+    do {                                                                                                                        \
+        if ((g).stamps && threadIdx.x == 0) {                                                                                   \
+            unsigned long long *sp_ = (g).stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;                          \
+            sp_[k] = __builtin_amdgcn_s_memrealtime();                                                                          \
+            sp_[8 + (k)] = __builtin_amdgcn_s_memtime();                                                                        \
+        }                                                                                                                       \
+    } while (0)
+#define GEMM_STAMP_IDS(g)                                                                                                       \
+    do {                                                                                                                        \
+        if ((g).stamps && threadIdx.x == 0) {                                                                                   \
+            unsigned long long *sp_ = (g).stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;                          \
+            sp_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                                 \
+            sp_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                                \
+        }                                                                                                                       \
+    } while (0)
+extern unsigned long long *g_gemm_stamps;   // gemm.hip; set by sculpt_experiment_gemm_stamps
+#else
+#define GEMM_STAMP(g, k) do { } while (0)
+#define GEMM_STAMP_IDS(g) do { } while (0)
+#endif
+
 }  // namespace sculpt

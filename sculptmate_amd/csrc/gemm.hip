@@ -104,27 +104,8 @@ struct GemmArgs {
 };
 
 #ifdef SCULPT_EXPERIMENTS
-#define GEMM_STAMP(g, k)                                                                                                        \
-    do {                                                                                                                        \
-        if ((g).stamps && threadIdx.x == 0) {                                                                                   \
-            unsigned long long *sp_ = (g).stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;                          \
-            sp_[k] = __builtin_amdgcn_s_memrealtime();                                                                          \
-            sp_[8 + (k)] = __builtin_amdgcn_s_memtime();                                                                        \
-        }                                                                                                                       \
-    } while (0)
-#define GEMM_STAMP_IDS(g)                                                                                                       \
-    do {                                                                                                                        \
-        if ((g).stamps && threadIdx.x == 0) {                                                                                   \
-            unsigned long long *sp_ = (g).stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;                          \
-            sp_[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                                                 \
-            sp_[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                                                \
-        }                                                                                                                       \
-    } while (0)
-static unsigned long long *g_gemm_stamps = nullptr;
+unsigned long long *g_gemm_stamps = nullptr;   // (declared in common.h with the GEMM_STAMP macros)
 extern "C" void sculpt_experiment_gemm_stamps(void *p) { g_gemm_stamps = static_cast<unsigned long long *>(p); }
-#else
-#define GEMM_STAMP(g, k) do { } while (0)
-#define GEMM_STAMP_IDS(g) do { } while (0)
 #endif
 
 // (n tile, m tile) of workgroup-linear index `lin` in a grid of gx weight tiles x gy activation-row tiles

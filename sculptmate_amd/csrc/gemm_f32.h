@@ -41,16 +41,29 @@ __device__ __forceinline__ int f32_tile_wrow(const GemmF32Args &g, int n0, int j
 template <int EPI, int JT = 2>
 __device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f32x16 (&acc)[2][JT], int n0, int m0, int wr, int wc,
                                                   int l31, int lh) {
+    // Every load of the epilogue -- the bias quads (they depend on (q4, i) only) and, sub-tile by sub-tile, the residual quads of
+    // this lane -- is issued BEFORE the first store of what it feeds: the output may be the residual updated in place, so hipcc
+    // keeps a load behind every earlier store, and vmcnt counts stores too -- written load / store / load / store (the form until
+    // round 6) this was eight dependent L2 round trips per sub-tile and lane under a saturated memory pipeline.
+    float4 bq[4][2];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = (EPI == SCULPT_EPI_GEGLU) ? (i ? g.N : 0) + n0 + wr * 32 + 8 * q4 + 4 * lh : n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
+            // (plain forms: a quad past N -- N is a multiple of 4: entirely in or out -- is never used; read a valid one instead)
+            bq[q4][i] = *reinterpret_cast<const float4 *>(g.bias + ((EPI == SCULPT_EPI_GEGLU || n < g.N) ? n : 0));
+        }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int m = m0 + wc * (32 * JT) + j * 32 + l31;
         if (m >= g.M) continue;
+        if (EPI == SCULPT_EPI_GEGLU) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {  // register quad: rows 8*q4 + 4*lh + {0..3}
-            if (EPI == SCULPT_EPI_GEGLU) {
+            for (int q4 = 0; q4 < 4; ++q4) {  // register quad: rows 8*q4 + 4*lh + {0..3}
                 // wave rows [wr*64, +32) = value group, [+32, +64) = gate group of output columns n0 + wr*32 ..
                 const int n = n0 + wr * 32 + 8 * q4 + 4 * lh;
-                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n), bg = *reinterpret_cast<const float4 *>(g.bias + g.N + n);
+                const float4 bv = bq[q4][0], bg = bq[q4][1];
                 const float bvs[4] = {bv.x, bv.y, bv.z, bv.w}, bgs[4] = {bg.x, bg.y, bg.z, bg.w};
                 float o[4];
 #pragma unroll
@@ -60,12 +73,25 @@ __device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f3
                     o[r] = v * gelu_erf_exact(gt);
                 }
                 *reinterpret_cast<float4 *>(g.out + (long)m * g.ldo + n) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
+            }
+        } else {
+            float4 rq[4][2];
+            if (g.residual) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int n = n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
+                        rq[q4][i] = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + (n < g.N ? n : 0));
+                    }
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int n = n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
                     if (n >= g.N) continue;  // N is a multiple of 4: a quad is entirely in or out
-                    const float4 b4 = *reinterpret_cast<const float4 *>(g.bias + n);
+                    const float4 b4 = bq[q4][i];
                     const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
                     float o[4];
 #pragma unroll
@@ -76,7 +102,7 @@ __device__ __forceinline__ void f32_tile_epilogue(const GemmF32Args &g, const f3
                         o[r] = v;
                     }
                     if (g.residual) {
-                        const float4 rs = *reinterpret_cast<const float4 *>(g.residual + (long)m * g.ldr + n);
+                        const float4 rs = rq[q4][i];
                         o[0] += rs.x; o[1] += rs.y; o[2] += rs.z; o[3] += rs.w;
                     }
                     const bool tpart = n >= g.n_split;

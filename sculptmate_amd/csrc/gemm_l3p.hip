@@ -53,6 +53,7 @@ struct GemmL3pArgs {
     // band of activation rows with every weight tile, or (n_major = 1, W the larger operand) a band of weight rows with every
     // activation tile; -1 = the natural order (A/B)
     int n_major;
+    unsigned long long *stamps;   // -DSCULPT_EXPERIMENTS builds (common.h GEMM_STAMP); nullptr otherwise
 };
 
 // The epilogue when the result leaves as limbs: a lane holds four consecutive output columns of one row = one 8-byte half of a
@@ -62,6 +63,16 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
                                                    int l31, int lh) {
     const GemmF32Args &g = a.g;
     const int out_blocks = (g.M + 31) >> 5;
+    // the bias quads of this lane (they depend on (q4, i) only), all before the first limb store: a load behind a store waits for
+    // it as well (f32_tile_epilogue, gemm_f32.h)
+    float4 bq[4][2];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = (EPI == SCULPT_EPI_GEGLU) ? (i ? g.N : 0) + n0 + wr * 32 + 8 * q4 + 4 * lh : n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
+            bq[q4][i] = *reinterpret_cast<const float4 *>(g.bias + n);
+        }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int m = m0 + wc * (32 * JT) + j * 32 + l31;   // rows >= M of the last block are pad rows: written, never read as results
@@ -70,7 +81,7 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
         for (int q4 = 0; q4 < 4; ++q4) {
             if (EPI == SCULPT_EPI_GEGLU) {
                 const int n = n0 + wr * 32 + 8 * q4 + 4 * lh;
-                const float4 bv = *reinterpret_cast<const float4 *>(g.bias + n), bg = *reinterpret_cast<const float4 *>(g.bias + g.N + n);
+                const float4 bv = bq[q4][0], bg = bq[q4][1];
                 const float bvs[4] = {bv.x, bv.y, bv.z, bv.w}, bgs[4] = {bg.x, bg.y, bg.z, bg.w};
                 float o[4];
 #pragma unroll
@@ -84,7 +95,7 @@ __device__ __forceinline__ void l3p_epilogue_limbs(const GemmL3pArgs &a, const f
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int n = n0 + wr * 64 + i * 32 + 8 * q4 + 4 * lh;
-                    const float4 b4 = *reinterpret_cast<const float4 *>(g.bias + n);
+                    const float4 b4 = bq[q4][i];
                     const float bs[4] = {b4.x, b4.y, b4.z, b4.w};
                     float o[4];
 #pragma unroll
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
         mt = a.n_major ? tile % gy : tile / gx;
     }
     const int n0 = nt * NOUT, m0 = mt * BM;
+    GEMM_STAMP(a, 0);
     const long kblk = (long)g.K * (64 * NL);   // bytes of one 32-row block: K / 8 chunks x NL limbs x 512
     // staging: wave w copies row block w of the stage and (when there are more blocks than waves) row block w + NW; blocks 0..3 are
     // the tile's weight rows (a GEGLU weight is stored with its row blocks already in the tile's value / gate order: 4 blocks per
@@ -189,6 +201,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+#ifdef SCULPT_EXPERIMENTS
+        if (kt == 0) GEMM_STAMP(a, 1);
+#endif
         // every wave finished reading stage (kt - 1) % NST == (kt + DIST) % NST before it passed the barrier
         if (kt + DIST < nk) L3P_STAGE((kt + DIST) % NST, kt + DIST);
         const unsigned char *sb = smem + (kt % NST) * STG;
@@ -224,8 +239,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_l3p_kernel(Gemm
         }
     }
 #undef L3P_STAGE
+    GEMM_STAMP(a, 2);
     if (a.out_lt) l3p_epilogue_limbs<EPI, JT>(a, acc, n0, m0, wr, wc, l31, lh);
     else f32_tile_epilogue<EPI, JT>(g, acc, n0, m0, wr, wc, l31, lh);
+    GEMM_STAMP(a, 3);
+    GEMM_STAMP(a, 4);
+    GEMM_STAMP_IDS(a);
 }
 
 // fp32 [R][K] (row stride ld) times `scale` (a power of two: exact) -> limb-tiled; one thread per (row of a block, k chunk): the 32
@@ -327,6 +346,10 @@ int sculpt_gemm_l3p(const void *A_lt, const void *W_lt, int format, float alpha,
     a.a_blocks = (M + 31) / 32;
     a.out_k8 = N / 8;
     a.out_fmt = out_format;
+    a.stamps = nullptr;
+#ifdef SCULPT_EXPERIMENTS
+    a.stamps = g_gemm_stamps;
+#endif
     hipStream_t st = as_stream(stream);
     const int gx = geglu ? N / 64 : N / 128;
     // XCD band order: measured equal to the natural order on every shape of the two transformers (tools/time_l3p.py; the operands

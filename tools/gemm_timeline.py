@@ -1,7 +1,7 @@
 """Where the time of one 192 x 256-tile GEMM launch goes, per workgroup and per CU (experiment builds only).
 
     SCULPT_EXTRA_HIPCC_FLAGS=-DSCULPT_EXPERIMENTS python -m sculptmate_amd.build
-    SCULPT_EXTRA_HIPCC_FLAGS=-DSCULPT_EXPERIMENTS python tools/gemm_timeline.py [ff1|qkv|plain|o|ff2]
+    SCULPT_EXTRA_HIPCC_FLAGS=-DSCULPT_EXPERIMENTS python tools/gemm_timeline.py [ff1|qkv|plain|o|ff2|l3o|l3ff2|l3qkv|l3ff1]
 
 gemm256_kernel / gemm_bf16_kernel stamp s_memrealtime at entry / first K-tile landed / K loop done / epilogue arithmetic done / exit, and the CU it ran
 on (csrc/gemm.hip, GEMM_STAMP).  Printed: the medians of the four phases, and per CU the order of its workgroups with the gaps
@@ -47,6 +47,18 @@ else:
     N, epi = 8192, 0
     W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(BF)
     bias = None
+L3 = what.startswith("l3")     # the limb GEMM of the tolerance mode (two fp16 limbs): l3o, l3ff2 (+ residual -> fp32), l3qkv, l3ff1 (-> limbs)
+if L3:
+    N, K, epi = {"l3o": (1024, 1024, 0), "l3ff2": (1024, 4096, 0), "l3qkv": (3072, 1024, 0), "l3ff1": (4096, 1024, _lib.EPI_GEGLU)}[what]
+    rows = 2 * N if epi else N
+    Wf = torch.randn(rows, K, device=dev) / math.sqrt(K)
+    A_h = ops.Limbs.of(torch.randn(M, K, device=dev), fmt="f16x2")
+    W_h = ops.Limbs.of(ops.geglu_row_blocks(Wf) if epi else Wf, fmt="f16x2", weight=True)
+    bias = torch.randn(rows, device=dev) * 0.1
+    res = torch.randn(M, N, device=dev) if what in ("l3o", "l3ff2") else None
+    out_lt = ops.Limbs(M, N, dev, fmt="f16x2") if res is None else None
+    stats = None
+    TILE = (64 if epi else 128, 128)
 A = torch.randn(M, K, device=dev).to(BF)
 out = torch.empty(M, N, dtype=BF, device=dev)
 outf = torch.empty(M, N, device=dev) if res is not None else None
@@ -55,7 +67,9 @@ stamps = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
 
 
 def run():
-    if res is not None:
+    if L3:
+        ops.gemm_l3p(A_h, W_h, M, N, K, bias=bias, residual=res, out=outf, out_lt=out_lt, epilogue=epi)
+    elif res is not None:
         ops.gemm(A, W, bias=bias, residual=res, out_f32=outf, out_bf16=out, stats_out=stats)
     else:
         ops.gemm(A, W, bias=bias, out_bf16=out, epilogue=epi)
